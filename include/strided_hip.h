@@ -1,0 +1,224 @@
+/*
+ * strided_hip.h -- C ABI of libstrided_hip.so: the MI355X (gfx950) implementation of
+ * Strided.jl's fused N-ary strided map / map-reduce engine.
+ *
+ * Drop-in boundary.  The reference has no FFI; its single internal
+ * funnel is
+ *     _mapreduce_fuse!(f, op, initop, dims::Dims, arrays::Tuple{Vararg{StridedView}})
+ *                                                   (reference src/mapreduce.jl:98-117)
+ * reached from map! (src/mapreduce.jl:50), broadcast copyto! (src/broadcast.jl:35) and
+ * _mapreducedim! (src/mapreduce.jl:93).  A Julia method specialised on a device-backed
+ * parent array serialises its arguments into an `smr_problem` and `ccall`s `smr_mapreduce`
+ * (binding shown in INTEGRATION.md / julia/StridedHIP.jl).  Plain C: pointers, sizes and
+ * PODs only, no exceptions, no C++ or torch types.
+ *
+ * Conventions
+ *  - Column-major, strides and offsets in ELEMENTS, 0-based:
+ *        element (i_1..i_N), 0 <= i_k < dims[k], of operand j lives at
+ *        ((T*)ops[j].base)[ ops[j].offset + sum_k i_k * ops[j].strides[k] ]
+ *    (the reference's 1-based ParentIndex = offset + 1 + sum (i_k-1)*stride_k,
+ *     src/mapreduce.jl:268).  Strides may be 0 (broadcast / reduced dim,
+ *    src/broadcast.jl:50-65) or negative (reversed ranges).
+ *  - ops[0] is the destination (arrays[1] of the reference), ops[1..M-1] are the inputs.
+ *  - redop == SMR_RED_NONE : pure map, destination overwritten with f(inputs...)
+ *    (kernel body src/mapreduce.jl:310-312).
+ *    redop != NONE : dest[I] = op(dest[I], f(inputs...)) accumulated over every index that
+ *    maps to the same destination element (dims with destination stride 0),
+ *    src/mapreduce.jl:313-316.  The existing destination content takes part, after
+ *    `initop` (if any) was applied to it exactly once (src/mapreduce.jl:351-382,403-409).
+ *  - `conj` on an input: the loaded value is conjugated; on the destination: loads and
+ *    stores conjugate (StridedView.op in {identity, conj}, ParentIndex get/set,
+ *    src/mapreduce.jl:276-278, src/linalg.jl:50).
+ *  - No dimension may be 0 (callers return early: src/mapreduce.jl:48,88-91).
+ *  - All entry points return 0 (SMR_OK) or a negative smr_status; a human-readable
+ *    message for the calling thread's last failure is available from smr_last_error().
+ *    The reference throws DimensionMismatch etc. on the Julia side before the funnel
+ *    (src/mapreduce.jl:43-46, src/broadcast.jl:61); the engine itself never throws.
+ *  - Device pointers must belong to the current HIP device of the calling thread.
+ *    Calls are asynchronous on `stream` (NULL = the null stream); the caller keeps the
+ *    buffers alive until the stream reaches the kernels.
+ */
+#ifndef STRIDED_HIP_H
+#define STRIDED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMR_ABI_VERSION 1
+#define SMR_MAXN 8      /* max rank of the iteration box (reference tests go to N = 6)   */
+#define SMR_MAXM 8      /* max operands including the destination                        */
+#define SMR_MAXPROG 96  /* max instructions in an f-program                              */
+#define SMR_MAXCONST 16 /* max (complex) constants captured by an f-program              */
+
+typedef enum {
+    SMR_OK = 0,
+    SMR_EINVAL = -1,       /* malformed problem (rank, dims, program, null pointers)      */
+    SMR_EUNSUPPORTED = -2, /* valid in the reference but outside the device whitelist ->
+                              the host shim falls back to the CPU method                  */
+    SMR_EHIP = -3,         /* a HIP runtime call failed                                   */
+    SMR_ENOMEM = -4,
+    SMR_ENODEVICE = -5     /* no usable gfx950 device                                     */
+} smr_status;
+
+/* Element types.  Arithmetic is done in one of the four float classes every reference
+ * test-set iterates over (test/othertests.jl:2); integer types are bit-moved by
+ * copy!/permutedims! and may be the destination of counting reductions.              */
+typedef enum {
+    SMR_F32 = 0,
+    SMR_F64 = 1,
+    SMR_C32 = 2, /* ComplexF32: interleaved (re, im) float  */
+    SMR_C64 = 3, /* ComplexF64: interleaved (re, im) double */
+    SMR_I8 = 4,
+    SMR_I16 = 5,
+    SMR_I32 = 6,
+    SMR_I64 = 7,
+    SMR_U8 = 8, /* also Bool */
+    SMR_U16 = 9,
+    SMR_U32 = 10,
+    SMR_U64 = 11,
+    SMR_DTYPE_COUNT = 12
+} smr_dtype;
+
+/* Reduction operator `op` (neutral elements follow _init_reduction!,
+ * src/mapreduce.jl:182-191; the caller pre-fills the destination).                      */
+typedef enum {
+    SMR_RED_NONE = 0,
+    SMR_RED_ADD = 1, /* +, Base.add_sum */
+    SMR_RED_MUL = 2, /* *, Base.mul_prod */
+    SMR_RED_MIN = 3,
+    SMR_RED_MAX = 4
+} smr_redop;
+
+/* `initop`, applied once to each destination element before accumulation.  These are
+ * exactly the five forms the reference exercises (test/othertests.jl:76-102,
+ * src/linalg.jl:146-160).                                                               */
+typedef enum {
+    SMR_INIT_NONE = 0,     /* nothing            */
+    SMR_INIT_IDENTITY = 1, /* identity           */
+    SMR_INIT_ZERO = 2,     /* zero / x -> 0      */
+    SMR_INIT_SCALE = 3,    /* x -> x * beta      (beta = initarg[0] + i*initarg[1])      */
+    SMR_INIT_CONST = 4,    /* x -> beta                                                   */
+    SMR_INIT_CONJ = 5      /* conj                                                        */
+} smr_initop;
+
+/* f-program: the fused N-ary elementwise function f (the CaptureArgs functor tree of
+ * src/broadcast.jl:67-98, or map!'s closure) serialised as postfix code, two bytes per
+ * instruction: {opcode, immediate}.  The program must leave exactly one value.          */
+typedef enum {
+    SMR_OP_ARG = 0,   /* push input #imm (1-based: ops[imm]), conj flag applied           */
+    SMR_OP_CONST = 1, /* push fconsts[2*imm] + i*fconsts[2*imm+1]                         */
+    /* unary: pop 1, push 1 */
+    SMR_OP_NEG = 8,
+    SMR_OP_ABS = 9,
+    SMR_OP_ABS2 = 10,
+    SMR_OP_CONJ = 11,
+    SMR_OP_REAL = 12,
+    SMR_OP_IMAG = 13,
+    SMR_OP_SQRT = 14,
+    SMR_OP_EXP = 15,
+    SMR_OP_LOG = 16,
+    SMR_OP_SIN = 17,
+    SMR_OP_COS = 18,
+    SMR_OP_TANH = 19,
+    SMR_OP_INV = 20,
+    /* binary: pop b, pop a, push a (op) b */
+    SMR_OP_ADD = 32,
+    SMR_OP_SUB = 33,
+    SMR_OP_MUL = 34,
+    SMR_OP_DIV = 35,
+    SMR_OP_MIN = 36,
+    SMR_OP_MAX = 37,
+    SMR_OP_LT = 38, /* comparisons act on real parts and push 1.0 / 0.0                   */
+    SMR_OP_LE = 39,
+    SMR_OP_GT = 40,
+    SMR_OP_GE = 41,
+    SMR_OP_EQ = 42,
+    SMR_OP_NE = 43,
+    /* ternary: pop c, pop b, pop a, push (real(a) != 0 ? b : c)                           */
+    SMR_OP_SELECT = 64
+} smr_opcode;
+
+/* One StridedView operand: (parent, size, strides, offset, op) of the reference's
+ * StridedView (5-argument constructor call src/broadcast.jl:64) minus the shared size.  */
+typedef struct smr_operand {
+    void* base;                /* device pointer to parent[0]                             */
+    int64_t offset;            /* element offset of the view's first element              */
+    int64_t strides[SMR_MAXN]; /* element strides; 0 = broadcast/reduced; may be < 0      */
+    int32_t dtype;             /* smr_dtype                                               */
+    int32_t conj;              /* 0 = identity, 1 = conj                                  */
+} smr_operand;
+
+/* The fully lowered argument list of _mapreduce_fuse! (src/mapreduce.jl:98-99). */
+typedef struct smr_problem {
+    int32_t N;              /* rank of the iteration box, 1..SMR_MAXN                     */
+    int32_t M;              /* operands incl. destination, 2..SMR_MAXM (1 allowed when
+                               the program has no ARG, e.g. fill)                         */
+    int64_t dims[SMR_MAXN]; /* common size of all operands, every entry >= 1             */
+    smr_operand ops[SMR_MAXM];
+    const uint8_t* fprog; /* 2*fprog_len bytes; NULL/0 = identity on ops[1]             */
+    int32_t fprog_len;
+    int32_t nconsts;
+    const double* fconsts; /* 2*nconsts doubles (re, im)                                 */
+    int32_t redop;         /* smr_redop                                                  */
+    int32_t initop;        /* smr_initop, only with redop != NONE                        */
+    double initarg[2];     /* beta for SCALE / CONST                                     */
+    void* stream;          /* hipStream_t, NULL = null stream                            */
+} smr_problem;
+
+typedef struct smr_plan smr_plan; /* opaque: canonicalised problem + chosen kernel */
+
+/* ---- library / device ---------------------------------------------------------------- */
+int smr_abi_version(void);
+/* Bind the calling thread to `device` (>= 0) and create the per-device state.  Replaces
+ * the reference's thread-count configuration (src/Strided.jl:18-35,50-52).             */
+int smr_init(int device);
+int smr_shutdown(void);
+int smr_device_count(void);
+const char* smr_last_error(void);
+/* Device memory for hosts without their own allocator (the Julia shim's HipBuffer).     */
+int smr_malloc(size_t bytes, void** out);
+int smr_free(void* p);
+int smr_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int smr_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int smr_stream_sync(void* stream);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* One-shot replacement of _mapreduce_fuse! (src/mapreduce.jl:98): canonicalise, pick the
+ * kernel family, launch on problem->stream.  Plans are cached per problem signature.    */
+int smr_mapreduce(const smr_problem* problem);
+
+/* Planned form (the planner is the analogue of _mapreduce_order!/_mapreduce_block!/
+ * _computeblocks, src/mapreduce.jl:119-180,452-500, evaluated once and reused).          */
+int smr_plan_create(const smr_problem* problem, smr_plan** out);
+/* `bases` (optional, M entries) rebinds the operand base pointers; NULL keeps the ones the
+ * plan was created with.  `stream` overrides problem->stream.                            */
+int smr_plan_execute(smr_plan* plan, void* const* bases, void* stream);
+int smr_plan_destroy(smr_plan* plan);
+/* Writes a one-line description ("family=tiled tile=32x32 grid=1024 ...") into buf.      */
+int smr_plan_describe(const smr_plan* plan, char* buf, size_t buflen);
+/* Algorithmic bytes of one execution: every distinct operand footprint counted once
+ * (SURVEY.md section 8d).                                                                 */
+int64_t smr_plan_algorithmic_bytes(const smr_plan* plan);
+
+/* Block-partition a problem over `nshards` devices/ranks exactly like the reference's
+ * task bisection splits the iteration box (src/mapreduce.jl:203-222): sub-box `shard`
+ * gets its dims and per-operand offsets in *out.  Pure host arithmetic.  For reductions
+ * whose split dim is a reduced one, *needs_allreduce is set: the caller combines the
+ * per-shard partial destinations with RCCL (ncclAllReduce, op = redop).                  */
+int smr_shard(const smr_problem* problem, int nshards, int shard, smr_problem* out,
+              int* needs_allreduce);
+
+/* Tuning knobs (name = "tile_log2", "block_threads", "force_family", ...); returns
+ * SMR_EINVAL for unknown names.  Analogue of the reference's compile-time constants
+ * MINTHREADLENGTH / BLOCKMEMORYSIZE (src/mapreduce.jl:141,462).                          */
+int smr_set_option(const char* name, int64_t value);
+int64_t smr_get_option(const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRIDED_HIP_H */

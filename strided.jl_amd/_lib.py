@@ -1,0 +1,195 @@
+"""ctypes binding of libstrided_hip.so -- the C ABI declared in include/strided_hip.h.
+
+The HIP library is the only compute path of this package: if it is missing or no gfx950
+device is usable, every compute entry point raises (there is no CPU fallback; the CPU
+restatement under oracle/ is test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+SMR_MAXN = 8
+SMR_MAXM = 8
+SMR_MAXPROG = 96
+SMR_MAXCONST = 16
+
+# smr_status
+SMR_OK, SMR_EINVAL, SMR_EUNSUPPORTED, SMR_EHIP, SMR_ENOMEM, SMR_ENODEVICE = 0, -1, -2, -3, -4, -5
+
+# smr_dtype
+(SMR_F32, SMR_F64, SMR_C32, SMR_C64, SMR_I8, SMR_I16, SMR_I32, SMR_I64,
+ SMR_U8, SMR_U16, SMR_U32, SMR_U64) = range(12)
+
+# smr_redop / smr_initop
+SMR_RED_NONE, SMR_RED_ADD, SMR_RED_MUL, SMR_RED_MIN, SMR_RED_MAX = range(5)
+(SMR_INIT_NONE, SMR_INIT_IDENTITY, SMR_INIT_ZERO, SMR_INIT_SCALE, SMR_INIT_CONST,
+ SMR_INIT_CONJ) = range(6)
+
+# smr_opcode
+OPCODES = dict(
+    ARG=0, CONST=1,
+    NEG=8, ABS=9, ABS2=10, CONJ=11, REAL=12, IMAG=13, SQRT=14, EXP=15, LOG=16, SIN=17, COS=18,
+    TANH=19, INV=20,
+    ADD=32, SUB=33, MUL=34, DIV=35, MIN=36, MAX=37, LT=38, LE=39, GT=40, GE=41, EQ=42, NE=43,
+    SELECT=64,
+)
+
+
+class smr_operand(C.Structure):
+    _fields_ = [
+        ("base", C.c_void_p),
+        ("offset", C.c_int64),
+        ("strides", C.c_int64 * SMR_MAXN),
+        ("dtype", C.c_int32),
+        ("conj", C.c_int32),
+    ]
+
+
+class smr_problem(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("M", C.c_int32),
+        ("dims", C.c_int64 * SMR_MAXN),
+        ("ops", smr_operand * SMR_MAXM),
+        ("fprog", C.POINTER(C.c_uint8)),
+        ("fprog_len", C.c_int32),
+        ("nconsts", C.c_int32),
+        ("fconsts", C.POINTER(C.c_double)),
+        ("redop", C.c_int32),
+        ("initop", C.c_int32),
+        ("initarg", C.c_double * 2),
+        ("stream", C.c_void_p),
+    ]
+
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libstrided_hip.so")
+CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
+
+# every symbol include/strided_hip.h declares
+EXPORTS = [
+    "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
+    "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
+    "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_shard", "smr_set_option",
+    "smr_get_option",
+]
+
+
+class StridedHIPError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libstrided_hip error {code}: {msg}")
+        self.code = code
+
+
+class UnsupportedOnDevice(StridedHIPError):
+    """SMR_EUNSUPPORTED: valid in the reference but outside the device whitelist."""
+
+
+def build(jobs: int | None = None, verbose: bool = False) -> str:
+    """Compile libstrided_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    jobs = jobs or max(1, os.cpu_count() or 1)
+    r = subprocess.run(["make", "-C", CSRC_DIR, f"-j{jobs}"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libstrided_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-8000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950).  strided_jl_amd has no CPU fallback.")
+    try:  # share torch's HIP runtime (same SONAME libamdhip64.so.7) when torch is around
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.smr_last_error.restype = C.c_char_p
+    lib.smr_abi_version.restype = C.c_int
+    lib.smr_init.argtypes = [C.c_int]
+    lib.smr_malloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.smr_free.argtypes = [C.c_void_p]
+    lib.smr_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.smr_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.smr_stream_sync.argtypes = [C.c_void_p]
+    lib.smr_mapreduce.argtypes = [C.POINTER(smr_problem)]
+    lib.smr_plan_create.argtypes = [C.POINTER(smr_problem), C.POINTER(C.c_void_p)]
+    lib.smr_plan_execute.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
+    lib.smr_plan_destroy.argtypes = [C.c_void_p]
+    lib.smr_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.smr_plan_algorithmic_bytes.argtypes = [C.c_void_p]
+    lib.smr_plan_algorithmic_bytes.restype = C.c_int64
+    lib.smr_shard.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.POINTER(smr_problem),
+                              C.POINTER(C.c_int)]
+    lib.smr_set_option.argtypes = [C.c_char_p, C.c_int64]
+    lib.smr_get_option.argtypes = [C.c_char_p]
+    lib.smr_get_option.restype = C.c_int64
+    if lib.smr_abi_version() != 1:
+        raise ImportError("libstrided_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc == SMR_OK:
+        return
+    msg = load().smr_last_error().decode("utf-8", "replace")
+    if rc == SMR_EUNSUPPORTED:
+        raise UnsupportedOnDevice(rc, msg)
+    raise StridedHIPError(rc, msg)
+
+
+def set_option(name: str, value: int):
+    check(load().smr_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    return int(load().smr_get_option(name.encode()))
+
+
+class Plan:
+    """smr_plan handle: canonicalised problem + chosen kernel, reusable across launches."""
+
+    def __init__(self, problem: smr_problem, keepalive=()):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self._keep = (problem, keepalive)
+        check(self._lib.smr_plan_create(C.byref(problem), C.byref(self._h)))
+
+    def execute(self, stream: int | None = None, bases=None):
+        arr = None
+        if bases is not None:
+            arr = (C.c_void_p * len(bases))(*bases)
+        check(self._lib.smr_plan_execute(self._h, arr, C.c_void_p(stream or 0)))
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(1024)
+        check(self._lib.smr_plan_describe(self._h, buf, 1024))
+        return buf.value.decode()
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return int(self._lib.smr_plan_algorithmic_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.smr_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,193 @@
+"""Broadcast lowering -- mirror of /root/reference/src/broadcast.jl.
+
+Julia's dot syntax builds a lazy `Broadcasted(f, args)` tree whose style is resolved to
+`StridedArrayStyle{N}` when every array leaf is a StridedView (src/broadcast.jl:3-18), and
+`copyto!(dest::StridedView, bc)` (src/broadcast.jl:27-37) lowers it onto the map engine:
+
+    stridedargs = promoteshape(size(dest), capturestridedargs(bc)...)
+    c = make_capture(bc)
+    _mapreduce_fuse!(c, nothing, nothing, size(dest), (dest, stridedargs...))
+
+Python has no dot syntax, so the arithmetic operators of StridedView (and the functions in
+fn.py) build the same lazy tree; `dest.assign(bc)` / `dest[...] = bc` is `dest .= bc` and
+`materialize(bc)` is the out-of-place form (allocation via `similar`, src/broadcast.jl:20-22).
+"""
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+
+from . import expr as E
+from .stridedview import DimensionMismatch, StridedView
+
+
+class Broadcasted(E._OpsMixin):
+    """Lazy `Base.Broadcast.Broadcasted{StridedArrayStyle{N}}` node."""
+
+    def __init__(self, f: str, args: tuple):
+        self.f, self.args = f, tuple(args)
+
+    @classmethod
+    def _make(cls, op, *args):
+        for a in args:
+            _check_leaf(a)
+        return Broadcasted(op, args)
+
+    # out-of-place result
+    def materialize(self):
+        return materialize(self)
+
+    def __repr__(self):
+        return f"Broadcasted({self.f}, {self.args})"
+
+
+class Ref:
+    """`Ref(x)`: a wrapped scalar that broadcasts as a 0-dim value (src/broadcast.jl:39,81)."""
+
+    def __init__(self, x):
+        self.x = x
+
+
+def _check_leaf(a):
+    if isinstance(a, (StridedView, Broadcasted, Ref, numbers.Number, np.generic)):
+        return
+    if hasattr(a, "numerator"):
+        return
+    if isinstance(a, np.ndarray) or type(a).__module__.startswith("torch"):
+        # StridedArrayStyle x DefaultArrayStyle -> DefaultArrayStyle (src/broadcast.jl:12-14):
+        # the reference silently falls back to Base's CPU broadcast.  There is no CPU path here.
+        raise TypeError("broadcast mixes a StridedView with a plain array; the reference would fall back to "
+                        "Base broadcasting on the CPU -- wrap the array in StridedView instead")
+    raise TypeError(f"cannot broadcast over {type(a)}")
+
+
+# install the operators on StridedView
+def _sv_make(op, *args):
+    return Broadcasted._make(op, *args)
+
+
+StridedView._make = staticmethod(_sv_make)
+for _name in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__",
+              "__rtruediv__", "__neg__", "__pos__", "__abs__", "__lt__", "__le__", "__gt__", "__ge__"):
+    setattr(StridedView, _name, getattr(E._OpsMixin, _name))
+
+
+# ---- the lowering steps, named as in the reference --------------------------------------------------
+def capturestridedargs(t, *rest):
+    """Depth-first, left-to-right flatten keeping only StridedView leaves (src/broadcast.jl:41-46)."""
+    out = []
+
+    def walk(n):
+        if isinstance(n, Broadcasted):
+            for a in n.args:
+                walk(a)
+        elif isinstance(n, StridedView):
+            out.append(n)
+
+    walk(t)
+    for r in rest:
+        walk(r)
+    return tuple(out)
+
+
+def promoteshape1(sz, a: StridedView) -> StridedView:
+    """Size-1 (or missing trailing) dims become stride 0 (src/broadcast.jl:55-65)."""
+    newstrides = []
+    for d in range(len(sz)):
+        if a._size(d) == sz[d]:
+            newstrides.append(a.stride(d) if d < a.ndim else 0)
+        elif a._size(d) == 1:
+            newstrides.append(0)
+        else:
+            raise DimensionMismatch("array could not be broadcasted to match destination")
+    for d in range(len(sz), a.ndim):
+        if a.size[d] != 1:
+            raise DimensionMismatch("array could not be broadcasted to match destination")
+    return StridedView(a.parent, tuple(sz), tuple(newstrides), a.offset, a.op)
+
+
+def promoteshape(sz, *arrays):
+    return tuple(promoteshape1(sz, a) for a in arrays)
+
+
+def make_capture(bc) -> E.Expr:
+    """`CaptureArgs` tree: StridedView leaves -> positional `Arg()`, Ref/0-dim unwrapped, other
+    scalars captured (src/broadcast.jl:75-83).  Positions follow capturestridedargs' order."""
+    counter = [0]
+
+    def go(n):
+        if isinstance(n, Broadcasted):
+            return E.Call(n.f, tuple(go(a) for a in n.args))
+        if isinstance(n, StridedView):
+            counter[0] += 1
+            return E.Arg(counter[0])
+        if isinstance(n, Ref):
+            return E.as_expr(n.x)
+        return E.as_expr(n)
+
+    return go(bc)
+
+
+def broadcast_shape(bc) -> tuple:
+    """`Broadcast.combine_axes`: trailing dims of lower-rank leaves count as 1."""
+    leaves = capturestridedargs(bc)
+    n = max((a.ndim for a in leaves), default=0)
+    shape = [1] * n
+    for a in leaves:
+        for d in range(a.ndim):
+            if a.size[d] != 1:
+                if shape[d] != 1 and shape[d] != a.size[d]:
+                    raise DimensionMismatch(f"arrays could not be broadcast to a common size: {shape[d]} vs {a.size[d]}")
+                shape[d] = a.size[d]
+    return tuple(shape)
+
+
+def copyto_(dest: StridedView, bc) -> StridedView:
+    """`Base.copyto!(dest::StridedView{<:Any,N}, bc::Broadcasted{StridedArrayStyle{N}})`,
+    src/broadcast.jl:27-37."""
+    from .mapreduce import _mapreduce_fuse_, copy_
+    if isinstance(bc, StridedView):  # dest .= src
+        return copy_(dest, promoteshape1(dest.size, bc))
+    if any(d == 0 for d in dest.size):
+        return dest
+    if isinstance(bc, Ref):
+        bc = bc.x
+    if not isinstance(bc, Broadcasted):  # dest .= scalar: a functor tree without Arg leaves
+        _mapreduce_fuse_(E.as_expr(bc), None, None, dest.size, (dest,))
+        return dest
+    stridedargs = promoteshape(dest.size, *capturestridedargs(bc))
+    c = make_capture(bc)
+    _mapreduce_fuse_(c, None, None, dest.size, (dest,) + stridedargs)
+    return dest
+
+
+def materialize(bc):
+    """Out-of-place broadcast: `similar(bc, T)` then copyto! (src/broadcast.jl:20-22)."""
+    if isinstance(bc, StridedView):
+        from .mapreduce import copy
+        return copy(bc)
+    leaves = capturestridedargs(bc)
+    if not leaves:
+        raise TypeError("materialize needs at least one StridedView operand")
+    c = make_capture(bc)
+    T = E.result_dtype(c, [a.dtype for a in leaves])
+    dest = leaves[0].similar(T, broadcast_shape(bc))
+    return copyto_(dest, bc)
+
+
+def _assign(self: StridedView, bc):
+    return copyto_(self, bc)
+
+
+def _setitem(self: StridedView, idx, value):
+    """`dest[idx...] .= bc`  (dotview, src/broadcast.jl:24)."""
+    if idx is Ellipsis or idx == slice(None):
+        target = self
+    else:
+        target = self.sview(*(idx if isinstance(idx, tuple) else (idx,)))
+    copyto_(target, value)
+
+
+StridedView.assign = _assign
+StridedView.__setitem__ = _setitem

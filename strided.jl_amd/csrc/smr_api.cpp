@@ -1,0 +1,368 @@
+// smr_api.cpp -- the C ABI of libstrided_hip.so (include/strided_hip.h): error reporting,
+// device/memory helpers, plan cache, execution dispatch, sharding.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "smr_dispatch.h"
+
+namespace smr {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+int hip_error(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? SMR_ENOMEM : (e == hipErrorNoDevice ? SMR_ENODEVICE : SMR_EHIP);
+}
+
+// ---- per-type dispatch ---------------------------------------------------------------------------
+#define SMR_DISPATCH_CT(fn)                                                   \
+    switch (plan.c.bitcopy ? SMR_F32 : plan.c.ct) {                           \
+        case SMR_F32: return fn##_ct<SMR_F32>(plan, bases, s);                \
+        case SMR_F64: return fn##_ct<SMR_F64>(plan, bases, s);                \
+        case SMR_C32: return fn##_ct<SMR_C32>(plan, bases, s);                \
+        case SMR_C64: return fn##_ct<SMR_C64>(plan, bases, s);                \
+    }                                                                         \
+    return set_error(SMR_EINVAL, "bad compute class");
+
+int launch_generic_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_generic_map) }
+int launch_stream_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_stream_map) }
+int launch_tiled_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_tiled_map) }
+int launch_reduce_all(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_reduce_all) }
+int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_reduce_part) }
+
+static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
+    switch (plan.family) {
+        case FAM_GENERIC: return launch_generic_map(plan, bases, s);
+        case FAM_STREAM: return launch_stream_map(plan, bases, s);
+        case FAM_TILED: return launch_tiled_map(plan, bases, s);
+        case FAM_REDUCE_ALL: return launch_reduce_all(plan, bases, s);
+        case FAM_REDUCE_PART: return launch_reduce_part(plan, bases, s);
+    }
+    return set_error(SMR_EINVAL, "plan has no kernel family");
+}
+
+static bool g_device_checked = false;
+static int ensure_device() {
+    if (g_device_checked) return SMR_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(SMR_ENODEVICE, "libstrided_hip: no HIP device available (the HIP kernels are the only compute path; there is no CPU fallback)");
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+                return set_error(SMR_ENODEVICE, std::string("libstrided_hip is built for gfx950 only, found ") + prop.gcnArchName);
+        }
+    }
+    g_device_checked = true;
+    return SMR_OK;
+}
+
+}  // namespace smr
+
+using namespace smr;
+
+struct smr_plan {
+    Plan plan;
+    int nops = 0;  // M of the originating problem (length of a `bases` rebinding array)
+    void* stream = nullptr;
+};
+
+static int plan_build(const smr_problem* p, smr_plan** out) {
+    if (!p || !out) return set_error(SMR_EINVAL, "null argument");
+    smr_plan* h = new (std::nothrow) smr_plan();
+    if (!h) return set_error(SMR_ENOMEM, "out of host memory");
+    int rc = make_plan(p, h->plan);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    h->nops = p->M;
+    h->stream = p->stream;
+    *out = h;
+    return SMR_OK;
+}
+
+// reduction partials are allocated on first execution (planning itself needs no device)
+static int ensure_scratch(smr_plan* h) {
+    if (h->plan.scratch || h->plan.scratch_bytes == 0 || h->plan.red_blocks <= 1) return SMR_OK;
+    hipError_t e = hipMalloc(&h->plan.scratch, h->plan.scratch_bytes);
+    if (e != hipSuccess) return hip_error(e, "hipMalloc(reduction partials)");
+    return SMR_OK;
+}
+
+static void plan_free(smr_plan* h) {
+    if (!h) return;
+    if (h->plan.scratch) (void)hipFree(h->plan.scratch);
+    delete h;
+}
+
+// ---- plan cache for the one-shot entry point ---------------------------------------------------------
+namespace {
+struct Cache {
+    std::mutex mu;
+    std::list<std::pair<std::string, smr_plan*>> lru;
+    std::unordered_map<std::string, std::list<std::pair<std::string, smr_plan*>>::iterator> map;
+    static constexpr size_t CAP = 512;
+    uint64_t epoch = 0;  // bumped by smr_set_option: plans depend on the options
+    ~Cache() {}
+};
+Cache& cache() {
+    static Cache* c = new Cache();  // intentionally leaked: no HIP calls at process exit
+    return *c;
+}
+
+std::string signature(const smr_problem* p) {
+    std::string s;
+    auto put = [&](const void* d, size_t n) { s.append((const char*)d, n); };
+    put(&p->N, sizeof p->N);
+    put(&p->M, sizeof p->M);
+    put(p->dims, sizeof(int64_t) * (size_t)p->N);
+    for (int k = 0; k < p->M; ++k) {
+        put(&p->ops[k].base, sizeof(void*));
+        put(&p->ops[k].offset, sizeof(int64_t));
+        put(p->ops[k].strides, sizeof(int64_t) * (size_t)p->N);
+        put(&p->ops[k].dtype, sizeof(int32_t));
+        put(&p->ops[k].conj, sizeof(int32_t));
+    }
+    put(&p->fprog_len, sizeof(int32_t));
+    if (p->fprog && p->fprog_len > 0) put(p->fprog, (size_t)(2 * p->fprog_len));
+    put(&p->nconsts, sizeof(int32_t));
+    if (p->fconsts && p->nconsts > 0) put(p->fconsts, sizeof(double) * (size_t)(2 * p->nconsts));
+    put(&p->redop, sizeof(int32_t));
+    put(&p->initop, sizeof(int32_t));
+    put(p->initarg, sizeof p->initarg);
+    put(&p->stream, sizeof(void*));
+    return s;
+}
+
+void cache_clear_locked(Cache& c) {
+    for (auto& kv : c.lru) plan_free(kv.second);
+    c.lru.clear();
+    c.map.clear();
+}
+}  // namespace
+
+extern "C" {
+
+int smr_abi_version(void) { return SMR_ABI_VERSION; }
+
+const char* smr_last_error(void) { return g_last_error.c_str(); }
+
+int smr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int smr_init(int device) {
+    int n = smr_device_count();
+    if (n <= 0) return set_error(SMR_ENODEVICE, "smr_init: no HIP device");
+    if (device < 0 || device >= n) return set_error(SMR_EINVAL, "smr_init: device index out of range");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_error(e, "hipSetDevice");
+    g_device_checked = false;
+    return ensure_device();
+}
+
+int smr_shutdown(void) {
+    Cache& c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    cache_clear_locked(c);
+    return SMR_OK;
+}
+
+int smr_malloc(size_t bytes, void** out) {
+    if (!out) return set_error(SMR_EINVAL, "null out");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    return e == hipSuccess ? SMR_OK : hip_error(e, "hipMalloc");
+}
+int smr_free(void* p) {
+    hipError_t e = hipFree(p);
+    return e == hipSuccess ? SMR_OK : hip_error(e, "hipFree");
+}
+int smr_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? SMR_OK : hip_error(e, "hipMemcpyAsync(h2d)");
+}
+int smr_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return e == hipSuccess ? SMR_OK : hip_error(e, "hipMemcpyAsync(d2h)");
+}
+int smr_stream_sync(void* stream) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? SMR_OK : hip_error(e, "hipStreamSynchronize");
+}
+
+int smr_plan_create(const smr_problem* problem, smr_plan** out) {
+    // planning is pure host arithmetic; the device is only required to execute (or to
+    // allocate reduction scratch)
+    return plan_build(problem, out);
+}
+
+int smr_plan_execute(smr_plan* plan, void* const* bases, void* stream) {
+    if (!plan) return set_error(SMR_EINVAL, "null plan");
+    int rc = ensure_device();
+    if (rc) return rc;
+    rc = ensure_scratch(plan);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)(stream ? stream : plan->stream);
+    return execute(plan->plan, bases, s);
+}
+
+int smr_plan_destroy(smr_plan* plan) {
+    plan_free(plan);
+    return SMR_OK;
+}
+
+int smr_plan_describe(const smr_plan* plan, char* buf, size_t buflen) {
+    if (!plan || !buf || buflen == 0) return set_error(SMR_EINVAL, "null argument");
+    std::snprintf(buf, buflen, "%s", plan->plan.desc.c_str());
+    return SMR_OK;
+}
+
+int64_t smr_plan_algorithmic_bytes(const smr_plan* plan) { return plan ? plan->plan.c.algbytes : 0; }
+
+int smr_mapreduce(const smr_problem* problem) {
+    if (!problem) return set_error(SMR_EINVAL, "null problem");
+    if (problem->N < 1 || problem->N > SMR_MAXN || problem->M < 1 || problem->M > SMR_MAXM)
+        return set_error(SMR_EINVAL, "rank / operand count out of range");
+    int rc = ensure_device();
+    if (rc) return rc;
+    Cache& c = cache();
+    std::string key = signature(problem);
+    smr_plan* h = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        auto it = c.map.find(key);
+        if (it != c.map.end()) {
+            c.lru.splice(c.lru.begin(), c.lru, it->second);
+            h = it->second->second;
+        }
+    }
+    if (!h) {
+        rc = plan_build(problem, &h);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> g(c.mu);
+        c.lru.emplace_front(key, h);
+        c.map[key] = c.lru.begin();
+        if (c.lru.size() > Cache::CAP) {
+            auto& last = c.lru.back();
+            // the evicted plan's scratch may still be in use by queued kernels of its stream
+            (void)hipStreamSynchronize((hipStream_t)last.second->stream);
+            plan_free(last.second);
+            c.map.erase(last.first);
+            c.lru.pop_back();
+        }
+    }
+    rc = ensure_scratch(h);
+    if (rc) return rc;
+    return execute(h->plan, nullptr, (hipStream_t)problem->stream);
+}
+
+int smr_shard(const smr_problem* p, int nshards, int shard, smr_problem* out, int* needs_allreduce) {
+    if (!p || !out) return set_error(SMR_EINVAL, "null argument");
+    if (nshards < 1 || shard < 0 || shard >= nshards) return set_error(SMR_EINVAL, "bad shard index");
+    if (p->N < 1 || p->N > SMR_MAXN || p->M < 1 || p->M > SMR_MAXM) return set_error(SMR_EINVAL, "bad N/M");
+    *out = *p;
+    if (needs_allreduce) *needs_allreduce = 0;
+    if (nshards == 1) return SMR_OK;
+    // Split dim: the slowest-varying destination dim that is long enough (destination slabs
+    // are then disjoint and contiguous-ish); for reductions prefer a kept dim so that no
+    // exchange is needed -- the same race-freedom rule as src/mapreduce.jl:172-177.  Only when
+    // no kept dim is long enough split a reduced dim and combine partials afterwards, like
+    // the reference's complete-reduction branch (:153-170).
+    int best = -1;
+    int64_t beststride = -1;
+    for (int i = 0; i < p->N; ++i) {
+        int64_t s = p->ops[0].strides[i] < 0 ? -p->ops[0].strides[i] : p->ops[0].strides[i];
+        if (s != 0 && p->dims[i] >= nshards && s > beststride) {
+            best = i;
+            beststride = s;
+        }
+    }
+    int allred = 0;
+    if (best < 0) {
+        if (p->redop == SMR_RED_NONE) {
+            // tiny map: give everything to shard 0, empty work elsewhere is not expressible
+            // (dims >= 1), so fall back to the longest dim
+            for (int i = 0; i < p->N; ++i)
+                if (best < 0 || p->dims[i] > p->dims[best]) best = i;
+            if (p->dims[best] < nshards) return set_error(SMR_EUNSUPPORTED, "box too small to shard");
+        } else {
+            int64_t bs = -1;
+            for (int i = 0; i < p->N; ++i) {
+                if (p->ops[0].strides[i] != 0 || p->dims[i] < nshards) continue;
+                int64_t s = 0;
+                for (int k = 1; k < p->M; ++k) {
+                    int64_t v = p->ops[k].strides[i] < 0 ? -p->ops[k].strides[i] : p->ops[k].strides[i];
+                    s = std::max(s, v);
+                }
+                if (s > bs) {
+                    bs = s;
+                    best = i;
+                }
+            }
+            if (best < 0) return set_error(SMR_EUNSUPPORTED, "box too small to shard");
+            allred = 1;
+        }
+    }
+    const int64_t d = p->dims[best];
+    const int64_t start = d * shard / nshards, end = d * (shard + 1) / nshards;
+    out->dims[best] = end - start;
+    for (int k = 0; k < p->M; ++k) out->ops[k].offset = p->ops[k].offset + start * p->ops[k].strides[best];
+    if (allred && shard != 0) out->initop = SMR_INIT_NONE;  // initop is applied once, on shard 0
+    if (needs_allreduce) *needs_allreduce = allred;
+    return SMR_OK;
+}
+
+int smr_set_option(const char* name, int64_t value) {
+    if (!name) return set_error(SMR_EINVAL, "null option name");
+    Options& o = options();
+    std::string n(name);
+    bool ok = true;
+    if (n == "force_family") o.force_family = value;
+    else if (n == "tile_log2") o.tile_log2 = value;
+    else if (n == "block_threads") o.block_threads = value;
+    else if (n == "stream_unroll") o.stream_unroll = value;
+    else if (n == "xcd_swizzle") o.xcd_swizzle = value;
+    else if (n == "max_lds_bytes") o.max_lds_bytes = value;
+    else if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') o.tile_lg[n[7] - '0'] = value;
+    else ok = false;
+    if (!ok) return set_error(SMR_EINVAL, "unknown option " + n);
+    Cache& c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    (void)hipDeviceSynchronize();
+    cache_clear_locked(c);
+    return SMR_OK;
+}
+
+int64_t smr_get_option(const char* name) {
+    if (!name) return -1;
+    const Options& o = options();
+    std::string n(name);
+    if (n == "force_family") return o.force_family;
+    if (n == "tile_log2") return o.tile_log2;
+    if (n == "block_threads") return o.block_threads;
+    if (n == "stream_unroll") return o.stream_unroll;
+    if (n == "xcd_swizzle") return o.xcd_swizzle;
+    if (n == "max_lds_bytes") return o.max_lds_bytes;
+    if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') return o.tile_lg[n[7] - '0'];
+    return -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,393 @@
+// smr_device.h -- device-side building blocks: element types, loads/stores with the
+// StridedView `op` (identity/conj) applied, the fused elementwise functors and the
+// wave-uniform f-program interpreter.  gfx950 only (wave64).
+//
+// Compiled with -ffp-contract=off: Julia never contracts (a+b)/2 or c*x+y into FMAs, and
+// the map results must match the reference bit-for-bit for + - * / (SURVEY section 7).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "smr_internal.h"
+
+namespace smr {
+
+#define SMR_DEV __device__ __forceinline__
+
+template <class R>
+struct alignas(2 * sizeof(R)) cplx {
+    R re, im;
+};
+typedef cplx<float> c32;
+typedef cplx<double> c64;
+
+// opaque movers for bit copies of 1- and 2-byte integers
+struct b8 {
+    uint8_t v;
+};
+struct b16 {
+    uint16_t v;
+};
+
+template <class T> struct tr;
+template <> struct tr<float> { typedef float real; static constexpr bool cx = false; static constexpr bool arith = true; static constexpr int dt = SMR_F32; };
+template <> struct tr<double> { typedef double real; static constexpr bool cx = false; static constexpr bool arith = true; static constexpr int dt = SMR_F64; };
+template <> struct tr<c32> { typedef float real; static constexpr bool cx = true; static constexpr bool arith = true; static constexpr int dt = SMR_C32; };
+template <> struct tr<c64> { typedef double real; static constexpr bool cx = true; static constexpr bool arith = true; static constexpr int dt = SMR_C64; };
+template <> struct tr<b8> { typedef float real; static constexpr bool cx = false; static constexpr bool arith = false; static constexpr int dt = SMR_U8; };
+template <> struct tr<b16> { typedef float real; static constexpr bool cx = false; static constexpr bool arith = false; static constexpr int dt = SMR_U16; };
+
+// ---- construction / parts ----------------------------------------------------------------
+template <class T> SMR_DEV T mk(typename tr<T>::real re, typename tr<T>::real im);
+template <> SMR_DEV float mk<float>(float re, float) { return re; }
+template <> SMR_DEV double mk<double>(double re, double) { return re; }
+template <> SMR_DEV c32 mk<c32>(float re, float im) { return c32{re, im}; }
+template <> SMR_DEV c64 mk<c64>(double re, double im) { return c64{re, im}; }
+
+SMR_DEV float re_(float x) { return x; }
+SMR_DEV double re_(double x) { return x; }
+template <class R> SMR_DEV R re_(cplx<R> x) { return x.re; }
+SMR_DEV float im_(float) { return 0.f; }
+SMR_DEV double im_(double) { return 0.; }
+template <class R> SMR_DEV R im_(cplx<R> x) { return x.im; }
+
+SMR_DEV float cj(float x) { return x; }
+SMR_DEV double cj(double x) { return x; }
+template <class R> SMR_DEV cplx<R> cj(cplx<R> x) { return cplx<R>{x.re, -x.im}; }
+SMR_DEV b8 cj(b8 x) { return x; }
+SMR_DEV b16 cj(b16 x) { return x; }
+
+// ---- arithmetic (complex: Julia's plain 4-multiply product, Base complex.jl) -------------
+template <class R> SMR_DEV cplx<R> operator+(cplx<R> a, cplx<R> b) { return cplx<R>{a.re + b.re, a.im + b.im}; }
+template <class R> SMR_DEV cplx<R> operator-(cplx<R> a, cplx<R> b) { return cplx<R>{a.re - b.re, a.im - b.im}; }
+template <class R> SMR_DEV cplx<R> operator-(cplx<R> a) { return cplx<R>{-a.re, -a.im}; }
+template <class R> SMR_DEV cplx<R> operator*(cplx<R> a, cplx<R> b) {
+    return cplx<R>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+template <class R> SMR_DEV cplx<R> operator/(cplx<R> a, cplx<R> b) {
+    // scaled (Smith) division: avoids overflow of |b|^2
+    if (fabs(b.re) >= fabs(b.im)) {
+        R r = b.im / b.re, den = b.re + b.im * r;
+        return cplx<R>{(a.re + a.im * r) / den, (a.im - a.re * r) / den};
+    } else {
+        R r = b.re / b.im, den = b.re * r + b.im;
+        return cplx<R>{(a.re * r + a.im) / den, (a.im * r - a.re) / den};
+    }
+}
+
+template <class T> struct mathx;  // unary / binary ops of the f-program per compute type
+
+template <class R>
+struct mathx_real {
+    static SMR_DEV R un(int op, R a) {
+        switch (op) {
+            case SMR_OP_NEG: return -a;
+            case SMR_OP_ABS: return fabs(a);
+            case SMR_OP_ABS2: return a * a;
+            case SMR_OP_CONJ: return a;
+            case SMR_OP_REAL: return a;
+            case SMR_OP_IMAG: return R(0);
+            case SMR_OP_SQRT: return sqrt(a);
+            case SMR_OP_EXP: return exp(a);
+            case SMR_OP_LOG: return log(a);
+            case SMR_OP_SIN: return sin(a);
+            case SMR_OP_COS: return cos(a);
+            case SMR_OP_TANH: return tanh(a);
+            case SMR_OP_INV: return R(1) / a;
+        }
+        return a;
+    }
+    static SMR_DEV R bin(int op, R a, R b) {
+        switch (op) {
+            case SMR_OP_ADD: return a + b;
+            case SMR_OP_SUB: return a - b;
+            case SMR_OP_MUL: return a * b;
+            case SMR_OP_DIV: return a / b;
+            case SMR_OP_MIN: return (b < a) ? b : a;
+            case SMR_OP_MAX: return (a < b) ? b : a;
+            case SMR_OP_LT: return a < b ? R(1) : R(0);
+            case SMR_OP_LE: return a <= b ? R(1) : R(0);
+            case SMR_OP_GT: return a > b ? R(1) : R(0);
+            case SMR_OP_GE: return a >= b ? R(1) : R(0);
+            case SMR_OP_EQ: return a == b ? R(1) : R(0);
+            case SMR_OP_NE: return a != b ? R(1) : R(0);
+        }
+        return a;
+    }
+    static SMR_DEV bool truthy(R a) { return a != R(0); }
+};
+template <> struct mathx<float> : mathx_real<float> {};
+template <> struct mathx<double> : mathx_real<double> {};
+
+template <class R>
+struct mathx_cx {
+    typedef cplx<R> T;
+    static SMR_DEV T csqrt(T a) {
+        R r = hypot(a.re, a.im);
+        if (r == R(0)) return T{R(0), a.im};
+        if (a.re >= R(0)) {
+            R t = sqrt((r + a.re) * R(0.5));
+            return T{t, a.im / (t + t)};
+        }
+        R t = sqrt((r - a.re) * R(0.5));
+        return T{fabs(a.im) / (t + t), copysign(t, a.im)};
+    }
+    static SMR_DEV T un(int op, T a) {
+        switch (op) {
+            case SMR_OP_NEG: return -a;
+            case SMR_OP_ABS: return T{hypot(a.re, a.im), R(0)};
+            case SMR_OP_ABS2: return T{a.re * a.re + a.im * a.im, R(0)};
+            case SMR_OP_CONJ: return T{a.re, -a.im};
+            case SMR_OP_REAL: return T{a.re, R(0)};
+            case SMR_OP_IMAG: return T{a.im, R(0)};
+            case SMR_OP_SQRT: return csqrt(a);
+            case SMR_OP_EXP: {
+                R e = exp(a.re);
+                return T{e * cos(a.im), e * sin(a.im)};
+            }
+            case SMR_OP_LOG: return T{log(hypot(a.re, a.im)), atan2(a.im, a.re)};
+            case SMR_OP_SIN: return T{sin(a.re) * cosh(a.im), cos(a.re) * sinh(a.im)};
+            case SMR_OP_COS: return T{cos(a.re) * cosh(a.im), -sin(a.re) * sinh(a.im)};
+            case SMR_OP_TANH: {
+                R x2 = a.re + a.re, y2 = a.im + a.im;
+                R den = cosh(x2) + cos(y2);
+                return T{sinh(x2) / den, sin(y2) / den};
+            }
+            case SMR_OP_INV: return T{R(1), R(0)} / a;
+        }
+        return a;
+    }
+    static SMR_DEV T bin(int op, T a, T b) {
+        switch (op) {
+            case SMR_OP_ADD: return a + b;
+            case SMR_OP_SUB: return a - b;
+            case SMR_OP_MUL: return a * b;
+            case SMR_OP_DIV: return a / b;
+            case SMR_OP_MIN: return (b.re < a.re) ? b : a;
+            case SMR_OP_MAX: return (a.re < b.re) ? b : a;
+            case SMR_OP_LT: return T{a.re < b.re ? R(1) : R(0), R(0)};
+            case SMR_OP_LE: return T{a.re <= b.re ? R(1) : R(0), R(0)};
+            case SMR_OP_GT: return T{a.re > b.re ? R(1) : R(0), R(0)};
+            case SMR_OP_GE: return T{a.re >= b.re ? R(1) : R(0), R(0)};
+            case SMR_OP_EQ: return T{(a.re == b.re && a.im == b.im) ? R(1) : R(0), R(0)};
+            case SMR_OP_NE: return T{(a.re != b.re || a.im != b.im) ? R(1) : R(0), R(0)};
+        }
+        return a;
+    }
+    static SMR_DEV bool truthy(T a) { return a.re != R(0); }
+};
+template <> struct mathx<c32> : mathx_cx<float> {};
+template <> struct mathx<c64> : mathx_cx<double> {};
+
+// ---- loads / stores ------------------------------------------------------------------------
+// Typed fast path: the operand's dtype is the compute type.
+template <class T>
+SMR_DEV T ld(const void* base, i64 idx) {
+    return ((const T*)base)[idx];
+}
+template <class T>
+SMR_DEV void st(void* base, i64 idx, T v) {
+    ((T*)base)[idx] = v;
+}
+// Mixed path: convert from/to the operand's own dtype (wave-uniform switch).
+template <class T>
+SMR_DEV T ld_as(const void* base, i64 idx, int dt) {
+    typedef typename tr<T>::real R;
+    switch (dt) {
+        case SMR_F32: return mk<T>(R(((const float*)base)[idx]), R(0));
+        case SMR_F64: return mk<T>(R(((const double*)base)[idx]), R(0));
+        case SMR_C32: { c32 v = ((const c32*)base)[idx]; return mk<T>(R(v.re), R(v.im)); }
+        case SMR_C64: { c64 v = ((const c64*)base)[idx]; return mk<T>(R(v.re), R(v.im)); }
+        case SMR_I8: return mk<T>(R(((const int8_t*)base)[idx]), R(0));
+        case SMR_U8: return mk<T>(R(((const uint8_t*)base)[idx]), R(0));
+        case SMR_I16: return mk<T>(R(((const int16_t*)base)[idx]), R(0));
+        case SMR_U16: return mk<T>(R(((const uint16_t*)base)[idx]), R(0));
+        case SMR_I32: return mk<T>(R(((const int32_t*)base)[idx]), R(0));
+        case SMR_U32: return mk<T>(R(((const uint32_t*)base)[idx]), R(0));
+        case SMR_I64: return mk<T>(R(((const long long*)base)[idx]), R(0));
+        case SMR_U64: return mk<T>(R(((const unsigned long long*)base)[idx]), R(0));
+    }
+    return mk<T>(R(0), R(0));
+}
+template <class T>
+SMR_DEV void st_as(void* base, i64 idx, int dt, T v) {
+    auto re = re_(v);
+    auto im = im_(v);
+    switch (dt) {
+        case SMR_F32: ((float*)base)[idx] = (float)re; break;
+        case SMR_F64: ((double*)base)[idx] = (double)re; break;
+        case SMR_C32: ((c32*)base)[idx] = c32{(float)re, (float)im}; break;
+        case SMR_C64: ((c64*)base)[idx] = c64{(double)re, (double)im}; break;
+        case SMR_I8: ((int8_t*)base)[idx] = (int8_t)llrint((double)re); break;
+        case SMR_U8: ((uint8_t*)base)[idx] = (uint8_t)llrint((double)re); break;
+        case SMR_I16: ((int16_t*)base)[idx] = (int16_t)llrint((double)re); break;
+        case SMR_U16: ((uint16_t*)base)[idx] = (uint16_t)llrint((double)re); break;
+        case SMR_I32: ((int32_t*)base)[idx] = (int32_t)llrint((double)re); break;
+        case SMR_U32: ((uint32_t*)base)[idx] = (uint32_t)llrint((double)re); break;
+        case SMR_I64: ((long long*)base)[idx] = (long long)llrint((double)re); break;
+        case SMR_U64: ((unsigned long long*)base)[idx] = (unsigned long long)llrint((double)re); break;
+    }
+}
+
+// Operand table passed to every kernel by value.
+struct OpTab {
+    void* base[MAXM];   // base pointer with the element offset already applied
+    int32_t dtype[MAXM];
+    int32_t conj[MAXM];
+};
+
+template <class T, bool MIXED>
+SMR_DEV T load_op(const OpTab& t, int k, i64 idx) {
+    T v;
+    if constexpr (MIXED)
+        v = ld_as<T>(t.base[k], idx, t.dtype[k]);
+    else
+        v = ld<T>(t.base[k], idx);
+    if constexpr (tr<T>::cx) {
+        if (t.conj[k]) v = cj(v);
+    }
+    return v;
+}
+template <class T, bool MIXED>
+SMR_DEV void store_op(const OpTab& t, i64 idx, T v) {
+    if constexpr (tr<T>::cx) {
+        if (t.conj[0]) v = cj(v);
+    }
+    if constexpr (MIXED)
+        st_as<T>(t.base[0], idx, t.dtype[0], v);
+    else
+        st<T>(t.base[0], idx, v);
+}
+
+// ---- functors: f(a[0..NIN-1]) ---------------------------------------------------------------
+// NIN < 0 means "runtime" (interpreter).  Constants come from Canon::fc.
+template <class T> struct FIdent {
+    static constexpr int NIN = 1;
+    SMR_DEV T operator()(const T* a) const { return a[0]; }
+};
+template <class T> struct FAdd2 {
+    static constexpr int NIN = 2;
+    SMR_DEV T operator()(const T* a) const { return a[0] + a[1]; }
+};
+template <class T> struct FAdd3 {
+    static constexpr int NIN = 3;
+    SMR_DEV T operator()(const T* a) const { return (a[0] + a[1]) + a[2]; }
+};
+template <class T> struct FAdd4 {
+    static constexpr int NIN = 4;
+    SMR_DEV T operator()(const T* a) const { return ((a[0] + a[1]) + a[2]) + a[3]; }
+};
+template <class T> struct FScale {
+    static constexpr int NIN = 1;
+    T c;
+    SMR_DEV T operator()(const T* a) const { return a[0] * c; }
+};
+template <class T> struct FSym {
+    static constexpr int NIN = 2;
+    T c;
+    SMR_DEV T operator()(const T* a) const { return (a[0] + a[1]) / c; }
+};
+template <class T> struct FAxpy {
+    static constexpr int NIN = 2;
+    T c;
+    SMR_DEV T operator()(const T* a) const { return c * a[0] + a[1]; }
+};
+template <class T> struct FAxpby {
+    static constexpr int NIN = 2;
+    T c, d;
+    SMR_DEV T operator()(const T* a) const { return c * a[0] + d * a[1]; }
+};
+template <class T> struct FAbs2 {
+    static constexpr int NIN = 1;
+    SMR_DEV T operator()(const T* a) const { return mathx<T>::un(SMR_OP_ABS2, a[0]); }
+};
+template <class T> struct FMul2 {
+    static constexpr int NIN = 2;
+    SMR_DEV T operator()(const T* a) const { return a[0] * a[1]; }
+};
+template <class T> struct FExpr5 {  // a*exp(c*a) + sin(a*a), real types only
+    static constexpr int NIN = 1;
+    T c;
+    SMR_DEV T operator()(const T* a) const {
+        T x = a[0];
+        return x * exp(c * x) + sin(x * x);
+    }
+};
+
+// Bytecode interpreter.  The program is wave-uniform, so every branch below is a scalar
+// branch; the value stack lives in registers and is rotated on push/pop so that every
+// register index is static (runtime-indexed arrays would be demoted to scratch memory).
+template <class T> struct FProg {
+    static constexpr int NIN = -1;
+    ProgD p;
+    SMR_DEV T operator()(const T* a) const {
+        typedef typename tr<T>::real R;
+        T s0 = mk<T>(R(0), R(0)), s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0, s6 = s0, s7 = s0;
+        const int n = p.len;
+        for (int pc = 0; pc < n; ++pc) {
+            const int op = p.code[2 * pc], imm = p.code[2 * pc + 1];
+            if (op <= SMR_OP_CONST) {
+                T v;
+                if (op == SMR_OP_ARG) {
+                    v = a[0];
+#pragma unroll
+                    for (int k = 1; k < MAXIN; ++k)
+                        if (imm == k + 1) v = a[k];
+                } else {
+                    v = mk<T>(R(p.consts[2 * imm]), R(p.consts[2 * imm + 1]));
+                }
+                s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+            } else if (op < 32) {
+                s0 = mathx<T>::un(op, s0);
+            } else if (op < 64) {
+                s0 = mathx<T>::bin(op, s1, s0);
+                s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+            } else {  // SELECT: a ? b : c with a=s2, b=s1, c=s0
+                s0 = mathx<T>::truthy(s2) ? s1 : s0;
+                s1 = s3; s2 = s4; s3 = s5; s4 = s6; s5 = s7;
+            }
+        }
+        return s0;
+    }
+};
+
+// reduction operator / initop (wave-uniform switches)
+template <class T>
+SMR_DEV T red_apply(int op, T a, T b) {
+    if constexpr (tr<T>::arith) {
+        switch (op) {
+            case SMR_RED_ADD: return a + b;
+            case SMR_RED_MUL: return a * b;
+            case SMR_RED_MIN: return mathx<T>::bin(SMR_OP_MIN, a, b);
+            case SMR_RED_MAX: return mathx<T>::bin(SMR_OP_MAX, a, b);
+        }
+    }
+    return b;
+}
+template <class T>
+SMR_DEV T init_apply(int op, T x, T beta) {
+    typedef typename tr<T>::real R;
+    switch (op) {
+        case SMR_INIT_ZERO: return mk<T>(R(0), R(0));
+        case SMR_INIT_SCALE: return x * beta;
+        case SMR_INIT_CONST: return beta;
+        case SMR_INIT_CONJ: return cj(x);
+    }
+    return x;
+}
+
+// wave64 shuffle of arbitrary POD (by 32-bit words)
+template <class T>
+SMR_DEV T shfl_xor_any(T v, int mask) {
+    static_assert(sizeof(T) % 4 == 0, "word multiple");
+    union {
+        T t;
+        int w[sizeof(T) / 4];
+    } u;
+    u.t = v;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) u.w[i] = __shfl_xor(u.w[i], mask, 64);
+    return u.t;
+}
+
+}  // namespace smr

@@ -1,0 +1,85 @@
+// smr_dispatch.h -- compile-time dispatch helpers shared by the kernel translation units.
+//
+// Every kernel family is a template over <compute type T, functor F, MIXED>.  Each family's
+// .hip file is compiled once per compute type (-DSMR_CT=0..3) so the instantiation matrix
+// builds in parallel; the per-type entry points are the explicit specialisations of
+// launch_<family>_ct<CT>.
+#pragma once
+
+#include <algorithm>
+#include <cstring>
+
+#include "smr_device.h"
+
+namespace smr {
+
+template <int CT> struct ct_type;
+template <> struct ct_type<SMR_F32> { typedef float type; };
+template <> struct ct_type<SMR_F64> { typedef double type; };
+template <> struct ct_type<SMR_C32> { typedef c32 type; };
+template <> struct ct_type<SMR_C64> { typedef c64 type; };
+
+template <class T> inline T hostmk(double re, double im);
+template <> inline float hostmk<float>(double re, double) { return (float)re; }
+template <> inline double hostmk<double>(double re, double) { return re; }
+template <> inline c32 hostmk<c32>(double re, double im) { return c32{(float)re, (float)im}; }
+template <> inline c64 hostmk<c64>(double re, double im) { return c64{re, im}; }
+
+constexpr unsigned fbit(int k) { return 1u << k; }
+constexpr unsigned FMASK_ALL = 0xffffffffu;
+
+// Calls fn(functor) with the natively compiled functor for c.fkind when `mask` allows it,
+// otherwise with the bytecode interpreter.
+template <class T, class Fn>
+int with_functor(const Canon& c, unsigned mask, Fn&& fn) {
+    const int k = (mask & fbit(c.fkind)) ? c.fkind : FK_PROG;
+    switch (k) {
+        case FK_IDENT: return fn(FIdent<T>{});
+        case FK_ADD2: return fn(FAdd2<T>{});
+        case FK_ADD3: return fn(FAdd3<T>{});
+        case FK_ADD4: return fn(FAdd4<T>{});
+        case FK_SCALE: return fn(FScale<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_SYM: return fn(FSym<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_AXPY: return fn(FAxpy<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_AXPBY: return fn(FAxpby<T>{hostmk<T>(c.fc[0], c.fc[1]), hostmk<T>(c.fc[2], c.fc[3])});
+        case FK_ABS2: return fn(FAbs2<T>{});
+        case FK_MUL2: return fn(FMul2<T>{});
+        case FK_EXPR5:
+            if constexpr (!tr<T>::cx) return fn(FExpr5<T>{hostmk<T>(c.fc[0], 0)});
+            break;
+        default: break;
+    }
+    return fn(FProg<T>{c.prog});
+}
+
+// Per-type launch entry points (explicitly specialised in the -DSMR_CT objects).
+template <int CT> int launch_generic_map_ct(const Plan&, void* const*, hipStream_t);
+template <int CT> int launch_stream_map_ct(const Plan&, void* const*, hipStream_t);
+template <int CT> int launch_tiled_map_ct(const Plan&, void* const*, hipStream_t);
+template <int CT> int launch_reduce_all_ct(const Plan&, void* const*, hipStream_t);
+template <int CT> int launch_reduce_part_ct(const Plan&, void* const*, hipStream_t);
+
+// Fills the kernel operand table: base pointers with the element offset folded in.
+inline OpTab make_optab(const Canon& c, void* const* bases) {
+    OpTab t;
+    for (int k = 0; k < MAXM; ++k) {
+        t.base[k] = nullptr;
+        t.dtype[k] = 0;
+        t.conj[k] = 0;
+    }
+    for (int k = 0; k < c.M; ++k) {
+        char* b = (char*)(bases ? bases[c.orig[k]] : c.base[k]);
+        t.base[k] = b + c.offsets[k] * (i64)c.esize[k];
+        t.dtype[k] = c.dtype[k];
+        t.conj[k] = c.conj[k];
+    }
+    return t;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_error(e, what);
+    return SMR_OK;
+}
+
+}  // namespace smr

@@ -1,0 +1,152 @@
+// smr_internal.h -- host-side structures shared by the planner, the C ABI and the kernel
+// launchers of libstrided_hip.so.  Not part of the public ABI (that is include/strided_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/strided_hip.h"
+
+namespace smr {
+
+typedef int64_t i64;
+constexpr int MAXN = SMR_MAXN;
+constexpr int MAXM = SMR_MAXM;
+constexpr int MAXIN = SMR_MAXM - 1;
+constexpr int STACK = 8;  // device evaluator stack depth (register-rotated)
+
+int set_error(int code, const std::string& msg);  // returns code
+int hip_error(hipError_t e, const char* what);
+
+inline int dtype_size(int dt) {
+    switch (dt) {
+        case SMR_F32: return 4;
+        case SMR_F64: return 8;
+        case SMR_C32: return 8;
+        case SMR_C64: return 16;
+        case SMR_I8: case SMR_U8: return 1;
+        case SMR_I16: case SMR_U16: return 2;
+        case SMR_I32: case SMR_U32: return 4;
+        case SMR_I64: case SMR_U64: return 8;
+    }
+    return 0;
+}
+
+// f-program as passed to kernels by value (lands in SGPRs / scalar cache: it is
+// wave-uniform, so the interpreter's control flow never diverges).
+struct ProgD {
+    int32_t len;
+    int32_t nconst;
+    uint8_t code[2 * SMR_MAXPROG];
+    double consts[2 * SMR_MAXCONST];
+};
+
+// Recognised shapes of f that have a natively compiled functor (smr_device.h).
+enum FKind : int {
+    FK_PROG = 0,   // bytecode interpreter
+    FK_IDENT = 1,  // a1                      copy!/permutedims!  (src/mapreduce.jl:2-14)
+    FK_ADD2 = 2,   // a1 + a2
+    FK_ADD3 = 3,   // (a1 + a2) + a3
+    FK_ADD4 = 4,   // ((a1 + a2) + a3) + a4   README 4-way permuted sum
+    FK_SCALE = 5,  // a1 * c  (== c * a1 bitwise for IEEE)          mul!/rmul!/lmul!
+    FK_SYM = 6,    // (a1 + a2) / c           README symmetrise
+    FK_AXPY = 7,   // c * a1 + a2                                    axpy!
+    FK_AXPBY = 8,  // c * a1 + d * a2                                axpby!
+    FK_ABS2 = 9,   // abs2(a1)                                       mapreduce(abs2, +, A)
+    FK_MUL2 = 10,  // a1 * a2                                        __mul! (src/linalg.jl:130)
+    FK_EXPR5 = 11, // a1*exp(c*a1) + sin(a1*a1), c real             README compute-bound map
+    FK_COUNT
+};
+
+enum Family : int {
+    FAM_AUTO = 0,
+    FAM_GENERIC = 1,  // one thread per element, index decomposition (any strides)
+    FAM_STREAM = 2,   // every operand unit-stride (or broadcast) along the fast dim
+    FAM_TILED = 3,    // LDS-staged: operands with different unit-stride axes
+    FAM_REDUCE_ALL = 4,
+    FAM_REDUCE_PART = 5
+};
+
+// Canonical problem: size-1 dims dropped, dims sorted (kept dims by destination stride,
+// then reduced dims), destination strides made positive, jointly contiguous dims fused,
+// identical inputs deduplicated.  GPU analogue of _mapreduce_fuse! + _mapreduce_order!
+// (reference src/mapreduce.jl:98-139).
+struct Canon {
+    int N = 0, M = 0;
+    int NK = 0;  // kept (non-reduced) dims come first: 0..NK-1; reduced dims NK..N-1
+    i64 dims[MAXN];
+    i64 strides[MAXM][MAXN];
+    i64 offsets[MAXM];  // elements
+    void* base[MAXM];
+    int orig[MAXM];     // index of this operand in the caller's smr_problem::ops
+    int dtype[MAXM], conj[MAXM], esize[MAXM];
+    int ct = SMR_F32;  // compute class
+    bool mixed = false;  // some operand dtype != ct
+    bool bitcopy = false;  // pure move of opaque elements (integer dtypes)
+    int redop = 0, initop = 0;
+    double initarg[2] = {0, 0};
+    ProgD prog;
+    int fkind = FK_PROG;
+    double fc[4] = {0, 0, 0, 0};  // constants of the recognised functor: c=(fc0,fc1) d=(fc2,fc3)
+    i64 total = 1;                // number of box elements
+    i64 nout = 1;                 // number of destination elements
+    i64 algbytes = 0;             // distinct operand footprints, once each
+};
+
+// Tile description for FAM_TILED.  Tile extents are powers of two so that the element
+// enumeration inside a tile is pure bit slicing.
+struct TilePlan {
+    int nt = 0;          // number of tiled dims
+    int tdim[MAXN];      // canonical dim index of tiled dim j (tdim[0] == 0)
+    int tlog[MAXN];      // log2 tile extent of tiled dim j
+    int tilelog = 0;     // sum tlog = log2(elements per tile)
+    int nstaged = 0;     // inputs staged through LDS
+    int staged[MAXM];    // per input k (1..M-1): LDS slot or -1 (read straight from global)
+    int order[MAXM][MAXN];  // per input: enumeration order of tiled dims (fastest first)
+    int threads = 256;
+    i64 ntiles[MAXN];    // tiles per canonical dim
+    i64 grid = 1;
+    size_t lds_bytes = 0;
+};
+
+struct Plan {
+    Canon c;
+    int family = FAM_GENERIC;
+    TilePlan tile;
+    // STREAM
+    int vec = 1;        // elements per vector access
+    // reductions
+    void* scratch = nullptr;  // partials (owned)
+    size_t scratch_bytes = 0;
+    int red_blocks = 0;
+    int part_tr = 1;    // REDUCE_PART: lanes cooperating on one output
+    std::string desc;
+};
+
+// Options (smr_set_option)
+struct Options {
+    i64 force_family = 0;
+    i64 tile_log2 = 0;       // 0 = planner default
+    i64 block_threads = 256;
+    i64 stream_unroll = 4;
+    i64 tiled_minrun_bytes = 64;
+    i64 xcd_swizzle = 1;
+    i64 max_lds_bytes = 65536;
+    i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override
+};
+Options& options();
+
+int canonicalise(const smr_problem* p, Canon& c);
+int make_plan(const smr_problem* p, Plan& plan);
+void describe(Plan& plan);
+
+// launchers (one per kernel TU)
+int launch_generic_map(const Plan& plan, void* const* bases, hipStream_t s);
+int launch_stream_map(const Plan& plan, void* const* bases, hipStream_t s);
+int launch_tiled_map(const Plan& plan, void* const* bases, hipStream_t s);
+int launch_reduce_all(const Plan& plan, void* const* bases, hipStream_t s);
+int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s);
+
+}  // namespace smr

@@ -1,0 +1,329 @@
+// smr_k_reduce.hip -- the reduce path: dest[I] = op(initop(dest[I]), op_over_reduced_dims f(...))
+//
+// Semantics follow _mapreduce_kernel! with op !== nothing (reference src/mapreduce.jl:313-327)
+// and the initop-once rule (:351-382, :403-409): `initop` is applied exactly once to every
+// destination element, then the mapped values are accumulated into it.  On the GPU this is
+//     dest = op(initop(dest_old), partial)     in the epilogue,
+// where `partial` is a deterministic tree reduction (per-lane accumulators -> wave64
+// __shfl_xor butterflies -> LDS across the workgroup's waves -> one partial per workgroup ->
+// a single-workgroup second pass).  No float atomics, so results are run-to-run identical;
+// this mirrors the reference's per-task partial slots + serial fold (:153-170).
+//   REDUCE_ALL : complete reduction (destination is one element)
+//   REDUCE_PART: some dims kept; TR lanes cooperate per destination element
+#include "smr_dispatch.h"
+
+#ifndef SMR_CT
+#error "compile with -DSMR_CT=0..3"
+#endif
+
+namespace smr {
+
+struct RedArgs {
+    OpTab ops;
+    int32_t N, NK, M, redop, initop, linear, tr, trlog;
+    i64 total, nout, nred;
+    i64 dims[MAXN];
+    i64 strides[MAXM][MAXN];
+    double beta[2];
+    void* partials;
+    int32_t nparts;
+};
+
+template <class T>
+SMR_DEV T neutral(int op) {
+    typedef typename tr<T>::real R;
+    switch (op) {
+        case SMR_RED_MUL: return mk<T>(R(1), R(0));
+        case SMR_RED_MIN: return mk<T>(R(INFINITY), R(0));
+        case SMR_RED_MAX: return mk<T>(R(-INFINITY), R(0));
+    }
+    return mk<T>(R(0), R(0));
+}
+
+// reduce `v` over the `width` (power of two <= 64) consecutive lanes of a wave
+template <class T>
+SMR_DEV T wave_reduce(T v, int op, int width) {
+    for (int m = width >> 1; m > 0; m >>= 1) v = red_apply<T>(op, v, shfl_xor_any(v, m));
+    return v;
+}
+
+template <class T, bool MIXED>
+SMR_DEV void epilogue(const RedArgs& a, i64 off0, T acc) {
+    typedef typename tr<T>::real R;
+    T old = load_op<T, MIXED>(a.ops, 0, off0);
+    if (a.initop != SMR_INIT_NONE) old = init_apply<T>(a.initop, old, mk<T>(R(a.beta[0]), R(a.beta[1])));
+    store_op<T, MIXED>(a.ops, off0, red_apply<T>(a.redop, old, acc));
+}
+
+// offsets of box element `i` (decomposed over dims [d0, d1)) added into off[]
+SMR_DEV void decompose(const RedArgs& a, i64 i, int d0, int d1, i64* off) {
+    i64 rem = i;
+#pragma unroll
+    for (int d = 0; d < MAXN; ++d) {
+        if (d >= d0 && d < d1) {
+            i64 c;
+            if (d == d1 - 1) {
+                c = rem;
+            } else {
+                const i64 q = rem / a.dims[d];
+                c = rem - q * a.dims[d];
+                rem = q;
+            }
+#pragma unroll
+            for (int k = 0; k < MAXM; ++k)
+                if (k < a.M) off[k] += c * a.strides[k][d];
+        }
+    }
+}
+
+// ---- complete reduction -------------------------------------------------------------------------
+template <class T, int V>
+struct alignas(sizeof(T) * V) RVec {
+    T v[V];
+};
+
+template <class T, class F, bool MIXED, int V>
+__global__ void __launch_bounds__(256) k_reduce_all(RedArgs a, F f) {
+    __shared__ T wsum[4];
+    const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
+    constexpr int ACC = 4;
+    T acc[ACC];
+#pragma unroll
+    for (int j = 0; j < ACC; ++j) acc[j] = neutral<T>(a.redop);
+    const i64 nthreads = (i64)gridDim.x * 256;
+    const i64 t0 = (i64)blockIdx.x * 256 + threadIdx.x;
+    if constexpr (V > 1) {
+        // linear, unit-stride (or broadcast) inputs: 16-byte loads, ACC vectors in flight
+        typedef RVec<T, V> VT;
+        const i64 nvec = a.total / V;
+        for (i64 i = t0; i < nvec; i += nthreads * ACC) {
+            VT x[ACC][MAXIN];
+#pragma unroll
+            for (int j = 0; j < ACC; ++j) {
+                const i64 ii = i + j * nthreads;
+                if (ii < nvec) {
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k)
+                        if (k < nin) {
+                            if (a.strides[k + 1][0] == 0) {
+                                const T s = load_op<T, false>(a.ops, k + 1, 0);
+#pragma unroll
+                                for (int e = 0; e < V; ++e) x[j][k].v[e] = s;
+                            } else {
+                                x[j][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + ii * V);
+                                if constexpr (tr<T>::cx) {
+                                    if (a.ops.conj[k + 1]) {
+#pragma unroll
+                                        for (int e = 0; e < V; ++e) x[j][k].v[e] = cj(x[j][k].v[e]);
+                                    }
+                                }
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ACC; ++j) {
+                const i64 ii = i + j * nthreads;
+                if (ii < nvec) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        T in[MAXIN];
+#pragma unroll
+                        for (int k = 0; k < MAXIN; ++k) {
+                            in[k] = T{};
+                            if (k < nin) in[k] = x[j][k].v[e];
+                        }
+                        acc[j] = red_apply<T>(a.redop, acc[j], f(in));
+                    }
+                }
+            }
+        }
+    } else {
+        for (i64 i = t0; i < a.total; i += nthreads * ACC) {
+#pragma unroll
+            for (int j = 0; j < ACC; ++j) {
+                const i64 ii = i + j * nthreads;
+                if (ii < a.total) {
+                    i64 off[MAXM];
+#pragma unroll
+                    for (int k = 0; k < MAXM; ++k) off[k] = 0;
+                    if (a.linear) {
+#pragma unroll
+                        for (int k = 1; k < MAXM; ++k)
+                            if (k < a.M) off[k] = ii * a.strides[k][0];
+                    } else {
+                        decompose(a, ii, 0, a.N, off);
+                    }
+                    T in[MAXIN];
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k) {
+                        in[k] = T{};
+                        if (k < nin) in[k] = load_op<T, MIXED>(a.ops, k + 1, off[k + 1]);
+                    }
+                    acc[j] = red_apply<T>(a.redop, acc[j], f(in));
+                }
+            }
+        }
+    }
+    T v = red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3]));
+    v = wave_reduce(v, a.redop, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = red_apply<T>(a.redop, red_apply<T>(a.redop, wsum[0], wsum[1]), red_apply<T>(a.redop, wsum[2], wsum[3]));
+        if (gridDim.x == 1)
+            epilogue<T, MIXED>(a, 0, v);
+        else
+            ((T*)a.partials)[blockIdx.x] = v;
+    }
+}
+
+template <class T, bool MIXED>
+__global__ void __launch_bounds__(256) k_reduce_final(RedArgs a) {
+    __shared__ T wsum[4];
+    T v = neutral<T>(a.redop);
+    for (int i = threadIdx.x; i < a.nparts; i += 256) v = red_apply<T>(a.redop, v, ((const T*)a.partials)[i]);
+    v = wave_reduce(v, a.redop, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = red_apply<T>(a.redop, red_apply<T>(a.redop, wsum[0], wsum[1]), red_apply<T>(a.redop, wsum[2], wsum[3]));
+        epilogue<T, MIXED>(a, 0, v);
+    }
+}
+
+// ---- partial reduction ----------------------------------------------------------------------------
+// 256 threads = (256/TR) destination elements x TR lanes.  Lanes of one destination element
+// are consecutive threads, so when the inputs' unit-stride axis is a reduced dim the loads
+// coalesce; with TR == 1 consecutive threads own consecutive destination elements instead.
+template <class T, class F, bool MIXED>
+__global__ void __launch_bounds__(256) k_reduce_part(RedArgs a, F f) {
+    __shared__ T xbuf[256];
+    const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
+    const int tr_ = a.tr;
+    const int ob = 256 >> a.trlog;
+    const int rl = threadIdx.x & (tr_ - 1);
+    const int ol = threadIdx.x >> a.trlog;
+    const i64 o = (i64)blockIdx.x * ob + ol;
+    const bool live = o < a.nout;
+    i64 ooff[MAXM];
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
+    if (live) decompose(a, o, 0, a.NK, ooff);
+    T acc = neutral<T>(a.redop);
+    if (live) {
+        for (i64 r = rl; r < a.nred; r += tr_) {
+            i64 off[MAXM];
+#pragma unroll
+            for (int k = 0; k < MAXM; ++k) off[k] = ooff[k];
+            decompose(a, r, a.NK, a.N, off);
+            T in[MAXIN];
+#pragma unroll
+            for (int k = 0; k < MAXIN; ++k) {
+                in[k] = T{};
+                if (k < nin) in[k] = load_op<T, MIXED>(a.ops, k + 1, off[k + 1]);
+            }
+            acc = red_apply<T>(a.redop, acc, f(in));
+        }
+    }
+    if (tr_ > 1) {
+        const int w = tr_ < 64 ? tr_ : 64;
+        acc = wave_reduce(acc, a.redop, w);
+        if (tr_ > 64) {  // lanes of one output span several waves
+            xbuf[threadIdx.x] = acc;
+            __syncthreads();
+            if (rl == 0) {
+                for (int j = 64; j < tr_; j += 64) acc = red_apply<T>(a.redop, acc, xbuf[threadIdx.x + j]);
+            }
+        }
+    }
+    if (live && rl == 0) epilogue<T, MIXED>(a, ooff[0], acc);
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------
+static void fill_args(const Plan& plan, void* const* bases, RedArgs& a) {
+    const Canon& c = plan.c;
+    std::memset(&a, 0, sizeof a);
+    a.ops = make_optab(c, bases);
+    a.N = c.N;
+    a.NK = c.NK;
+    a.M = c.M;
+    a.redop = c.redop;
+    a.initop = c.initop;
+    a.total = c.total;
+    a.nout = c.nout;
+    a.nred = c.total / c.nout;
+    a.beta[0] = c.initarg[0];
+    a.beta[1] = c.initarg[1];
+    for (int i = 0; i < MAXN; ++i) a.dims[i] = (i < c.N) ? c.dims[i] : 1;
+    for (int k = 0; k < MAXM; ++k)
+        for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
+    a.partials = plan.scratch;
+}
+
+template <class T, class F, bool MIXED>
+static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    const Canon& c = plan.c;
+    RedArgs a;
+    fill_args(plan, bases, a);
+    a.linear = (c.N == 1) ? 1 : 0;
+    int blocks = plan.red_blocks;
+    if (blocks > 1 && !plan.scratch) blocks = 1;
+    a.nparts = blocks;
+    // vector path: one fused dim, every input unit stride / broadcast, 16-B aligned
+    constexpr int VMAX = (sizeof(T) >= 16) ? 1 : (int)(16 / sizeof(T));
+    bool vec = !MIXED && VMAX > 1 && c.N == 1 && (c.total % VMAX == 0) && c.total >= 4096;
+    for (int k = 1; k < c.M && vec; ++k) {
+        if (c.strides[k][0] == 0) continue;
+        if (c.strides[k][0] != 1) vec = false;
+        if (((uintptr_t)a.ops.base[k]) % 16) vec = false;
+    }
+    if constexpr (!MIXED && VMAX > 1) {
+        if (vec) hipLaunchKernelGGL((k_reduce_all<T, F, false, VMAX>), dim3(blocks), dim3(256), 0, s, a, f);
+    }
+    if (!vec) hipLaunchKernelGGL((k_reduce_all<T, F, MIXED, 1>), dim3(blocks), dim3(256), 0, s, a, f);
+    int rc = check_launch("k_reduce_all");
+    if (rc) return rc;
+    if (blocks > 1) {
+        hipLaunchKernelGGL((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
+        rc = check_launch("k_reduce_final");
+    }
+    return rc;
+}
+
+template <class T, class F, bool MIXED>
+static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    const Canon& c = plan.c;
+    RedArgs a;
+    fill_args(plan, bases, a);
+    a.tr = plan.part_tr;
+    a.trlog = 0;
+    while ((1 << a.trlog) < a.tr) ++a.trlog;
+    const int ob = 256 / a.tr;
+    const i64 blocks = (c.nout + ob - 1) / ob;
+    if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
+    hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+    return check_launch("k_reduce_part");
+}
+
+template <>
+int launch_reduce_all_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
+    typedef ct_type<SMR_CT>::type T;
+    const Canon& c = plan.c;
+    if (c.mixed) return go_all<T, FProg<T>, true>(plan, bases, s, FProg<T>{c.prog});
+    const unsigned mask = fbit(FK_IDENT) | fbit(FK_ABS2) | fbit(FK_MUL2);
+    return with_functor<T>(c, mask, [&](auto f) { return go_all<T, decltype(f), false>(plan, bases, s, f); });
+}
+
+template <>
+int launch_reduce_part_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
+    typedef ct_type<SMR_CT>::type T;
+    const Canon& c = plan.c;
+    if (c.mixed) return go_part<T, FProg<T>, true>(plan, bases, s, FProg<T>{c.prog});
+    const unsigned mask = fbit(FK_IDENT) | fbit(FK_MUL2);
+    return with_functor<T>(c, mask, [&](auto f) { return go_part<T, decltype(f), false>(plan, bases, s, f); });
+}
+
+}  // namespace smr

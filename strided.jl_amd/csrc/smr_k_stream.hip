@@ -1,0 +1,163 @@
+// smr_k_stream.hip -- family STREAM: every operand is unit-stride (or broadcast, stride 0)
+// along the destination's fast dim.  Contiguous broadcasts, axpy-type updates, the
+// compute-bound README map.  16-byte vector accesses, U vectors in flight per lane, outer
+// dims resolved once per workgroup with scalar arithmetic.
+#include "smr_dispatch.h"
+
+#ifndef SMR_CT
+#error "compile with -DSMR_CT=0..3"
+#endif
+
+namespace smr {
+
+struct StreamArgs {
+    OpTab ops;
+    int32_t N, M;
+    i64 n0v;   // vectors along dim 0
+    i64 rows;  // product of the outer dims
+    i64 bpr;   // workgroups per row
+    i64 dims[MAXN];
+    i64 strides[MAXM][MAXN];
+};
+
+template <class T, int V>
+struct alignas(sizeof(T) * V) Vec {
+    T v[V];
+};
+
+template <class T, class F, bool MIXED, int V, int U>
+__global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f) {
+    const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
+    i64 row = 0, cb = blockIdx.x;
+    if (a.rows > 1) {
+        row = cb / a.bpr;
+        cb -= row * a.bpr;
+    }
+    i64 roff[MAXM];
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) roff[k] = 0;
+    if (a.rows > 1) {
+        i64 rem = row;
+#pragma unroll
+        for (int d = 1; d < MAXN; ++d) {
+            if (d < a.N) {
+                const i64 q = rem / a.dims[d];
+                const i64 c = rem - q * a.dims[d];
+                rem = q;
+#pragma unroll
+                for (int k = 0; k < MAXM; ++k)
+                    if (k < a.M) roff[k] += c * a.strides[k][d];
+            }
+        }
+    }
+    typedef Vec<T, V> VT;
+    VT in[U][MAXIN];
+    i64 col[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        col[u] = (cb * U + u) * 256 + threadIdx.x;
+        if (col[u] < a.n0v) {
+#pragma unroll
+            for (int k = 0; k < MAXIN; ++k) {
+                if (k < nin) {
+                    if (a.strides[k + 1][0] == 0) {
+                        const T s = load_op<T, MIXED>(a.ops, k + 1, roff[k + 1]);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) in[u][k].v[e] = s;
+                    } else if constexpr (MIXED || V == 1) {
+                        in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, roff[k + 1] + col[u]);
+                    } else {
+                        in[u][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + roff[k + 1] + col[u] * V);
+                        if constexpr (tr<T>::cx) {
+                            if (a.ops.conj[k + 1]) {
+#pragma unroll
+                                for (int e = 0; e < V; ++e) in[u][k].v[e] = cj(in[u][k].v[e]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (col[u] < a.n0v) {
+            VT out;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                T x[MAXIN];
+#pragma unroll
+                for (int k = 0; k < MAXIN; ++k) {
+                    x[k] = T{};
+                    if (k < nin) x[k] = in[u][k].v[e];
+                }
+                out.v[e] = f(x);
+            }
+            if constexpr (MIXED || V == 1) {
+                store_op<T, MIXED>(a.ops, roff[0] + col[u], out.v[0]);
+            } else {
+                if constexpr (tr<T>::cx) {
+                    if (a.ops.conj[0]) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) out.v[e] = cj(out.v[e]);
+                    }
+                }
+                *reinterpret_cast<VT*>((T*)a.ops.base[0] + roff[0] + col[u] * V) = out;
+            }
+        }
+    }
+}
+
+template <class T, class F, bool MIXED, int V>
+static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    const Canon& c = plan.c;
+    constexpr int U = (sizeof(T) * V >= 16) ? 4 : 8;
+    StreamArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.ops = make_optab(c, bases);
+    a.N = c.N;
+    a.M = c.M;
+    a.n0v = c.dims[0] / V;
+    a.rows = 1;
+    for (int i = 1; i < c.N; ++i) a.rows *= c.dims[i];
+    a.bpr = (a.n0v + 256 * U - 1) / (256 * U);
+    for (int i = 0; i < MAXN; ++i) a.dims[i] = (i < c.N) ? c.dims[i] : 1;
+    for (int k = 0; k < MAXM; ++k)
+        for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
+    const i64 grid = a.bpr * a.rows;
+    if (grid > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "stream grid too large");
+    hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
+    return check_launch("k_stream_map");
+}
+
+template <class T, class F>
+static int go_vec(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    constexpr int VMAX = (sizeof(T) >= 16) ? 1 : (int)(16 / sizeof(T));
+    if constexpr (VMAX > 1) {
+        if (plan.vec == VMAX) return go<T, F, false, VMAX>(plan, bases, s, f);
+    }
+    return go<T, F, false, 1>(plan, bases, s, f);
+}
+
+template <>
+int launch_stream_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
+    typedef ct_type<SMR_CT>::type T;
+    const Canon& c = plan.c;
+    if (c.bitcopy) {
+#if SMR_CT == SMR_F32
+        switch (c.esize[0]) {
+            case 1: return go_vec<b8>(plan, bases, s, FIdent<b8>{});
+            case 2: return go_vec<b16>(plan, bases, s, FIdent<b16>{});
+            case 4: return go_vec<float>(plan, bases, s, FIdent<float>{});
+            case 8: return go_vec<double>(plan, bases, s, FIdent<double>{});
+            default: return go_vec<c64>(plan, bases, s, FIdent<c64>{});
+        }
+#else
+        return set_error(SMR_EINVAL, "bitcopy is dispatched through the f32 object");
+#endif
+    }
+    if (c.mixed) return go<T, FProg<T>, true, 1>(plan, bases, s, FProg<T>{c.prog});
+    return with_functor<T>(c, FMASK_ALL, [&](auto f) { return go_vec<T>(plan, bases, s, f); });
+}
+
+}  // namespace smr

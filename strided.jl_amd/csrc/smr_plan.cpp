@@ -1,0 +1,548 @@
+// smr_plan.cpp -- host-side planner of libstrided_hip.so.
+//
+// GPU analogue of the reference's planning chain
+//   _mapreduce_fuse!  (src/mapreduce.jl:98-117)   -> canonicalise(): drop/sort/flip/fuse/dedupe
+//   _mapreduce_order! (src/mapreduce.jl:119-139)  -> canonical dim order (destination-stride
+//                                                    sorted) + kernel-family classification
+//   _mapreduce_block!/_computeblocks (:142-180, :452-500)
+//                                                 -> plan_tiles(): LDS tile shape instead of
+//                                                    L1 cache blocks
+// The CPU heuristics (importance digits, 32 KiB blocks, 64 B lines) are NOT transliterated:
+// on CDNA4 the quantities that matter are the unit-stride axis of every operand (coalescing),
+// the LDS budget and the number of workgroups.  The faithful restatement of the CPU planner
+// lives in oracle/ as test infrastructure.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "smr_internal.h"
+
+namespace smr {
+
+Options& options() {
+    static Options o;
+    return o;
+}
+
+static int nextpow2_log(i64 v) {
+    int l = 0;
+    while (((i64)1 << l) < v) ++l;
+    return l;
+}
+
+// ---- f-program validation / recognition -------------------------------------------------------
+static int check_prog(const ProgD& p, int M, int& maxdepth) {
+    int sp = 0;
+    maxdepth = 0;
+    for (int pc = 0; pc < p.len; ++pc) {
+        int op = p.code[2 * pc], imm = p.code[2 * pc + 1];
+        if (op == SMR_OP_ARG) {
+            if (imm < 1 || imm >= M) return -1;
+            ++sp;
+        } else if (op == SMR_OP_CONST) {
+            if (imm >= p.nconst) return -1;
+            ++sp;
+        } else if (op >= SMR_OP_NEG && op <= SMR_OP_INV) {
+            if (sp < 1) return -1;
+        } else if (op >= SMR_OP_ADD && op <= SMR_OP_NE) {
+            if (sp < 2) return -1;
+            --sp;
+        } else if (op == SMR_OP_SELECT) {
+            if (sp < 3) return -1;
+            sp -= 2;
+        } else {
+            return -1;
+        }
+        maxdepth = std::max(maxdepth, sp);
+    }
+    return sp == 1 ? 0 : -1;
+}
+
+static void recognise(Canon& c) {
+    const ProgD& p = c.prog;
+    auto op = [&](int i) { return (int)p.code[2 * i]; };
+    auto im = [&](int i) { return (int)p.code[2 * i + 1]; };
+    auto isarg = [&](int i, int k) { return op(i) == SMR_OP_ARG && im(i) == k; };
+    auto isconst = [&](int i) { return op(i) == SMR_OP_CONST; };
+    auto cre = [&](int i) { return p.consts[2 * im(i)]; };
+    auto cim = [&](int i) { return p.consts[2 * im(i) + 1]; };
+    c.fkind = FK_PROG;
+    const int n = p.len, nin = c.M - 1;
+    if (n == 1 && isarg(0, 1) && nin == 1) { c.fkind = FK_IDENT; return; }
+    if (n == 3 && isarg(0, 1) && isarg(1, 2) && op(2) == SMR_OP_ADD && nin == 2) { c.fkind = FK_ADD2; return; }
+    if (n == 5 && isarg(0, 1) && isarg(1, 2) && op(2) == SMR_OP_ADD && isarg(3, 3) && op(4) == SMR_OP_ADD && nin == 3) {
+        c.fkind = FK_ADD3; return;
+    }
+    if (n == 7 && isarg(0, 1) && isarg(1, 2) && op(2) == SMR_OP_ADD && isarg(3, 3) && op(4) == SMR_OP_ADD &&
+        isarg(5, 4) && op(6) == SMR_OP_ADD && nin == 4) {
+        c.fkind = FK_ADD4; return;
+    }
+    if (n == 3 && nin == 1 && op(2) == SMR_OP_MUL &&
+        ((isarg(0, 1) && isconst(1)) || (isconst(0) && isarg(1, 1)))) {
+        int ci = isconst(0) ? 0 : 1;
+        c.fkind = FK_SCALE; c.fc[0] = cre(ci); c.fc[1] = cim(ci); return;
+    }
+    if (n == 5 && nin == 2 && isarg(0, 1) && isarg(1, 2) && op(2) == SMR_OP_ADD && isconst(3) && op(4) == SMR_OP_DIV) {
+        c.fkind = FK_SYM; c.fc[0] = cre(3); c.fc[1] = cim(3); return;
+    }
+    if (n == 5 && nin == 2 && isconst(0) && isarg(1, 1) && op(2) == SMR_OP_MUL && isarg(3, 2) && op(4) == SMR_OP_ADD) {
+        c.fkind = FK_AXPY; c.fc[0] = cre(0); c.fc[1] = cim(0); return;
+    }
+    if (n == 7 && nin == 2 && isconst(0) && isarg(1, 1) && op(2) == SMR_OP_MUL && isconst(3) && isarg(4, 2) &&
+        op(5) == SMR_OP_MUL && op(6) == SMR_OP_ADD) {
+        c.fkind = FK_AXPBY; c.fc[0] = cre(0); c.fc[1] = cim(0); c.fc[2] = cre(3); c.fc[3] = cim(3); return;
+    }
+    if (n == 2 && nin == 1 && isarg(0, 1) && op(1) == SMR_OP_ABS2) { c.fkind = FK_ABS2; return; }
+    if (n == 3 && nin == 2 && isarg(0, 1) && isarg(1, 2) && op(2) == SMR_OP_MUL) { c.fkind = FK_MUL2; return; }
+    // a .* exp.(c .* a) .+ sin.(a .* a)   (real types)
+    if (n == 11 && nin == 1 && (c.ct == SMR_F32 || c.ct == SMR_F64) && isarg(0, 1) && isconst(1) && isarg(2, 1) &&
+        op(3) == SMR_OP_MUL && op(4) == SMR_OP_EXP && op(5) == SMR_OP_MUL && isarg(6, 1) && isarg(7, 1) &&
+        op(8) == SMR_OP_MUL && op(9) == SMR_OP_SIN && op(10) == SMR_OP_ADD && cim(1) == 0.0) {
+        c.fkind = FK_EXPR5; c.fc[0] = cre(1); return;
+    }
+}
+
+// ---- canonicalisation ---------------------------------------------------------------------------
+int canonicalise(const smr_problem* p, Canon& c) {
+    if (!p) return set_error(SMR_EINVAL, "null problem");
+    const int N0 = p->N, M0 = p->M;
+    if (N0 < 1 || N0 > MAXN) return set_error(SMR_EINVAL, "rank N out of range 1..8");
+    if (M0 < 1 || M0 > MAXM) return set_error(SMR_EINVAL, "operand count M out of range 1..8");
+    for (int i = 0; i < N0; ++i)
+        if (p->dims[i] < 1) return set_error(SMR_EINVAL, "every dim must be >= 1 (zero-size is handled by the caller, src/mapreduce.jl:48,88)");
+    for (int k = 0; k < M0; ++k) {
+        if (!p->ops[k].base) return set_error(SMR_EINVAL, "null operand base pointer");
+        if (dtype_size(p->ops[k].dtype) == 0) return set_error(SMR_EINVAL, "bad operand dtype");
+    }
+    if (p->redop < SMR_RED_NONE || p->redop > SMR_RED_MAX) return set_error(SMR_EINVAL, "bad redop");
+    if (p->initop < SMR_INIT_NONE || p->initop > SMR_INIT_CONJ) return set_error(SMR_EINVAL, "bad initop");
+    if (p->redop == SMR_RED_NONE && p->initop != SMR_INIT_NONE)
+        return set_error(SMR_EINVAL, "initop requires a reduction op (src/mapreduce.jl:310-316)");
+
+    // program
+    ProgD& prog = c.prog;
+    std::memset(&prog, 0, sizeof(prog));
+    if (!p->fprog || p->fprog_len == 0) {
+        if (M0 < 2) return set_error(SMR_EINVAL, "identity program needs an input");
+        prog.len = 1;
+        prog.code[0] = SMR_OP_ARG;
+        prog.code[1] = 1;
+    } else {
+        if (p->fprog_len < 0 || p->fprog_len > SMR_MAXPROG) return set_error(SMR_EINVAL, "f-program too long");
+        prog.len = p->fprog_len;
+        std::memcpy(prog.code, p->fprog, (size_t)(2 * p->fprog_len));
+    }
+    if (p->nconsts < 0 || p->nconsts > SMR_MAXCONST) return set_error(SMR_EINVAL, "too many constants");
+    if (p->nconsts > 0 && !p->fconsts) return set_error(SMR_EINVAL, "null fconsts");
+    prog.nconst = p->nconsts;
+    for (int i = 0; i < 2 * p->nconsts; ++i) prog.consts[i] = p->fconsts[i];
+    int depth = 0;
+    if (check_prog(prog, std::max(M0, 1), depth) != 0) return set_error(SMR_EINVAL, "malformed f-program");
+    if (depth > STACK) return set_error(SMR_EUNSUPPORTED, "f-program needs more than 8 stack slots");
+
+    // compute class (Julia promote_type over the operand eltypes, restricted to the four
+    // float classes of the reference tests)
+    bool dbl = false, cplx = false, anyint = false;
+    for (int k = 0; k < M0; ++k) {
+        int dt = p->ops[k].dtype;
+        if (dt == SMR_F64 || dt == SMR_C64) dbl = true;
+        if (dt == SMR_C32 || dt == SMR_C64) cplx = true;
+        if (dt >= SMR_I8) { anyint = true; dbl = true; }
+    }
+    for (int i = 0; i < prog.nconst; ++i)
+        if (prog.consts[2 * i + 1] != 0.0) cplx = true;
+    c.ct = cplx ? (dbl ? SMR_C64 : SMR_C32) : (dbl ? SMR_F64 : SMR_F32);
+    c.redop = p->redop;
+    c.initop = p->initop;
+    c.initarg[0] = p->initarg[0];
+    c.initarg[1] = p->initarg[1];
+    c.bitcopy = false;
+    if (anyint) {
+        bool pure = p->redop == SMR_RED_NONE && M0 == 2 && p->ops[0].dtype == p->ops[1].dtype && prog.len == 1 &&
+                    prog.code[0] == SMR_OP_ARG;
+        if (pure) c.bitcopy = true;
+    }
+
+    // working copies
+    int N = 0;
+    i64 dims[MAXN];
+    i64 str[MAXM][MAXN];
+    int M = M0;
+    for (int i = 0; i < N0; ++i) {
+        if (p->dims[i] == 1) continue;  // size-1 dims carry no information
+        dims[N] = p->dims[i];
+        for (int k = 0; k < M0; ++k) str[k][N] = p->ops[k].strides[i];
+        ++N;
+    }
+    i64 off[MAXM];
+    void* base[MAXM];
+    int dtype[MAXM], conj[MAXM];
+    for (int k = 0; k < M0; ++k) {
+        off[k] = p->ops[k].offset;
+        base[k] = p->ops[k].base;
+        dtype[k] = p->ops[k].dtype;
+        conj[k] = (p->ops[k].conj && (dtype[k] == SMR_C32 || dtype[k] == SMR_C64)) ? 1 : 0;
+    }
+
+    // dedupe identical inputs (capturestridedargs does not: src/broadcast.jl:41-46), and
+    // drop inputs the program never reads
+    {
+        int remap[MAXM];
+        bool used[MAXM] = {false};
+        for (int pc = 0; pc < prog.len; ++pc)
+            if (prog.code[2 * pc] == SMR_OP_ARG) used[prog.code[2 * pc + 1]] = true;
+        int newM = 1;
+        int keep[MAXM];
+        keep[0] = 0;
+        for (int k = 1; k < M; ++k) {
+            remap[k] = -1;
+            if (!used[k]) continue;
+            for (int j = 1; j < newM; ++j) {
+                int q = keep[j];
+                bool same = base[q] == base[k] && off[q] == off[k] && dtype[q] == dtype[k] && conj[q] == conj[k];
+                for (int i = 0; i < N && same; ++i) same = str[q][i] == str[k][i];
+                if (same) { remap[k] = j; break; }
+            }
+            if (remap[k] < 0) { keep[newM] = k; remap[k] = newM; ++newM; }
+        }
+        for (int pc = 0; pc < prog.len; ++pc)
+            if (prog.code[2 * pc] == SMR_OP_ARG) prog.code[2 * pc + 1] = (uint8_t)remap[prog.code[2 * pc + 1]];
+        i64 s2[MAXM][MAXN], o2[MAXM];
+        void* b2[MAXM];
+        int d2[MAXM], c2[MAXM];
+        for (int j = 0; j < newM; ++j) {
+            int q = keep[j];
+            for (int i = 0; i < N; ++i) s2[j][i] = str[q][i];
+            o2[j] = off[q]; b2[j] = base[q]; d2[j] = dtype[q]; c2[j] = conj[q];
+            c.orig[j] = q;
+        }
+        M = newM;
+        for (int j = 0; j < M; ++j) {
+            for (int i = 0; i < N; ++i) str[j][i] = s2[j][i];
+            off[j] = o2[j]; base[j] = b2[j]; dtype[j] = d2[j]; conj[j] = c2[j];
+        }
+    }
+
+    // a pure map must not alias destination elements (the reference would serialise the
+    // writes; on a GPU that is a race)
+    if (p->redop == SMR_RED_NONE)
+        for (int i = 0; i < N; ++i)
+            if (str[0][i] == 0) return set_error(SMR_EUNSUPPORTED, "map into a destination with a zero stride");
+
+    // flip dims so that destination strides (kept dims) / first-input strides (reduced dims)
+    // are positive; iteration direction is irrelevant for map and for associative reductions
+    for (int i = 0; i < N; ++i) {
+        i64 lead = str[0][i];
+        if (lead == 0)
+            for (int k = 1; k < M && lead == 0; ++k) lead = str[k][i];
+        if (lead < 0)
+            for (int k = 0; k < M; ++k) {
+                off[k] += (dims[i] - 1) * str[k][i];
+                str[k][i] = -str[k][i];
+            }
+    }
+
+    // sort: kept dims by destination stride, then reduced dims by smallest input stride
+    std::vector<int> perm(N);
+    for (int i = 0; i < N; ++i) perm[i] = i;
+    auto minin = [&](int i) {
+        i64 m = INT64_MAX;
+        for (int k = 1; k < M; ++k)
+            if (str[k][i] != 0) m = std::min<i64>(m, std::llabs(str[k][i]));
+        return m;
+    };
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+        bool ra = str[0][a] == 0, rb = str[0][b] == 0;
+        if (ra != rb) return !ra;
+        if (!ra) return str[0][a] < str[0][b];
+        return minin(a) < minin(b);
+    });
+    i64 sd[MAXN], ss[MAXM][MAXN];
+    for (int i = 0; i < N; ++i) {
+        sd[i] = dims[perm[i]];
+        for (int k = 0; k < M; ++k) ss[k][i] = str[k][perm[i]];
+    }
+    // fuse adjacent dims that are jointly contiguous in every operand (same rule as
+    // src/mapreduce.jl:103-115, applied after sorting so it fires more often); never across
+    // the kept/reduced boundary
+    int NF = 0;
+    i64 fd[MAXN], fs[MAXM][MAXN];
+    for (int i = 0; i < N; ++i) {
+        bool merged = false;
+        if (NF > 0) {
+            bool kb = fs[0][NF - 1] != 0, ka = ss[0][i] != 0;
+            bool ok = (kb == ka);
+            for (int k = 0; k < M && ok; ++k) ok = ss[k][i] == fd[NF - 1] * fs[k][NF - 1];
+            if (ok) {
+                fd[NF - 1] *= sd[i];
+                merged = true;
+            }
+        }
+        if (!merged) {
+            fd[NF] = sd[i];
+            for (int k = 0; k < M; ++k) fs[k][NF] = ss[k][i];
+            ++NF;
+        }
+    }
+    if (NF == 0) {  // every dim had size 1: a single element
+        NF = 1;
+        fd[0] = 1;
+        for (int k = 0; k < M; ++k) fs[k][0] = (k == 0 && p->redop == SMR_RED_NONE) ? 1 : 0;
+        if (p->redop != SMR_RED_NONE) fs[0][0] = 0;
+    }
+    c.N = NF;
+    c.M = M;
+    c.NK = 0;
+    c.total = 1;
+    c.nout = 1;
+    for (int i = 0; i < NF; ++i) {
+        c.dims[i] = fd[i];
+        c.total *= fd[i];
+        if (fs[0][i] != 0) { c.NK = i + 1; c.nout *= fd[i]; }
+    }
+    if (p->redop == SMR_RED_NONE) { c.NK = NF; }
+    c.mixed = false;
+    for (int k = 0; k < M; ++k) {
+        for (int i = 0; i < NF; ++i) c.strides[k][i] = fs[k][i];
+        for (int i = NF; i < MAXN; ++i) c.strides[k][i] = 0;
+        c.offsets[k] = off[k];
+        c.base[k] = base[k];
+        c.dtype[k] = dtype[k];
+        c.conj[k] = conj[k];
+        c.esize[k] = dtype_size(dtype[k]);
+        if (dtype[k] != c.ct) c.mixed = true;
+    }
+    for (int i = NF; i < MAXN; ++i) c.dims[i] = 1;
+    if (c.bitcopy) c.mixed = false;
+
+    // algorithmic bytes: every distinct buffer once
+    {
+        std::map<void*, i64> foot;
+        for (int k = 0; k < M; ++k) {
+            i64 n = 1;
+            for (int i = 0; i < NF; ++i)
+                if (c.strides[k][i] != 0) n *= c.dims[i];
+            i64 bytes = n * c.esize[k];
+            auto it = foot.find(c.base[k]);
+            if (it == foot.end()) foot[c.base[k]] = bytes;
+            else it->second = std::max(it->second, bytes);
+        }
+        c.algbytes = 0;
+        for (auto& kv : foot) c.algbytes += kv.second;
+    }
+    recognise(c);
+    return SMR_OK;
+}
+
+// ---- tile planning (FAM_TILED) -------------------------------------------------------------------
+// fast (unit-stride) axis of operand k, or -1
+static int fast_axis(const Canon& c, int k) {
+    for (int i = 0; i < c.N; ++i)
+        if (c.dims[i] > 1 && (c.strides[k][i] == 1 || c.strides[k][i] == -1)) return i;
+    return -1;
+}
+
+static bool plan_tiles(const Canon& c, TilePlan& t) {
+    if (c.redop != SMR_RED_NONE) return false;
+    if (c.N < 2 || c.strides[0][0] != 1) return false;
+    const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+    // which inputs need staging: unit-stride axis exists and differs from the destination's
+    bool axis_used[MAXN] = {false};
+    axis_used[0] = true;
+    int nst = 0;
+    t.staged[0] = -1;
+    for (int k = 1; k < c.M; ++k) {
+        int q = fast_axis(c, k);
+        t.staged[k] = -1;
+        if (q > 0 && c.strides[k][0] != 0 && std::llabs(c.strides[k][0]) != 1) {
+            t.staged[k] = nst++;
+            axis_used[q] = true;
+        } else if (q > 0 && c.strides[k][0] == 0) {
+            // broadcast along dim 0 with another unit axis: reads are wave-uniform along
+            // dim 0 anyway; leave it direct
+        }
+    }
+    if (nst == 0) return false;
+    t.nstaged = nst;
+    int axes[MAXN], na = 0;
+    for (int i = 0; i < c.N; ++i)
+        if (axis_used[i]) axes[na++] = i;
+    // target contiguous run per axis
+    const Options& o = options();
+    i64 runbytes = (na == 2) ? 256 : (na == 3 ? 128 : 64);
+    int tl_cap = o.tile_log2 > 0 ? (int)o.tile_log2 : 12;
+    // LDS budget
+    while (tl_cap > 6 && (size_t)nst * ((size_t)1 << tl_cap) * es > (size_t)o.max_lds_bytes) --tl_cap;
+    int lg[MAXN] = {0};
+    int total = 0;
+    // grow the axes round-robin towards the run target
+    int want = std::max(1, nextpow2_log(std::max<i64>(1, runbytes / es)));
+    if (o.tile_log2 > 0) want = std::max(want, (int)(o.tile_log2 + na - 1) / na);
+    bool forced = false;
+    for (int i = 0; i < c.N; ++i)
+        if (o.tile_lg[i] >= 0) forced = true;
+    if (forced) {  // tuning override: exact per-dim log2 extents
+        for (int i = 0; i < c.N; ++i) {
+            lg[i] = (int)std::max<i64>(0, o.tile_lg[i]);
+            while (lg[i] > 0 && ((i64)1 << (lg[i] - 1)) >= c.dims[i]) --lg[i];
+            total += lg[i];
+        }
+        tl_cap = total;
+    }
+    bool grew = !forced;
+    while (grew && total < tl_cap) {
+        grew = false;
+        for (int a = 0; a < na && total < tl_cap; ++a) {
+            int i = axes[a];
+            if (lg[i] < want && ((i64)1 << lg[i]) < c.dims[i]) {
+                ++lg[i];
+                ++total;
+                grew = true;
+            }
+        }
+    }
+    // small problems / short axes: widen the tile with the remaining dims (destination order)
+    // until a block has at least 1024 elements of work
+    int minlog = forced ? 0 : std::min(tl_cap, 10);
+    for (int i = 0; i < c.N && total < minlog; ++i)
+        while (total < minlog && ((i64)1 << lg[i]) < c.dims[i]) {
+            ++lg[i];
+            ++total;
+        }
+    if (total < 6) return false;  // less than one wave of work per tile
+    t.nt = 0;
+    t.tilelog = total;
+    for (int i = 0; i < c.N; ++i)
+        if (lg[i] > 0) {
+            if (t.nt >= 5) return false;
+            t.tdim[t.nt] = i;
+            t.tlog[t.nt] = lg[i];
+            ++t.nt;
+        }
+    if (t.tdim[0] != 0) return false;
+    // enumeration order per staged input: its own stride order over the tiled dims
+    for (int k = 1; k < c.M; ++k) {
+        int idx[MAXN];
+        for (int j = 0; j < t.nt; ++j) idx[j] = j;
+        if (t.staged[k] >= 0)
+            std::stable_sort(idx, idx + t.nt, [&](int a, int b) {
+                i64 sa = std::llabs(c.strides[k][t.tdim[a]]), sb = std::llabs(c.strides[k][t.tdim[b]]);
+                // zero strides last: they do not move the address
+                if ((sa == 0) != (sb == 0)) return sb == 0;
+                return sa < sb;
+            });
+        for (int j = 0; j < t.nt; ++j) t.order[k][j] = idx[j];
+    }
+    for (int j = 0; j < t.nt; ++j) t.order[0][j] = j;
+    t.threads = (int)std::min<i64>(o.block_threads, (i64)1 << total);
+    if (t.threads < 64) t.threads = 64;
+    t.grid = 1;
+    for (int i = 0; i < c.N; ++i) {
+        i64 e = (i64)1 << lg[i];
+        t.ntiles[i] = (c.dims[i] + e - 1) / e;
+        t.grid *= t.ntiles[i];
+    }
+    t.lds_bytes = (size_t)nst * ((size_t)1 << total) * es;
+    if (t.grid > 0x7fffffffLL) return false;
+    return true;
+}
+
+// ---- family selection -------------------------------------------------------------------------------
+int make_plan(const smr_problem* p, Plan& plan) {
+    int rc = canonicalise(p, plan.c);
+    if (rc) return rc;
+    const Canon& c = plan.c;
+    const Options& o = options();
+    int fam = FAM_GENERIC;
+    if (c.redop == SMR_RED_NONE) {
+        bool stream = true;
+        for (int k = 0; k < c.M; ++k) {
+            i64 s = c.strides[k][0];
+            if (!(s == 1 || (k > 0 && s == 0))) stream = false;
+        }
+        if (stream) {
+            fam = FAM_STREAM;
+        } else if (plan_tiles(c, plan.tile)) {
+            fam = FAM_TILED;
+        }
+    } else {
+        fam = (c.NK == 0) ? FAM_REDUCE_ALL : FAM_REDUCE_PART;
+    }
+    if (o.force_family == FAM_GENERIC && c.redop == SMR_RED_NONE) fam = FAM_GENERIC;
+    if (o.force_family == FAM_TILED && c.redop == SMR_RED_NONE && fam != FAM_TILED && plan_tiles(c, plan.tile)) fam = FAM_TILED;
+    plan.family = fam;
+
+    if (fam == FAM_STREAM) {
+        // vector width: 16 B per lane when every unit-stride operand stays 16-B aligned
+        const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+        int v = (c.mixed || es >= 16) ? 1 : 16 / es;
+        while (v > 1) {
+            bool ok = c.dims[0] % v == 0;
+            for (int k = 0; k < c.M && ok; ++k) {
+                if (c.strides[k][0] == 0) continue;
+                if (((uintptr_t)c.base[k] + (uintptr_t)(c.offsets[k] * c.esize[k])) % (size_t)(v * es)) ok = false;
+                for (int i = 1; i < c.N && ok; ++i)
+                    if (c.strides[k][i] % v) ok = false;
+            }
+            if (ok) break;
+            v >>= 1;
+        }
+        plan.vec = v;
+    }
+    if (fam == FAM_REDUCE_ALL || fam == FAM_REDUCE_PART) {
+        const int es = dtype_size(c.ct);
+        if (fam == FAM_REDUCE_ALL) {
+            i64 per_block = 256 * 16;
+            i64 nb = (c.total + per_block - 1) / per_block;
+            nb = std::max<i64>(1, std::min<i64>(nb, 2048));
+            plan.red_blocks = (int)nb;
+            plan.scratch_bytes = (size_t)nb * es;
+        } else {
+            // lanes cooperating per output: more when few outputs / long reductions
+            i64 red = c.total / std::max<i64>(1, c.nout);
+            int tr = 1;
+            // the inputs' fastest-varying dim is a reduced one -> lanes along it coalesce
+            bool red_fast = false;
+            for (int k = 1; k < c.M; ++k)
+                for (int i = c.NK; i < c.N; ++i)
+                    if (std::llabs(c.strides[k][i]) == 1) red_fast = true;
+            if (red_fast || c.nout < 256 * 256) {
+                while (tr < 256 && tr * 2 <= red && (tr < 64 || c.nout * tr < 256 * 1024)) tr <<= 1;
+            }
+            if (red_fast && tr < 16 && red >= 16) tr = 16;
+            plan.part_tr = tr;
+        }
+    }
+    describe(plan);
+    return SMR_OK;
+}
+
+void describe(Plan& plan) {
+    const Canon& c = plan.c;
+    static const char* fam[] = {"auto", "generic", "stream", "tiled", "reduce_all", "reduce_part"};
+    static const char* fk[] = {"prog", "ident", "add2", "add3", "add4", "scale", "sym", "axpy", "axpby", "abs2", "mul2", "expr5"};
+    static const char* ct[] = {"f32", "f64", "c32", "c64"};
+    char buf[1024];
+    int n = std::snprintf(buf, sizeof buf, "family=%s ct=%s%s f=%s N=%d M=%d dims=", fam[plan.family], ct[c.ct],
+                          c.bitcopy ? "(bitcopy)" : (c.mixed ? "(mixed)" : ""), fk[c.fkind], c.N, c.M);
+    for (int i = 0; i < c.N; ++i) n += std::snprintf(buf + n, sizeof buf - n, "%s%lld", i ? "x" : "", (long long)c.dims[i]);
+    if (plan.family == FAM_TILED) {
+        n += std::snprintf(buf + n, sizeof buf - n, " tile=");
+        for (int j = 0; j < plan.tile.nt; ++j)
+            n += std::snprintf(buf + n, sizeof buf - n, "%sd%d:%d", j ? "," : "", plan.tile.tdim[j], 1 << plan.tile.tlog[j]);
+        n += std::snprintf(buf + n, sizeof buf - n, " staged=%d lds=%zu grid=%lld threads=%d", plan.tile.nstaged,
+                           plan.tile.lds_bytes, (long long)plan.tile.grid, plan.tile.threads);
+    } else if (plan.family == FAM_STREAM) {
+        n += std::snprintf(buf + n, sizeof buf - n, " vec=%d", plan.vec);
+    } else if (plan.family == FAM_REDUCE_ALL) {
+        n += std::snprintf(buf + n, sizeof buf - n, " blocks=%d", plan.red_blocks);
+    } else if (plan.family == FAM_REDUCE_PART) {
+        n += std::snprintf(buf + n, sizeof buf - n, " nout=%lld lanes_per_out=%d", (long long)c.nout, plan.part_tr);
+    }
+    std::snprintf(buf + n, sizeof buf - n, " algbytes=%lld", (long long)c.algbytes);
+    plan.desc = buf;
+}
+
+}  // namespace smr

@@ -1,0 +1,331 @@
+"""Map / map-reduce front-ends and the device funnel -- mirror of
+/root/reference/src/mapreduce.jl:1-117.
+
+Julia's `f!` names become `f_` here (PyTorch's in-place convention).  Every front-end ends in
+`_mapreduce_fuse_` -- the reference's single funnel `_mapreduce_fuse!` (src/mapreduce.jl:98) --
+which is where this package crosses the C ABI into libstrided_hip.so (`smr_mapreduce`).  All
+argument checking happens before the funnel, with the reference's error types
+(DimensionMismatch, src/mapreduce.jl:43-46,81); the engine itself never raises for valid input.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import operator
+
+import numpy as np
+
+from . import _lib as L
+from . import expr as E
+from .stridedview import DimensionMismatch, StridedView, smr_dtype
+
+_REDOPS = {
+    "+": L.SMR_RED_ADD, "add": L.SMR_RED_ADD, "add_sum": L.SMR_RED_ADD, operator.add: L.SMR_RED_ADD,
+    "*": L.SMR_RED_MUL, "mul": L.SMR_RED_MUL, "mul_prod": L.SMR_RED_MUL, operator.mul: L.SMR_RED_MUL,
+    "min": L.SMR_RED_MIN, min: L.SMR_RED_MIN, "max": L.SMR_RED_MAX, max: L.SMR_RED_MAX,
+}
+
+
+def _redop_code(op):
+    if op is None:
+        return L.SMR_RED_NONE
+    try:
+        if op in _REDOPS:
+            return _REDOPS[op]
+    except TypeError:
+        pass
+    name = getattr(op, "__name__", None)
+    if name in _REDOPS:
+        return _REDOPS[name]
+    # _init_reduction!'s last method (src/mapreduce.jl:188-191): unknown reductions are an error
+    raise ValueError("unknown reduction; incompatible with the device reduction tree")
+
+
+def _initop_code(initop):
+    """initop -> (smr_initop, beta).  The five forms of test/othertests.jl:76-102 and
+    src/linalg.jl:146-160: nothing, identity, zero / x->0, x->x*beta, x->beta, conj."""
+    if initop is None:
+        return L.SMR_INIT_NONE, 0j
+    if isinstance(initop, str):
+        table = {"identity": L.SMR_INIT_IDENTITY, "zero": L.SMR_INIT_ZERO, "conj": L.SMR_INIT_CONJ}
+        if initop in table:
+            return table[initop], 0j
+        raise ValueError(f"unknown initop {initop!r}")
+    if isinstance(initop, tuple) and len(initop) == 2 and initop[0] in ("scale", "const"):
+        return (L.SMR_INIT_SCALE if initop[0] == "scale" else L.SMR_INIT_CONST), complex(initop[1])
+    if callable(initop):  # trace x -> ...
+        e = E.as_expr(initop(E.Arg(1)))
+        if isinstance(e, E.Arg):
+            return L.SMR_INIT_IDENTITY, 0j
+        if isinstance(e, E.Const):
+            return (L.SMR_INIT_ZERO, 0j) if e.value == 0 else (L.SMR_INIT_CONST, e.value)
+        if isinstance(e, E.Call) and e.op == "conj" and isinstance(e.args[0], E.Arg):
+            return L.SMR_INIT_CONJ, 0j
+        if isinstance(e, E.Call) and e.op == "mul" and len(e.args) == 2:
+            a, b = e.args
+            if isinstance(a, E.Arg) and isinstance(b, E.Const):
+                return L.SMR_INIT_SCALE, b.value
+            if isinstance(b, E.Arg) and isinstance(a, E.Const):
+                return L.SMR_INIT_SCALE, a.value
+    raise NotImplementedError("initop outside the device whitelist {identity, zero, x*beta, beta, conj}")
+
+
+def _current_stream() -> int:
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_stream().cuda_stream)
+    except Exception:
+        pass
+    return 0
+
+
+def build_problem(f, op, initop, dims, arrays, stream=None):
+    """Serialise the funnel's arguments into an `smr_problem` (plus the buffers it points to,
+    which the caller must keep alive for the duration of the call)."""
+    N, M = len(dims), len(arrays)
+    if N == 0:  # 0-dim arrays: one element
+        dims = (1,)
+        arrays = tuple(StridedView(a.parent, (1,), (1,), a.offset, a.op) for a in arrays)
+        N = 1
+    if N > L.SMR_MAXN:
+        raise L.UnsupportedOnDevice(L.SMR_EUNSUPPORTED, f"rank {N} > {L.SMR_MAXN}")
+    if M > L.SMR_MAXM:
+        raise L.UnsupportedOnDevice(L.SMR_EUNSUPPORTED, f"{M} operands > {L.SMR_MAXM}")
+    e = E.trace(f, M - 1)
+    if E.max_arg(e) > M - 1:
+        raise ValueError("f uses more arguments than arrays were given")
+    code, consts = E.serialize(e)
+    p = L.smr_problem()
+    p.N, p.M = N, M
+    for i, d in enumerate(dims):
+        p.dims[i] = int(d)
+    for k, a in enumerate(arrays):
+        if a.size != tuple(dims):
+            raise DimensionMismatch(f"operand {k} has size {a.size}, expected {tuple(dims)}")
+        o = p.ops[k]
+        o.base = a._base
+        o.offset = a.offset
+        for i, s in enumerate(a.strides):
+            o.strides[i] = int(s)
+        o.dtype = smr_dtype(a.dtype)
+        o.conj = 1 if a.op == "conj" else 0
+    codebuf = (C.c_uint8 * len(code))(*code)
+    cflat = []
+    for c in consts:
+        cflat += [c.real, c.imag]
+    constbuf = (C.c_double * max(1, len(cflat)))(*cflat)
+    p.fprog = C.cast(codebuf, C.POINTER(C.c_uint8))
+    p.fprog_len = len(code) // 2
+    p.fconsts = C.cast(constbuf, C.POINTER(C.c_double))
+    p.nconsts = len(consts)
+    p.redop = _redop_code(op)
+    ic, beta = _initop_code(initop)
+    p.initop = ic
+    p.initarg[0], p.initarg[1] = beta.real, beta.imag
+    p.stream = stream if stream is not None else _current_stream()
+    return p, (codebuf, constbuf, arrays)
+
+
+def _mapreduce_fuse_(f, op, initop, dims, arrays):
+    """`_mapreduce_fuse!(f, op, initop, dims, arrays)` (src/mapreduce.jl:98-117): the drop-in
+    boundary.  arrays[0] is the destination; all operands already share `dims` (broadcast /
+    reduced dims have stride 0); no dim is 0.  Runs asynchronously on the current HIP stream."""
+    for a in arrays:
+        if not a.on_device:
+            raise RuntimeError(
+                "strided_jl_amd computes on MI355X only: every StridedView must wrap a torch tensor on a "
+                "HIP device (host views are for the test oracle; there is no CPU fallback)")
+    p, keep = build_problem(f, op, initop, dims, arrays)
+    L.check(L.load().smr_mapreduce(C.byref(p)))
+    return arrays[0]
+
+
+def make_plan(f, op, initop, dims, arrays) -> L.Plan:
+    """Planned form of the funnel (smr_plan_create): canonicalise + choose the kernel once."""
+    p, keep = build_problem(f, op, initop, dims, arrays)
+    return L.Plan(p, keep)
+
+
+# ---- methods based on map! (src/mapreduce.jl:1-14) --------------------------------------------------
+def copy_(dst: StridedView, src: StridedView) -> StridedView:
+    """`Base.copy!(dst, src)` = map!(identity, dst, src)."""
+    return map_(lambda x: x, dst, src)
+
+
+def conj_(a: StridedView) -> StridedView:
+    """`Base.conj!`: no-op for real eltypes (src/mapreduce.jl:5-6)."""
+    if not np.issubdtype(a.dtype, np.complexfloating):
+        return a
+    from . import fn
+    return map_(fn.conj, a, a)
+
+
+def adjoint_(dst: StridedView, src: StridedView) -> StridedView:
+    """`LinearAlgebra.adjoint!(dst, src)` = copy!(dst, adjoint(src)) (src/mapreduce.jl:7-10)."""
+    return copy_(dst, src.adjoint())
+
+
+def transpose_(dst: StridedView, src: StridedView) -> StridedView:
+    return copy_(dst, src.transpose())
+
+
+def permutedims_(dst: StridedView, src: StridedView, p) -> StridedView:
+    """`Base.permutedims!(dst, src, p)` = copy!(dst, permutedims(src, p)) (src/mapreduce.jl:11-14).
+    `p` is 0-based."""
+    return copy_(dst, src.permutedims(p))
+
+
+def copy(a: StridedView) -> StridedView:
+    return copy_(a.similar(), a)
+
+
+def map(f, a1: StridedView, *A: StridedView) -> StridedView:  # noqa: A001
+    """`Base.map(f, a1, A...)`: allocates `similar(a1, promote_eltype)` (src/mapreduce.jl:32-36)."""
+    e = E.trace(f, 1 + len(A))
+    T = E.result_dtype(e, [a1.dtype] + [a.dtype for a in A])
+    return map_(e, a1.similar(T), a1, *A)
+
+
+def map_(f, b: StridedView, a1: StridedView, *A: StridedView) -> StridedView:
+    """`Base.map!(f, b, a1, A...)` (src/mapreduce.jl:38-53)."""
+    dims = b.size
+    if a1.size != dims:
+        raise DimensionMismatch()
+    for a in A:
+        if a.size != dims:
+            raise DimensionMismatch()
+    if any(d == 0 for d in dims):
+        return b  # don't do anything
+    _mapreduce_fuse_(f, None, None, dims, (b, a1) + tuple(A))
+    return b
+
+
+# ---- reductions (src/mapreduce.jl:16-30, 55-96) -----------------------------------------------------
+def _neutral(op, dtype):
+    """_init_reduction! (src/mapreduce.jl:182-187).  For min/max the reference fills with the first
+    mapped element; on the device that would cost a device->host read, so the typed
+    +inf / -inf is used -- the same result for every non-NaN input."""
+    code = _redop_code(op)
+    if code == L.SMR_RED_ADD:
+        return 0
+    if code == L.SMR_RED_MUL:
+        return 1
+    if np.issubdtype(dtype, np.integer):
+        info = np.iinfo(dtype)
+        return info.max if code == L.SMR_RED_MIN else info.min
+    return np.inf if code == L.SMR_RED_MIN else -np.inf
+
+
+def _fill_(out: StridedView, value):
+    from .broadcast import copyto_
+    return copyto_(out, value)
+
+
+def _reduced_dtype(e, op, A):
+    T = E.result_dtype(e, [A.dtype])
+    if T == np.bool_ or (np.issubdtype(T, np.integer) and T.itemsize < 8):
+        # Base.add_sum / mul_prod widen Bool and small ints to Int (src/mapreduce.jl:62-64 via
+        # Base.mapreduce_first)
+        if _redop_code(op) in (L.SMR_RED_ADD, L.SMR_RED_MUL):
+            T = np.dtype(np.int64)
+    return T
+
+
+def _mapreduce(f, op, A: StridedView, init=None):
+    """Complete reduction (src/mapreduce.jl:55-72): a 1-element `out` pre-filled with the neutral
+    element (or `init`), reshaped to all-ones dims, accumulated into by the engine."""
+    e = E.trace(f, 1)
+    if len(A) == 0 or any(d == 0 for d in A.size):
+        # Base.mapreduce_empty: defined for +, * (zero / one); min/max of an empty collection throw
+        code = _redop_code(op)
+        if code in (L.SMR_RED_MIN, L.SMR_RED_MAX) and init is None:
+            raise ValueError("reducing over an empty collection is not allowed")
+        b = _neutral(op, _reduced_dtype(e, op, A))
+        return b if init is None else {L.SMR_RED_ADD: b + init, L.SMR_RED_MUL: b * init}.get(code, init)
+    T = _reduced_dtype(e, op, A)
+    if init is not None:
+        T = np.result_type(T, np.asarray(init).dtype) if not isinstance(init, (int, bool)) else T
+    out = A.similar(T, (1,))
+    _fill_(out, _neutral(op, T) if init is None else init)
+    dims = A.size
+    _mapreducedim_(e, op, None, dims, (out.sreshape((1,) * len(dims)), A))
+    return out.item()
+
+
+def mapreduce(f, op, A: StridedView, dims=None, init=None):
+    """`Base.mapreduce(f, op, A::StridedView; dims=:, init)` (src/mapreduce.jl:16-30)."""
+    if dims is None:
+        return _mapreduce(f, op, A, init)
+    if isinstance(dims, int):
+        dims = (dims,)
+    e = E.trace(f, 1)
+    T = _reduced_dtype(e, op, A)
+    outsize = tuple(1 if d in dims else n for d, n in enumerate(A.size))
+    b = A.similar(T, outsize)  # Base.reducedim_init / reducedim_initarray
+    _fill_(b, _neutral(op, T) if init is None else init)
+    return mapreducedim_(e, op, b, A)
+
+
+def mapreducedim_(f, op, b: StridedView, a1: StridedView, *A: StridedView) -> StridedView:
+    """`Base.mapreducedim!(f, op, b, a1, A...)` (src/mapreduce.jl:74-84): accumulates INTO b."""
+    arrs = (a1,) + tuple(A)
+    N = b.ndim
+    if any(a.ndim != N for a in arrs):
+        raise DimensionMismatch("all arrays must have the same rank")
+    dims = tuple(max([b.size[d]] + [a.size[d] for a in arrs]) for d in range(N))
+    for x in (b,) + arrs:  # Broadcast.check_broadcast_axes
+        for d in range(N):
+            if x.size[d] != dims[d] and x.size[d] != 1:
+                raise DimensionMismatch("array could not be broadcast to match destination")
+    return _mapreducedim_(f, op, None, dims, (b,) + arrs)
+
+
+def _mapreducedim_(f, op, initop, dims, arrays):
+    """`_mapreducedim!` (src/mapreduce.jl:86-96): zero-size rule + promoteshape, then the funnel."""
+    from .broadcast import promoteshape
+    dims = tuple(int(d) for d in dims)
+    if any(d == 0 for d in dims):
+        if len(arrays[0]) != 0 and initop is not None:
+            code, beta = _initop_code(initop)
+            from . import fn
+            table = {
+                L.SMR_INIT_IDENTITY: lambda x: x, L.SMR_INIT_ZERO: lambda x: x * 0,
+                L.SMR_INIT_SCALE: lambda x: x * beta, L.SMR_INIT_CONJ: fn.conj,
+            }
+            if code == L.SMR_INIT_CONST:
+                _fill_(arrays[0], beta if beta.imag else beta.real)
+            else:
+                map_(table[code], arrays[0], arrays[0])
+    else:
+        _mapreduce_fuse_(f, op, initop, dims, promoteshape(dims, *arrays))
+    return arrays[0]
+
+
+def sum(A: StridedView, dims=None, f=None):  # noqa: A001
+    return mapreduce(f or (lambda x: x), "+", A, dims=dims)
+
+
+def prod(A: StridedView, dims=None, f=None):
+    return mapreduce(f or (lambda x: x), "*", A, dims=dims)
+
+
+def maximum(A: StridedView, dims=None, f=None):
+    return mapreduce(f or (lambda x: x), "max", A, dims=dims)
+
+
+def minimum(A: StridedView, dims=None, f=None):
+    return mapreduce(f or (lambda x: x), "min", A, dims=dims)
+
+
+# ---- conversion (src/convert.jl:1-17) -----------------------------------------------------------------
+def Array(a: StridedView, dtype=None) -> np.ndarray:
+    """`Array(a::StridedView)`: allocate dense + copy! (src/convert.jl).  On the device this is
+    a strided gather into a contiguous staging buffer followed by ONE device->host copy; the
+    result is a column-major NumPy array."""
+    if not a.on_device:
+        return np.asfortranarray(a.toarray().astype(dtype or a.dtype, copy=False))
+    b = a.similar(dtype or a.dtype)
+    if len(a) > 0:
+        copy_(b, a)
+    host = b.parent.cpu().numpy()
+    return host.reshape(a.size, order="F")
