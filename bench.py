@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the strided map/reduce hot path on MI355X.
+
+Metric (BASELINE.json): GB/s effective HBM (and % of roofline) for @strided permutedims! +
+broadcast on 32^4 Float64.  One STEP = the two README workloads on one pair of 32^4 f64 arrays,
+inputs resident in HBM:
+    (C2)  permutedims!(B, A, (4,3,2,1))                         README.md:98
+    (C3)  B .= A_p1 .+ A_p2 .+ A_p3 .+ A_p4  (4 permuted views) README.md:104
+Algorithmic bytes per step = 2 launches x (8 MiB read + 8 MiB written) = 33,554,432 B
+(every distinct array counted once).
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run (one rank per GPU); every rank runs the step on its
+own arrays (independent objects, no data-path collective -> "weak" scaling) and the value is
+the whole-job aggregate.  The reduce path (C4, RCCL all-reduce of the per-shard partial) is
+reported under "extra".
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside this run) and
+"cpu_baseline" (the oracle = C++ restatement of the reference's algorithm, on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def colmajor_view(S, t, shape):
+    st, s = [], 1
+    for d in shape:
+        st.append(s)
+        s *= d
+    return S.StridedView(t, shape, tuple(st), 0)
+
+
+def event_time_ms(torch, fn, iters):
+    """Average per-call time of fn() over `iters` back-to-back calls, HIP events on the current
+    stream (the stream the kernels are launched on)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def graph_of(torch, fn, reps):
+    """Capture `reps` calls of fn() into one hipGraph (removes host launch overhead; the
+    kernels are ~microseconds, a Python-side launch is not)."""
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(reps):
+            fn()
+    return g
+
+
+def cpu_baseline(S, budget_s=20.0):
+    """The reference algorithm's CPU path (oracle: fuse/order/blocks/threaded bisection/kernel
+    restated in C++) on the same 32^4 f64 step, timed on this box's host cores."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    n = 32
+    rng = np.random.default_rng(1234)
+    A = S.StridedView(np.asfortranarray(rng.standard_normal((n,) * 4)))
+    B = A.similar()
+    C = A.similar()
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    p2, k2 = S.build_problem(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))), stream=0)
+    p3, k3 = S.build_problem(lambda a, b, c, d: a + b + c + d, None, None, A.size,
+                             (C,) + tuple(A.permutedims(p) for p in perms), stream=0)
+    cores = os.cpu_count() or 1
+    out = {}
+    t_end = time.perf_counter() + budget_s
+    for nt in sorted({1, min(4, cores), cores}):
+        best2 = best3 = 1e30
+        reps = 0
+        t_stop = min(t_end, time.perf_counter() + budget_s / 3)
+        while reps < 5 or (time.perf_counter() < t_stop and reps < 200):
+            t0 = time.perf_counter(); oraclelib.mapreduce(p2, nt); t1 = time.perf_counter()
+            oraclelib.mapreduce(p3, nt); t2 = time.perf_counter()
+            best2, best3 = min(best2, t1 - t0), min(best3, t2 - t1)
+            reps += 1
+        out[nt] = dict(threads=nt, permutedims_ms=best2 * 1e3, broadcast4_ms=best3 * 1e3,
+                       gbs=2 * 16777216 / (best2 + best3) / 1e9, reps=reps)
+    best = max(out.values(), key=lambda d: d["gbs"])
+    return {
+        "value": round(best["gbs"], 3), "unit": "GB/s", "cores": best["threads"], "kind": "port",
+        "sample": "min over %d repetitions of the same 32^4 f64 step (permutedims! + 4-way broadcast), "
+                  "oracle = C++ restatement of the reference algorithm; host has %d cores" % (best["reps"], cores),
+        "by_threads": [out[k] for k in sorted(out)],
+        "readme_4threads_gbs": {"permutedims": 14.07, "broadcast4": 6.00, "hardware": "unstated (README.md:143-153)"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import strided_jl_amd as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    tA = torch.randn(n ** 4, dtype=torch.float64, device=dev, generator=g)
+    tB = torch.empty_like(tA)
+    tC = torch.empty_like(tA)
+    A, B, C = (colmajor_view(S, t, (n,) * 4) for t in (tA, tB, tC))
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    plan2 = S.make_plan(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))))
+    plan3 = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size,
+                        (C,) + tuple(A.permutedims(p) for p in perms))
+    bytes2, bytes3 = plan2.algorithmic_bytes, plan3.algorithmic_bytes
+    assert bytes2 == bytes3 == 2 * 8 * n ** 4
+
+    def cur():
+        return int(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        s = cur()
+        plan2.execute(s)
+        plan3.execute(s)
+
+    # correctness guard inside the bench: outputs must equal the torch permutes exactly
+    step()
+    torch.cuda.synchronize()
+    a4 = tA.reshape((n,) * 4)  # row-major view of the same memory: index order reversed
+    # column-major (i1,i2,i3,i4) <-> torch index [i4,i3,i2,i1]
+    ref2 = a4.permute(3, 2, 1, 0).contiguous().reshape(-1)
+    assert torch.equal(tB, ref2), "permutedims! result is wrong"
+    cm = lambda p: a4.permute(*[3 - p[3 - i] for i in range(4)])  # noqa: E731
+    ref3 = ((cm(perms[0]) + cm(perms[1])) + cm(perms[2])) + cm(perms[3])
+    assert torch.equal(tC, ref3.contiguous().reshape(-1)), "fused 4-way broadcast result is wrong"
+
+    K, W = args.steps, args.warmup
+    for _ in range(W):
+        step()
+    use_graph = not args.no_graph
+    if use_graph:
+        chunk = min(K, 500)
+        while K % chunk:
+            chunk -= 1
+        gstep = graph_of(torch, step, chunk)
+        nrep = K // chunk
+        gstep.replay()  # untimed: first replay uploads the graph
+    barrier()
+    t0 = time.perf_counter()
+    if use_graph:
+        for _ in range(nrep):
+            gstep.replay()
+    else:
+        for _ in range(K):
+            step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * K * (bytes2 + bytes3) / dt / 1e9
+
+    # per-kernel launch durations, HIP events on the launch stream (graph replay of one kernel
+    # type back to back: includes the dependent-launch gap, excludes host overhead)
+    reps = 500
+    s = cur()
+    g2 = graph_of(torch, lambda: plan2.execute(cur()), reps)
+    g3 = graph_of(torch, lambda: plan3.execute(cur()), reps)
+    g2.replay(); g3.replay()
+    torch.cuda.synchronize()
+    ms2 = min(event_time_ms(torch, g2.replay, 4) for _ in range(3)) / reps
+    ms3 = min(event_time_ms(torch, g3.replay, 4) for _ in range(3)) / reps
+    dom = ("broadcast4", ms3, bytes3, plan3) if ms3 >= ms2 else ("permutedims", ms2, bytes2, plan2)
+    achieved = dom[2] / (dom[1] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom[0])
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "us_per_launch": round(dom[1] * 1e3, 3),
+        "per_kernel": {
+            "permutedims": {"us": round(ms2 * 1e3, 3), "GB/s": round(bytes2 / (ms2 * 1e-3) / 1e9, 1),
+                            "frac": round(bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan": plan2.describe()},
+            "broadcast4": {"us": round(ms3 * 1e3, 3), "GB/s": round(bytes3 / (ms3 * 1e-3) / 1e9, 1),
+                           "frac": round(bytes3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan": plan3.describe()},
+        },
+        "note": "32^4 f64 = 8 MiB in + 8 MiB out per launch: the working set is L2/Infinity-Cache resident across "
+                "back-to-back launches, so 'achieved' is effective (algorithmic bytes / launch time), not DRAM traffic",
+    }
+
+    extra = {}
+    if not args.no_extra:
+        extra = secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur)
+
+    if rank == 0:
+        out = {
+            "metric": "GB/s effective HBM for @strided permutedims!+broadcast, 32^4 fp64",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]+configs[2]: permutedims!(B,A,(4,3,2,1)) then B .= sum of 4 permuted views, "
+                                   "32x32x32x32 Float64, one pair of arrays per GPU",
+                       "algorithmic_bytes_per_step": bytes2 + bytes3, "launch": "hipGraph" if use_graph else "eager",
+                       "parallelism": "replicas x%d (independent arrays per rank)" % world},
+            "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            "roofline": roofline,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(S)
+        if extra:
+            out["extra"] = extra
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur):
+    """The other BASELINE.json configs, short runs (not the headline value)."""
+    res = {}
+    fn = S.fn
+
+    def timed(plan, reps=50):
+        g = graph_of(torch, lambda: plan.execute(cur()), reps)
+        g.replay()
+        torch.cuda.synchronize()
+        ms = min(event_time_ms(torch, g.replay, 2) for _ in range(3)) / reps
+        return ms
+
+    def rec(name, plan, ms):
+        b = plan.algorithmic_bytes
+        res[name] = {"us": round(ms * 1e3, 2), "GB/s": round(b / (ms * 1e-3) / 1e9, 1),
+                     "frac_of_8TBs": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan": plan.describe()}
+
+    # C1 symmetrise 4000^2 f64
+    m = 4000
+    tA = torch.randn(m * m, dtype=torch.float64, device=dev)
+    tB = torch.empty_like(tA)
+    A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
+    p = S.make_plan(lambda x, y: (x + y) / 2, None, None, (m, m), (B, A, A.adjoint()))
+    rec("c1_symmetrise_4000_f64", p, timed(p))
+    # true-HBM variant of the headline: 128^4 f64 (2 GiB in, 2 GiB out)
+    n = 128
+    tA = torch.randn(n ** 4, dtype=torch.float64, device=dev)
+    tB = torch.empty_like(tA)
+    A, B = colmajor_view(S, tA, (n,) * 4), colmajor_view(S, tB, (n,) * 4)
+    p = S.make_plan(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))))
+    rec("permutedims_128^4_f64", p, timed(p, 5))
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    p = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (B,) + tuple(A.permutedims(q) for q in perms))
+    rec("broadcast4_128^4_f64", p, timed(p, 5))
+    del tA, tB
+    # C5 compute-bound map 8192^2 f32
+    m = 8192
+    tA = torch.rand(m * m, dtype=torch.float32, device=dev)
+    tB = torch.empty_like(tA)
+    A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
+    p = S.make_plan(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, (m, m), (B, A))
+    rec("c5_expr_8192_f32", p, timed(p, 20))
+    # C4 mapreduce(abs2,+) 4096x4096x64 f32 sharded over the ranks on dim 3 + RCCL all-reduce
+    slab = 64 // world if 64 % world == 0 else 64
+    tA = (torch.rand(4096 * 4096 * slab, dtype=torch.float32, device=dev) * 2 - 1)
+    A = colmajor_view(S, tA, (4096, 4096, slab))
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    O = S.StridedView(out, A.size, (0, 0, 0), 0)
+    p = S.make_plan(fn.abs2, "+", None, A.size, (O, A))
+    if world > 1:
+        import torch.distributed as dist
+
+    def c4():
+        out.zero_()
+        p.execute(cur())
+        if world > 1:
+            dist.all_reduce(out)
+
+    for _ in range(3):
+        c4()
+    torch.cuda.synchronize()
+    got = float(out.item())
+    ms = min(event_time_ms(torch, c4, 10) for _ in range(3))
+    b = 4 * 4096 * 4096 * slab * world
+    truth = float((tA.double() ** 2).sum().item())
+    if world > 1:
+        tt = torch.tensor([truth], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt)
+        truth = float(tt.item())
+    res["c4_mapreduce_abs2_4096x4096x64_f32"] = {
+        "us": round(ms * 1e3, 2), "GB/s_total": round(b / (ms * 1e-3) / 1e9, 1), "shards": world,
+        "frac_of_8TBs_per_gpu": round(b / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "rel_err_vs_f64": abs(got - truth) / truth, "plan": p.describe(),
+        "collective": "RCCL all_reduce(1 x f32)" if world > 1 else "none"}
+    return res
+
+
+if __name__ == "__main__":
+    main()

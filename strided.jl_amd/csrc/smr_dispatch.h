@@ -76,6 +76,9 @@ inline OpTab make_optab(const Canon& c, void* const* bases) {
     return t;
 }
 
+// A failed earlier HIP call (e.g. an attribute query) must not be mistaken for a launch failure.
+inline void clear_sticky_error() { (void)hipGetLastError(); }
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_error(e, what);

@@ -79,6 +79,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M) ? c.strides[k][i] : 0;
     i64 blocks = (c.total + 255) / 256;
     blocks = std::min<i64>(blocks, 256 * 32);
+    clear_sticky_error();
     hipLaunchKernelGGL((k_generic_map<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
     return check_launch("k_generic_map");
 }

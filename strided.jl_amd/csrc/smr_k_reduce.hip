@@ -281,13 +281,15 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         if (((uintptr_t)a.ops.base[k]) % 16) vec = false;
     }
     if constexpr (!MIXED && VMAX > 1) {
+        clear_sticky_error();
         if (vec) hipLaunchKernelGGL((k_reduce_all<T, F, false, VMAX>), dim3(blocks), dim3(256), 0, s, a, f);
     }
     if (!vec) hipLaunchKernelGGL((k_reduce_all<T, F, MIXED, 1>), dim3(blocks), dim3(256), 0, s, a, f);
     int rc = check_launch("k_reduce_all");
     if (rc) return rc;
     if (blocks > 1) {
-        hipLaunchKernelGGL((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
+        clear_sticky_error();
+    hipLaunchKernelGGL((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
         rc = check_launch("k_reduce_final");
     }
     return rc;
@@ -304,6 +306,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     const int ob = 256 / a.tr;
     const i64 blocks = (c.nout + ob - 1) / ob;
     if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
+    clear_sticky_error();
     hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
     return check_launch("k_reduce_part");
 }

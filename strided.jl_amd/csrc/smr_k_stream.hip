@@ -126,6 +126,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
     const i64 grid = a.bpr * a.rows;
     if (grid > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "stream grid too large");
+    clear_sticky_error();
     hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
     return check_launch("k_stream_map");
 }

@@ -5,15 +5,25 @@
 //   * a workgroup owns one N-d tile whose extents are powers of two and which is long enough
 //     along EVERY operand's unit-stride axis;
 //   * phase 1: each transposed input is read from HBM in ITS OWN stride order (consecutive
-//     lanes walk that input's unit-stride axis -> coalesced) and scattered into an LDS tile
-//     laid out in DESTINATION order, XOR-swizzled so that the strided LDS writes of a lane
-//     group fall on distinct banks;
+//     lanes walk that input's unit-stride axis -> coalesced, 16 bytes per lane) and scattered
+//     into an LDS tile laid out in DESTINATION order, XOR-swizzled so that the strided LDS
+//     writes of a lane group fall on distinct banks; every load is issued before the first
+//     LDS write (memory-level parallelism);
 //   * phase 2: the tile is walked in destination order: staged inputs come from LDS
 //     (conflict-free linear reads), inputs that already share the destination's unit axis
-//     come straight from HBM, f is applied in registers, the store is coalesced.
-// Because the extents are powers of two the element index inside a tile is pure bit slicing,
-// and e = r*T + tid splits into a per-thread part (computed once) and a wave-uniform part
-// (scalar registers) that are combined with one add (global offset) / one xor (LDS index).
+//     come straight from HBM, f is applied in registers, the store is coalesced (16 B/lane).
+//
+// Index arithmetic.  Tile extents are powers of two, so the position e of an element inside a
+// tile (in any operand's enumeration order) is a bit string, and both its global byte offset
+// and its swizzled LDS index are ADD/XOR-linear in those bits.  A lane owns NREP vectors of V
+// consecutive elements: e = ((r*256 + tid) << vlog) + h.  The host ships, per operand,
+//     Gt[b], Lt[b]  b < 8      contribution of bit b of tid   (8 masked VALU adds per phase)
+//     Gr[r], Lr[r]  r < NREP   contribution of repeat index r (pre-combined: no ALU at all)
+//     Lh[h]         h < V      LDS index of sub-element h
+// so the loops contain no scalar arithmetic.  Measured history (32^4 f64 permutedims!, kernel
+// time): generic per-dim decode with dependent kernarg loads 11.5 us (~2000 SALU
+// instructions per wave: bound by the CU's single scalar unit) -> per-bit tables 6.0 us
+// (~430 SALU) -> this version.
 #include "smr_dispatch.h"
 
 #ifndef SMR_CT
@@ -23,228 +33,515 @@
 namespace smr {
 
 constexpr int MAXT = 5;
+constexpr int THRLOG = 8;   // 256 threads, always
+constexpr int NG = 4;       // grid dims decoded branch-free; further ones in a (rare) loop
+constexpr int MAXREP = 16;  // max vectors per lane
+constexpr int MAXV = 16;    // max elements per vector (1-byte elements)
 
-struct TiledArgs {
-    OpTab ops;
-    int32_t N, M, nt, tilelog, thrlog, nstaged, swz, xcd;
-    i64 nblocks;
-    i64 dims[MAXN];
-    i64 ntiles[MAXN];
-    int32_t tlogdim[MAXN];
-    i64 strides[MAXM][MAXN];
-    int32_t tdim[MAXT], tlog[MAXT], lsh[MAXT];
-    int32_t staged[MAXM];
-    int32_t esh[MAXM][MAXT];  // bit position of tiled dim j inside the enumeration index
-                              // of operand k (k = 0: destination order == lsh)
+template <bool WIDE> struct off_t_of { typedef uint32_t type; };
+template <> struct off_t_of<true> { typedef i64 type; };
+
+// One operand as the kernel sees it.  Staged inputs are enumerated in their own stride order,
+// the destination and direct inputs in destination order.
+template <bool WIDE>
+struct OpDesc {
+    typedef typename off_t_of<WIDE>::type O;
+    void* base;  // element offset already applied
+    int32_t dtype, conj;
+    int32_t vecok, pad_;
+    O Gt[THRLOG];
+    O Gr[MAXREP];
+    O Gh[MAXV];            // byte offset of sub-element h (only used when !vecok)
+    uint32_t Lt[THRLOG];   // staged: swizzled LDS index contributions (own order)
+    uint32_t Lr[MAXREP];
+    uint32_t Lh[MAXV];
+    i64 tstep[MAXN];       // byte offset of one tile step along grid dim g
+    uint32_t tstep32[NG];
 };
 
-SMR_DEV uint32_t lds_swizzle(uint32_t l, int w) {
-    if (w == 0) return l;
-    const uint32_t x = l >> w;
-    const uint32_t f = (x ^ (x >> w) ^ (x >> (2 * w)) ^ (x >> (3 * w))) & ((1u << w) - 1u);
-    return l ^ f;
+template <bool WIDE>
+struct TiledArgs {
+    OpDesc<WIDE> dst;            // destination (destination order)
+    OpDesc<WIDE> in[MAXIN];      // inputs 1..M-1 in operand order
+    int32_t slot_in[MAXIN];      // input index (0-based) staged in LDS slot s
+    int32_t staged[MAXIN];       // LDS slot of input i or -1
+    uint32_t Ltd[THRLOG], Lrd[MAXREP], Lhd[MAXV];  // destination-order LDS index tables
+    uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
+    int32_t M, ng, tilelog, nstaged, xcd, base32;
+    uint32_t nblocks;
+    // edge tiles only
+    int32_t nt;
+    int32_t tgrid[MAXT], tlog[MAXT];  // grid dim / log2 extent of tiled dim j
+    int32_t esh[MAXM][MAXT];          // [0] = destination order, [1+i] = input i's order
+    i64 gdims[MAXN];
+    int32_t glog[MAXN];
+};
+
+SMR_DEV uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s) { return (__umulhi(m, n) + n) >> s; }
+
+// all-ones / zero 32-bit mask widened to the offset type
+template <class O> SMR_DEV O m_ext(uint32_t m);
+template <> SMR_DEV uint32_t m_ext<uint32_t>(uint32_t m) { return m; }
+template <> SMR_DEV i64 m_ext<i64>(uint32_t m) { return (i64)(int32_t)m; }
+
+template <class T, int V>
+struct alignas(sizeof(T) * V) TVec {
+    T v[V];
+};
+
+template <class T, bool MIXED>
+SMR_DEV T load_at(const char* p, int dtype, int conj) {
+    T v;
+    if constexpr (MIXED)
+        v = ld_as<T>(p, 0, dtype);
+    else
+        v = *reinterpret_cast<const T*>(p);
+    if constexpr (tr<T>::cx) {
+        if (conj) v = cj(v);
+    }
+    return v;
+}
+template <class T, bool MIXED>
+SMR_DEV void store_at(char* p, int dtype, int conj, T v) {
+    if constexpr (tr<T>::cx) {
+        if (conj) v = cj(v);
+    }
+    if constexpr (MIXED)
+        st_as<T>(p, 0, dtype, v);
+    else
+        *reinterpret_cast<T*>(p) = v;
 }
 
-template <class T, class F, bool MIXED>
-__global__ void __launch_bounds__(256) k_tiled_map(TiledArgs a, F f) {
+// V > 1 implies !MIXED && !WIDE (enforced by the launcher).
+template <class T, class F, bool MIXED, bool WIDE, int V, int NREP>
+__global__ void __launch_bounds__(256) k_tiled_map(const TiledArgs<WIDE> a, F f) {
+    typedef typename off_t_of<WIDE>::type O;
+    typedef TVec<T, V> VT;
+    constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : (V == 4 ? 2 : (V == 8 ? 3 : 4)));
+    constexpr int NIN_STATIC = F::NIN;
+    constexpr int NINMAX = (NIN_STATIC >= 0) ? NIN_STATIC : MAXIN;
+    // phase-2 chunk: vectors whose loads are in flight together (register budget)
+    constexpr int CAP = (NIN_STATIC < 0) ? 2 : (NIN_STATIC <= 1 ? 16 : (NIN_STATIC <= 2 ? 8 : 4));
+    constexpr int G2 = NREP < CAP ? NREP : CAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
-    const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
+    const int nin = (NIN_STATIC >= 0) ? NIN_STATIC : a.M - 1;
     const uint32_t tid = threadIdx.x;
 
-    // ---- which tile (XCD-aware: blocks b, b+8, b+16.. share an XCD and hence an L2; give
-    // each XCD a contiguous range of tiles so neighbouring tiles share cache lines there)
-    i64 b = blockIdx.x;
-    if (a.xcd) {
-        const i64 per = a.nblocks >> 3;
-        b = (b & 7) * per + (b >> 3);
+    // ---- which tile -----------------------------------------------------------------------------
+    uint32_t b = blockIdx.x;
+    if (a.xcd) b = (b & 7u) * (a.nblocks >> 3) + (b >> 3);  // XCD-contiguous tile ranges (optional)
+    uint32_t tc[MAXN];
+    uint32_t edge = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {  // unused grid dims are padded with ntiles = 1
+        const uint32_t q = fastdiv(b, a.div_m[g], a.div_s[g]);
+        tc[g] = b - q * a.ntiles[g];
+        b = q;
+        edge |= (tc[g] == a.last_ragged[g]) ? 1u : 0u;
     }
-    i64 org[MAXN];  // tile origin per canonical dim (wave-uniform)
+#pragma unroll
+    for (int g = NG; g < MAXN; ++g) tc[g] = 0;
+    if (a.ng > NG) {
+#pragma unroll
+        for (int g = NG; g < MAXN; ++g) {
+            const uint32_t q = fastdiv(b, a.div_m[g], a.div_s[g]);
+            tc[g] = b - q * a.ntiles[g];
+            b = q;
+            edge |= (tc[g] == a.last_ragged[g]) ? 1u : 0u;
+        }
+    }
     uint32_t lim[MAXT];
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) lim[j] = 1;
-    bool full = true;
-    {
-        i64 rem = b;
+    for (int j = 0; j < MAXT; ++j) lim[j] = 0x7fffffffu;
+    if (edge) {
 #pragma unroll
-        for (int d = 0; d < MAXN; ++d) {
-            org[d] = 0;
-            if (d < a.N) {
-                const i64 q = rem / a.ntiles[d];
-                const i64 t = rem - q * a.ntiles[d];
-                rem = q;
-                org[d] = t << a.tlogdim[d];
-                const i64 left = a.dims[d] - org[d];
-                if (left < ((i64)1 << a.tlogdim[d])) full = false;
+        for (int j = 0; j < MAXT; ++j)
+            if (j < a.nt && a.tgrid[j] >= 0) {
+                const int g = a.tgrid[j];
+                i64 left = a.gdims[g];
 #pragma unroll
-                for (int j = 0; j < MAXT; ++j)
-                    if (j < a.nt && a.tdim[j] == d) lim[j] = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
+                for (int gg = 0; gg < MAXN; ++gg)
+                    if (gg == g) left -= (i64)tc[gg] << a.glog[gg];
+                lim[j] = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
             }
-        }
     }
-    const int nrep = 1 << (a.tilelog - a.thrlog);
-
-    // ---- phase 1: stage transposed inputs into LDS in destination order ------------------------
-#pragma unroll 1
-    for (int k = 1; k < MAXM; ++k) {
-        if (k >= a.M || a.staged[k] < 0) continue;
-        T* L = lds + ((size_t)a.staged[k] << a.tilelog);
-        uint32_t ct[MAXT];
-        i64 gt = 0;
+    auto in_bounds = [&](int row, uint32_t e) {
+        bool ok = true;
 #pragma unroll
-        for (int d = 0; d < MAXN; ++d)
-            if (d < a.N) gt += org[d] * a.strides[k][d];
+        for (int j = 0; j < MAXT; ++j)
+            if (j < a.nt) ok = ok && (((e >> a.esh[row][j]) & ((1u << a.tlog[j]) - 1u)) < lim[j]);
+        return ok;
+    };
+    auto tile_base = [&](const OpDesc<WIDE>& d) -> char* {
+        if (a.base32) {  // whole operand spans < 4 GiB and no negative tile step
+            uint32_t o = 0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) o += tc[g] * d.tstep32[g];
+            return (char*)d.base + o;
+        }
+        i64 o = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) o += (i64)tc[g] * d.tstep[g];
+        if (a.ng > NG) {
+#pragma unroll
+            for (int g = NG; g < MAXN; ++g) o += (i64)tc[g] * d.tstep[g];
+        }
+        return (char*)d.base + o;
+    };
+    uint32_t tm[THRLOG];  // all-ones where the tid bit is set
+#pragma unroll
+    for (int bit = 0; bit < THRLOG; ++bit) tm[bit] = 0u - ((tid >> bit) & 1u);
+
+    // ---- phase 1: stage transposed inputs into LDS in destination order -------------------------
+#pragma unroll 1
+    for (int s = 0; s < a.nstaged; ++s) {
+        const int i = a.slot_in[s];
+        const OpDesc<WIDE>& d = a.in[i];
+        const char* bp = tile_base(d);
+        const int dt = d.dtype, cjk = d.conj;
+        T* L = lds + ((size_t)s << a.tilelog);
+        O gt = 0;
         uint32_t lt = 0;
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j) {
-            ct[j] = 0;
-            if (j < a.nt) {
-                ct[j] = (tid >> a.esh[k][j]) & ((1u << a.tlog[j]) - 1u);
-                gt += (i64)ct[j] * a.strides[k][a.tdim[j]];
-                lt |= ct[j] << a.lsh[j];
-            }
+        for (int bit = 0; bit < THRLOG; ++bit) {
+            gt += d.Gt[bit] & m_ext<O>(tm[bit]);
+            lt ^= d.Lt[bit] & tm[bit];
         }
-        lt = lds_swizzle(lt, a.swz);
-#pragma unroll 4
-        for (int r = 0; r < nrep; ++r) {
-            const uint32_t er = (uint32_t)r << a.thrlog;  // wave-uniform
-            i64 gr = 0;
-            uint32_t lr = 0;
-            bool ok = true;
+        VT v[NREP];
+        bool ok[NREP];
 #pragma unroll
-            for (int j = 0; j < MAXT; ++j) {
-                if (j < a.nt) {
-                    const uint32_t cr = (er >> a.esh[k][j]) & ((1u << a.tlog[j]) - 1u);
-                    gr += (i64)cr * a.strides[k][a.tdim[j]];
-                    lr |= cr << a.lsh[j];
-                    ok = ok && ((ct[j] | cr) < lim[j]);
+        for (int r = 0; r < NREP; ++r) {
+            ok[r] = true;
+            if (edge) ok[r] = in_bounds(1 + i, (((uint32_t)r << THRLOG) | tid) << VLOG);
+            if (ok[r]) {
+                const char* p = bp + (gt + d.Gr[r]);
+                if constexpr (V == 1) {
+                    v[r].v[0] = load_at<T, MIXED>(p, dt, cjk);
+                } else {
+                    v[r] = *reinterpret_cast<const VT*>(p);
+                    if constexpr (tr<T>::cx) {
+                        if (cjk) {
+#pragma unroll
+                            for (int h = 0; h < V; ++h) v[r].v[h] = cj(v[r].v[h]);
+                        }
+                    }
                 }
             }
-            lr = lds_swizzle(lr, a.swz);
-            if (full || ok) L[lt ^ lr] = load_op<T, MIXED>(a.ops, k, gt + gr);
+        }
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            if (ok[r]) {
+#pragma unroll
+                for (int h = 0; h < V; ++h) L[lt ^ d.Lr[r] ^ d.Lh[h]] = v[r].v[h];
+            }
         }
     }
     __syncthreads();
 
-    // ---- phase 2: destination order ---------------------------------------------------------------
-    uint32_t ct[MAXT];
-    i64 gt[MAXM];
+    // ---- phase 2: destination order ----------------------------------------------------------------
+    char* bp0 = tile_base(a.dst);
+    O gt0 = 0;
     uint32_t lt = 0;
 #pragma unroll
-    for (int k = 0; k < MAXM; ++k) {
-        gt[k] = 0;
-        if (k < a.M && (k == 0 || a.staged[k] < 0)) {
+    for (int bit = 0; bit < THRLOG; ++bit) {
+        gt0 += a.dst.Gt[bit] & m_ext<O>(tm[bit]);
+        lt ^= a.Ltd[bit] & tm[bit];
+    }
+    const char* bpi[NINMAX > 0 ? NINMAX : 1];
+    O gti[NINMAX > 0 ? NINMAX : 1];
 #pragma unroll
-            for (int d = 0; d < MAXN; ++d)
-                if (d < a.N) gt[k] += org[d] * a.strides[k][d];
+    for (int i = 0; i < NINMAX; ++i) {
+        bpi[i] = nullptr;
+        gti[i] = 0;
+        if (i < nin && a.staged[i] < 0) {
+            bpi[i] = tile_base(a.in[i]);
+#pragma unroll
+            for (int bit = 0; bit < THRLOG; ++bit) gti[i] += a.in[i].Gt[bit] & m_ext<O>(tm[bit]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-        ct[j] = 0;
-        if (j < a.nt) {
-            ct[j] = (tid >> a.lsh[j]) & ((1u << a.tlog[j]) - 1u);
-            lt |= ct[j] << a.lsh[j];
+    for (int r0 = 0; r0 < NREP; r0 += G2) {
+        VT x[G2][NINMAX > 0 ? NINMAX : 1];
+        bool ok[G2];
 #pragma unroll
-            for (int k = 0; k < MAXM; ++k)
-                if (k < a.M && (k == 0 || a.staged[k] < 0)) gt[k] += (i64)ct[j] * a.strides[k][a.tdim[j]];
-        }
-    }
-    lt = lds_swizzle(lt, a.swz);
-#pragma unroll 4
-    for (int r = 0; r < nrep; ++r) {
-        const uint32_t er = (uint32_t)r << a.thrlog;
-        uint32_t lr = 0;
-        bool ok = true;
-        i64 gr[MAXM];
+        for (int u = 0; u < G2; ++u) {
+            const int r = r0 + u;
+            ok[u] = true;
+            if (edge) ok[u] = in_bounds(0, (((uint32_t)r << THRLOG) | tid) << VLOG);
 #pragma unroll
-        for (int k = 0; k < MAXM; ++k) gr[k] = 0;
+            for (int i = 0; i < NINMAX; ++i) {
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j) {
-            if (j < a.nt) {
-                const uint32_t cr = (er >> a.lsh[j]) & ((1u << a.tlog[j]) - 1u);
-                lr |= cr << a.lsh[j];
-                ok = ok && ((ct[j] | cr) < lim[j]);
+                for (int h = 0; h < V; ++h) x[u][i].v[h] = T{};
+                if (i < nin && ok[u]) {
+                    const OpDesc<WIDE>& d = a.in[i];
+                    if (a.staged[i] < 0) {
+                        const char* p = bpi[i] + (gti[i] + d.Gr[r]);
+                        if constexpr (V == 1) {
+                            x[u][i].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
+                        } else {
+                            if (d.vecok) {
+                                x[u][i] = *reinterpret_cast<const VT*>(p);
+                            } else {  // broadcast / non-unit stride along the destination axis
 #pragma unroll
-                for (int k = 0; k < MAXM; ++k)
-                    if (k < a.M && (k == 0 || a.staged[k] < 0)) gr[k] += (i64)cr * a.strides[k][a.tdim[j]];
-            }
-        }
-        lr = lds_swizzle(lr, a.swz);
-        if (full || ok) {
-            const uint32_t l = lt ^ lr;
-            T in[MAXIN];
+                                for (int h = 0; h < V; ++h) x[u][i].v[h] = *reinterpret_cast<const T*>(p + d.Gh[h]);
+                            }
+                            if constexpr (tr<T>::cx) {
+                                if (d.conj) {
 #pragma unroll
-            for (int k = 0; k < MAXIN; ++k) {
-                in[k] = T{};
-                if (k < nin) {
-                    if (a.staged[k + 1] >= 0)
-                        in[k] = lds[((size_t)a.staged[k + 1] << a.tilelog) + l];
-                    else
-                        in[k] = load_op<T, MIXED>(a.ops, k + 1, gt[k + 1] + gr[k + 1]);
+                                    for (int h = 0; h < V; ++h) x[u][i].v[h] = cj(x[u][i].v[h]);
+                                }
+                            }
+                        }
+                    } else {
+                        const T* Ls = lds + ((size_t)a.staged[i] << a.tilelog);
+#pragma unroll
+                        for (int h = 0; h < V; ++h) x[u][i].v[h] = Ls[lt ^ a.Lrd[r] ^ a.Lhd[h]];
+                    }
                 }
             }
-            store_op<T, MIXED>(a.ops, gt[0] + gr[0], f(in));
+        }
+#pragma unroll
+        for (int u = 0; u < G2; ++u) {
+            const int r = r0 + u;
+            if (ok[u]) {
+                VT out;
+#pragma unroll
+                for (int h = 0; h < V; ++h) {
+                    T arg[MAXIN];
+#pragma unroll
+                    for (int i = 0; i < MAXIN; ++i) {
+                        arg[i] = T{};
+                        if (i < NINMAX) arg[i] = x[u][i < NINMAX ? i : 0].v[h];
+                    }
+                    out.v[h] = f(arg);
+                }
+                char* p = bp0 + (gt0 + a.dst.Gr[r]);
+                if constexpr (V == 1) {
+                    store_at<T, MIXED>(p, a.dst.dtype, a.dst.conj, out.v[0]);
+                } else {
+                    if constexpr (tr<T>::cx) {
+                        if (a.dst.conj) {
+#pragma unroll
+                            for (int h = 0; h < V; ++h) out.v[h] = cj(out.v[h]);
+                        }
+                    }
+                    *reinterpret_cast<VT*>(p) = out;
+                }
+            }
         }
     }
+}
+
+static uint32_t host_swizzle(uint32_t l, int w) {
+    if (w == 0) return l;
+    const uint32_t x = l >> w;
+    const uint32_t f = (x ^ (x >> w) ^ (x >> (2 * w)) ^ (x >> (3 * w)) ^ (x >> (4 * w))) & ((1u << w) - 1u);
+    return l ^ f;
+}
+
+template <class T, class F, bool MIXED, bool WIDE, int V, int NREP>
+static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+    typedef typename off_t_of<WIDE>::type O;
+    const Canon& c = plan.c;
+    const TilePlan& t = plan.tile;
+    int vlog = 0;
+    while ((1 << vlog) < V) ++vlog;
+    TiledArgs<WIDE> a;
+    std::memset(&a, 0, sizeof a);
+    a.M = c.M;
+    a.nt = t.nt;
+    a.tilelog = t.tilelog;
+    a.nstaged = t.nstaged;
+    a.nblocks = (uint32_t)t.grid;
+    a.xcd = (options().xcd_swizzle && (t.grid % 8 == 0) && t.grid >= 16) ? 1 : 0;
+    // swizzle width: the 128 B an LDS write group spans, in elements
+    int w = 0;
+    while ((sizeof(T) << w) < 128) ++w;
+    if (t.tilelog <= w) w = 0;
+    int tlogdim[MAXN] = {0};
+    int lsh[MAXT];
+    int sh = 0;
+    for (int j = 0; j < t.nt; ++j) {
+        lsh[j] = sh;
+        tlogdim[t.tdim[j]] = t.tlog[j];
+        sh += t.tlog[j];
+    }
+    // grid dims: canonical dims with more than one tile, in canonical order
+    int gof[MAXN], ng = 0;
+    for (int d = 0; d < c.N; ++d) {
+        gof[d] = -1;
+        if (t.ntiles[d] > 1) gof[d] = ng++;
+    }
+    for (int g = 0; g < MAXN; ++g) {
+        a.ntiles[g] = 1;
+        a.div_m[g] = 0;
+        a.div_s[g] = 0;
+        a.last_ragged[g] = 0xffffffffu;
+        a.gdims[g] = 1;
+        a.glog[g] = 0;
+    }
+    for (int d = 0; d < c.N; ++d) {
+        const int g = gof[d];
+        if (g < 0) continue;
+        const uint32_t nt = (uint32_t)t.ntiles[d];
+        a.ntiles[g] = nt;
+        int l = 0;
+        while ((1ull << l) < nt) ++l;
+        a.div_m[g] = (uint32_t)((((1ull << 32) * ((1ull << l) - nt)) / nt) + 1);
+        a.div_s[g] = (uint32_t)l;
+        a.gdims[g] = c.dims[d];
+        a.glog[g] = tlogdim[d];
+        if (c.dims[d] & (((i64)1 << tlogdim[d]) - 1)) a.last_ragged[g] = nt - 1;
+    }
+    for (int j = 0; j < t.nt; ++j) {
+        a.tlog[j] = t.tlog[j];
+        int g = gof[t.tdim[j]];
+        if (g < 0 && (c.dims[t.tdim[j]] & (((i64)1 << t.tlog[j]) - 1))) {
+            // a tiled dim covered by a single, partly empty tile: give it a one-tile grid slot so
+            // that every workgroup takes the bounds-checked path
+            if (ng >= MAXN) return set_error(SMR_EUNSUPPORTED, "tiled: too many grid dims");
+            g = ng++;
+            a.gdims[g] = c.dims[t.tdim[j]];
+            a.glog[g] = t.tlog[j];
+            a.last_ragged[g] = 0;  // tc == 0 always
+        }
+        a.tgrid[j] = g;
+    }
+    a.ng = ng;
+    // 32-bit tile-origin arithmetic when every operand's tile origins stay below 4 GiB
+    bool base32 = ng <= NG;
+    for (int k = 0; k < c.M && base32; ++k) {
+        long double span = 0;
+        for (int d = 0; d < c.N; ++d) {
+            if (gof[d] < 0) continue;
+            if (c.strides[k][d] < 0) base32 = false;
+            span += (long double)c.strides[k][d] * c.esize[k] * (long double)(t.ntiles[d] - 1) * (long double)((i64)1 << tlogdim[d]);
+        }
+        if (span >= 4294967296.0L) base32 = false;
+    }
+    a.base32 = base32 ? 1 : 0;
+
+    auto fill = [&](OpDesc<WIDE>& d, int k, bool own) {
+        const i64 es = c.esize[k];
+        d.base = tab.base[k];
+        d.dtype = tab.dtype[k];
+        d.conj = tab.conj[k];
+        for (int dd = 0; dd < c.N; ++dd)
+            if (gof[dd] >= 0) {
+                const i64 st = c.strides[k][dd] * ((i64)1 << tlogdim[dd]) * es;
+                d.tstep[gof[dd]] = st;
+                if (gof[dd] < NG) d.tstep32[gof[dd]] = (uint32_t)st;
+            }
+        // per-bit contributions in this operand's enumeration order
+        i64 gbit[32] = {0};
+        uint32_t lbit[32] = {0};
+        int pos = 0;
+        for (int jj = 0; jj < t.nt; ++jj) {
+            const int j = own ? t.order[k][jj] : jj;
+            a.esh[own ? k : 0][j] = pos;
+            if (!own && k > 0) a.esh[k][j] = pos;
+            for (int bit = 0; bit < t.tlog[j]; ++bit) {
+                gbit[pos + bit] = c.strides[k][t.tdim[j]] * ((i64)1 << bit) * es;
+                lbit[pos + bit] = host_swizzle(1u << (lsh[j] + bit), w);
+            }
+            pos += t.tlog[j];
+        }
+        for (int h = 0; h < V; ++h) {
+            i64 g = 0;
+            uint32_t l = 0;
+            for (int bit = 0; bit < vlog; ++bit)
+                if ((h >> bit) & 1) { g += gbit[bit]; l ^= lbit[bit]; }
+            d.Gh[h] = (O)g;
+            d.Lh[h] = l;
+        }
+        for (int bit = 0; bit < THRLOG; ++bit) {
+            d.Gt[bit] = (O)gbit[vlog + bit];
+            d.Lt[bit] = lbit[vlog + bit];
+        }
+        for (int r = 0; r < NREP; ++r) {
+            i64 g = 0;
+            uint32_t l = 0;
+            for (int bit = 0; bit < 5; ++bit)
+                if ((r >> bit) & 1) { g += gbit[vlog + THRLOG + bit]; l ^= lbit[vlog + THRLOG + bit]; }
+            d.Gr[r] = (O)g;
+            d.Lr[r] = l;
+        }
+        // one V-wide access is possible when the operand is unit-stride along its first axis
+        const int j0 = own ? t.order[k][0] : 0;
+        d.vecok = (c.strides[k][t.tdim[j0]] == 1) ? 1 : 0;
+    };
+    fill(a.dst, 0, false);
+    for (int bit = 0; bit < THRLOG; ++bit) a.Ltd[bit] = a.dst.Lt[bit];
+    for (int r = 0; r < NREP; ++r) a.Lrd[r] = a.dst.Lr[r];
+    for (int h = 0; h < V; ++h) a.Lhd[h] = a.dst.Lh[h];
+    for (int i = 0; i < MAXIN; ++i) a.staged[i] = -1;
+    for (int k = 1; k < c.M; ++k) {
+        const bool own = t.staged[k] >= 0;
+        fill(a.in[k - 1], k, own);
+        a.staged[k - 1] = t.staged[k];
+        if (own) a.slot_in[t.staged[k]] = k - 1;
+    }
+    size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
+    auto kern = k_tiled_map<T, F, MIXED, WIDE, V, NREP>;
+    clear_sticky_error();
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3(256), lds, s, a, f);
+    return check_launch("k_tiled_map");
+}
+
+// Can every operand be accessed V elements at a time (V * sizeof(T) <= 16 bytes)?
+template <class T>
+static bool vector_ok(const Plan& plan, const OpTab& tab, int V) {
+    const Canon& c = plan.c;
+    const TilePlan& t = plan.tile;
+    int vlog = 0;
+    while ((1 << vlog) < V) ++vlog;
+    const size_t vb = (size_t)V * sizeof(T);
+    for (int k = 0; k < c.M; ++k) {
+        const bool staged = k > 0 && t.staged[k] >= 0;
+        const int j0 = staged ? t.order[k][0] : 0;  // first axis of this operand's enumeration
+        const int d0 = t.tdim[j0];
+        const i64 s0 = c.strides[k][d0];
+        if (t.tlog[j0] < vlog) return false;
+        if (!staged && k > 0 && s0 != 1) continue;  // direct, not unit stride: read per element
+        if (s0 != 1) return false;
+        if (c.dims[d0] % V) return false;
+        if (((uintptr_t)tab.base[k]) % vb) return false;
+        for (int d = 0; d < c.N; ++d)
+            if (d != d0 && (c.strides[k][d] % V)) return false;
+    }
+    return true;
 }
 
 template <class T, class F, bool MIXED>
 static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     const Canon& c = plan.c;
     const TilePlan& t = plan.tile;
-    TiledArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.ops = make_optab(c, bases);
-    a.N = c.N;
-    a.M = c.M;
-    a.nt = t.nt;
-    a.tilelog = t.tilelog;
-    int thrlog = 0;
-    while ((1 << thrlog) < t.threads) ++thrlog;
-    a.thrlog = thrlog;
-    a.nstaged = t.nstaged;
-    // swizzle width: the 128 B an LDS write group spans, in elements
-    {
-        int w = 0;
-        while ((sizeof(T) << w) < 128) ++w;
-        a.swz = (t.tilelog > w) ? w : 0;
-    }
-    a.nblocks = t.grid;
-    a.xcd = (options().xcd_swizzle && (t.grid % 8 == 0) && t.grid >= 16) ? 1 : 0;
-    for (int i = 0; i < MAXN; ++i) {
-        a.dims[i] = (i < c.N) ? c.dims[i] : 1;
-        a.ntiles[i] = (i < c.N) ? t.ntiles[i] : 1;
-        a.tlogdim[i] = 0;
-    }
-    for (int k = 0; k < MAXM; ++k) {
-        a.staged[k] = (k < c.M) ? t.staged[k] : -1;
-        for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
-    }
-    int sh = 0;
-    for (int j = 0; j < t.nt; ++j) {
-        a.tdim[j] = t.tdim[j];
-        a.tlog[j] = t.tlog[j];
-        a.lsh[j] = sh;
-        a.tlogdim[t.tdim[j]] = t.tlog[j];
-        sh += t.tlog[j];
-    }
-    for (int k = 0; k < c.M; ++k) {
-        int pos = 0;
-        for (int jj = 0; jj < t.nt; ++jj) {
-            int j = t.order[k][jj];
-            a.esh[k][j] = pos;
-            pos += t.tlog[j];
+    if (t.tilelog != 10) return set_error(SMR_EINVAL, "tiled: the planner must pick 1024-element tiles");
+    const OpTab tab = make_optab(c, bases);
+    // 32-bit within-tile byte offsets when every tiled stride is >= 0 and the tile spans < 4 GiB
+    bool narrow = true;
+    for (int k = 0; k < c.M && narrow; ++k) {
+        long double span = 0;
+        for (int j = 0; j < t.nt; ++j) {
+            const i64 st = c.strides[k][t.tdim[j]];
+            if (st < 0) narrow = false;
+            span += (long double)st * (((i64)1 << t.tlog[j]) - 1) * c.esize[k];
         }
+        if (span >= 4294967296.0L) narrow = false;
     }
-    size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
-    auto kern = k_tiled_map<T, F, MIXED>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+    if (!narrow) return go3<T, F, MIXED, true, 1, 4>(plan, s, f, tab);
+    if constexpr (!MIXED && sizeof(T) < 16) {
+        // 1024 elements / 256 lanes = 4 per lane: as one 16-byte (or 2 x 8-byte ...) vector
+        constexpr int VMAX = (16 / sizeof(T)) > 4 ? 4 : (int)(16 / sizeof(T));
+        if (options().tiled_vec && vector_ok<T>(plan, tab, VMAX))
+            return go3<T, F, false, false, VMAX, 4 / VMAX>(plan, s, f, tab);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3((unsigned)t.threads), lds, s, a, f);
-    return check_launch("k_tiled_map");
+    return go3<T, F, MIXED, false, 1, 4>(plan, s, f, tab);
 }
 
 template <>
@@ -265,9 +562,19 @@ int launch_tiled_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_
 #endif
     }
     if (c.mixed) return go<T, FProg<T>, true>(plan, bases, s, FProg<T>{c.prog});
-    const unsigned mask = fbit(FK_IDENT) | fbit(FK_ADD2) | fbit(FK_ADD3) | fbit(FK_ADD4) | fbit(FK_SCALE) | fbit(FK_SYM) |
-                          fbit(FK_AXPY) | fbit(FK_AXPBY);
-    return with_functor<T>(c, mask, [&](auto f) { return go<T, decltype(f), false>(plan, bases, s, f); });
+    switch (c.fkind) {  // natively compiled functors of this family; everything else interprets
+        case FK_IDENT: return go<T, FIdent<T>, false>(plan, bases, s, FIdent<T>{});
+        case FK_ADD2: return go<T, FAdd2<T>, false>(plan, bases, s, FAdd2<T>{});
+        case FK_ADD3: return go<T, FAdd3<T>, false>(plan, bases, s, FAdd3<T>{});
+        case FK_ADD4: return go<T, FAdd4<T>, false>(plan, bases, s, FAdd4<T>{});
+        case FK_SCALE: return go<T, FScale<T>, false>(plan, bases, s, FScale<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_SYM: return go<T, FSym<T>, false>(plan, bases, s, FSym<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_AXPY: return go<T, FAxpy<T>, false>(plan, bases, s, FAxpy<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_AXPBY:
+            return go<T, FAxpby<T>, false>(plan, bases, s, FAxpby<T>{hostmk<T>(c.fc[0], c.fc[1]), hostmk<T>(c.fc[2], c.fc[3])});
+        default: break;
+    }
+    return go<T, FProg<T>, false>(plan, bases, s, FProg<T>{c.prog});
 }
 
 }  // namespace smr

@@ -372,14 +372,15 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     // target contiguous run per axis
     const Options& o = options();
     i64 runbytes = (na == 2) ? 256 : (na == 3 ? 128 : 64);
-    int tl_cap = o.tile_log2 > 0 ? (int)o.tile_log2 : 12;
-    // LDS budget
-    while (tl_cap > 6 && (size_t)nst * ((size_t)1 << tl_cap) * es > (size_t)o.max_lds_bytes) --tl_cap;
+    // The tiled kernel is specialised for 1024-element tiles (256 lanes x 4 elements): measured
+    // on MI355X, 1024-element tiles beat 4096-element ones at 32^4 (more workgroups in flight)
+    // and tie at 128^4.
+    int tl_cap = 10;
+    if ((size_t)nst * ((size_t)1 << tl_cap) * es > (size_t)o.max_lds_bytes) return false;
     int lg[MAXN] = {0};
     int total = 0;
     // grow the axes round-robin towards the run target
     int want = std::max(1, nextpow2_log(std::max<i64>(1, runbytes / es)));
-    if (o.tile_log2 > 0) want = std::max(want, (int)(o.tile_log2 + na - 1) / na);
     bool forced = false;
     for (int i = 0; i < c.N; ++i)
         if (o.tile_lg[i] >= 0) forced = true;
@@ -411,7 +412,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
             ++lg[i];
             ++total;
         }
-    if (total < 6) return false;  // less than one wave of work per tile
+    if (total != 10) return false;  // smaller problems go to the generic family
     t.nt = 0;
     t.tilelog = total;
     for (int i = 0; i < c.N; ++i)
@@ -436,8 +437,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
         for (int j = 0; j < t.nt; ++j) t.order[k][j] = idx[j];
     }
     for (int j = 0; j < t.nt; ++j) t.order[0][j] = j;
-    t.threads = (int)std::min<i64>(o.block_threads, (i64)1 << total);
-    if (t.threads < 64) t.threads = 64;
+    t.threads = 256;
     t.grid = 1;
     for (int i = 0; i < c.N; ++i) {
         i64 e = (i64)1 << lg[i];

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd sqlite database: per-kernel dispatch count / avg / min / max
+duration (ns) and, when present, PMC counter values per kernel.  Writes a text table to stdout.
+Usage: python tools/rocpd_summary.py results.db [more.db ...]"""
+import sqlite3
+import sys
+
+
+def summarise(path):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    print(f"== {path}")
+    q = f"""select s.kernel_name, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start),
+                   s.arch_vgpr_count, s.sgpr_count, max(d.group_segment_size), max(d.grid_size_x), max(d.workgroup_size_x)
+            from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name order by sum(d.end-d.start) desc"""
+    print(f"{'calls':>6} {'avg_ns':>10} {'min_ns':>10} {'max_ns':>10} {'vgpr':>5} {'sgpr':>5} {'lds':>7} {'grid':>9} {'wg':>4}  kernel")
+    for r in cur.execute(q):
+        name = r[0]
+        short = name if len(name) < 110 else name[:107] + "..."
+        print(f"{r[1]:6d} {r[2]:10.0f} {r[3]:10d} {r[4]:10d} {r[5]:5d} {r[6]:5d} {r[7]:7d} {r[8]:9d} {r[9]:4d}  {short}")
+    pm = [t for t in tabs if t.startswith("rocpd_pmc_event")]
+    pi = [t for t in tabs if t.startswith("rocpd_info_pmc")]
+    if pm and pi:
+        try:
+            q = f"""select s.kernel_name, p.name, count(*), avg(e.value), sum(e.value)
+                    from {pm[0]} e join {pi[0]} p on e.pmc_id = p.id
+                    join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id
+                    group by s.kernel_name, p.name order by s.kernel_name, p.name"""
+            rows = list(cur.execute(q))
+            if rows:
+                print("-- PMC (per-dispatch average)")
+                for r in rows:
+                    nm = r[0] if len(r[0]) < 70 else r[0][:67] + "..."
+                    print(f"   {r[1]:28s} {r[3]:16.1f}   n={r[2]:<5d} {nm}")
+        except sqlite3.Error as e:
+            print("   (pmc query failed:", e, ")")
+            for t in pm + pi:
+                print("   ", t, [c[1] for c in cur.execute(f"pragma table_info('{t}')")])
+
+
+for p in sys.argv[1:]:
+    summarise(p)
