@@ -406,7 +406,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     }
     // small problems / short axes: widen the tile with the remaining dims (destination order)
     // until a block has at least 1024 elements of work
-    int minlog = forced ? 0 : std::min(tl_cap, 10);
+    int minlog = forced ? 0 : tl_cap;
     for (int i = 0; i < c.N && total < minlog; ++i)
         while (total < minlog && ((i64)1 << lg[i]) < c.dims[i]) {
             ++lg[i];

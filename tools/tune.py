@@ -2,7 +2,6 @@
 """Sweeps the tile-shape / launch options of the TILED family on the headline workloads and
 prints a table (GPU box only).  Usage: python tools/tune.py [--n 32] [--reps 200]"""
 import argparse
-import itertools
 import os
 import sys
 
@@ -25,6 +24,14 @@ def time_plan(plan, reps):
     return min(event_time_ms(torch, g.replay, 3) for _ in range(3)) / reps * 1e3  # us
 
 
+def reset():
+    for i in range(8):
+        S.set_option(f"tile_lg{i}", -1)
+    S.set_option("tile_log2", 0)
+    S.set_option("tiled_vec", 1)
+    S.set_option("force_family", 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
@@ -44,53 +51,53 @@ def main():
         "bcast4": (lambda a, b, c, d: a + b + c + d, (B,) + tuple(A.permutedims(q) for q in perms)),
     }
     tiles = {
-        "perm4321": [None, (5, 0, 0, 5), (4, 1, 1, 4), (3, 2, 2, 3), (5, 1, 0, 4), (4, 0, 1, 5), (4, 2, 0, 4), (2, 3, 3, 2)],
-        "perm2341": [None, (5, 5, 0, 0), (6, 4, 0, 0), (4, 6, 0, 0), (7, 3, 0, 0)],
+        "perm4321": [None, "tl12", (5, 1, 1, 5)],
+        "perm2341": [None, "tl12"],
         "perm3412": [None],
-        "bcast4": [None, (3, 3, 2, 2), (3, 2, 2, 3), (2, 3, 3, 2), (2, 2, 3, 3), (4, 2, 2, 2), (3, 2, 3, 2), (3, 3, 3, 1), (4, 3, 2, 1),
-                   (2, 3, 2, 3), (4, 2, 1, 3)],
+        "bcast4": [None, "tl12", (3, 3, 2, 2), (3, 3, 3, 3), (4, 3, 3, 2), (4, 4, 2, 2), (4, 2, 3, 3), (4, 3, 2, 3), (5, 3, 2, 2), (4, 4, 3, 1)],
     }
-    S.set_option("max_lds_bytes", 160 * 1024)
     elem = tA.element_size()
     algb = 2 * elem * n ** 4
     print(f"# n={n} dtype={args.dtype} algorithmic bytes/launch={algb}")
     # floor: plain contiguous copy of the same bytes (STREAM family) and torch's own copy kernel
+    reset()
     plan = S.make_plan(lambda x: x, None, None, A.size, (B, A))
     us = time_plan(plan, args.reps)
     print(f"copy      STREAM          {us:9.2f} us {algb / us / 1e3:8.1f} GB/s  | {plan.describe()}")
     g = graph_of(torch, lambda: tB.copy_(tA), args.reps)
-    g.replay(); torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
     us = min(event_time_ms(torch, g.replay, 3) for _ in range(3)) / args.reps * 1e3
     print(f"copy      torch.copy_     {us:9.2f} us {algb / us / 1e3:8.1f} GB/s")
     sys.stdout.flush()
     for name, (f, arrays) in work.items():
-        for tile, xcd, thr in itertools.product(tiles[name], (0, 1), (1, 0)):
-            for i in range(8):
-                S.set_option(f"tile_lg{i}", -1)
-            if tile is not None:
-                for i, v in enumerate(tile):
-                    S.set_option(f"tile_lg{i}", v)
-            S.set_option("xcd_swizzle", xcd)
-            S.set_option("tiled_vec", thr)
-            try:
-                plan = S.make_plan(f, None, None, A.size, arrays)
-                us = time_plan(plan, args.reps)
-                d = plan.describe()
-                print(f"{name:9s} tile={str(tile):16s} xcd={xcd} vec={thr} {us:9.2f} us {algb / us / 1e3:8.1f} GB/s  | {d[d.find('tile='):d.find(' algbytes')] if 'tile=' in d else d}")
-            except Exception as e:  # noqa: BLE001
-                print(f"{name:9s} tile={tile} xcd={xcd} vec={thr}: {type(e).__name__}: {e}")
-            sys.stdout.flush()
+        for tile in tiles[name]:
+            for vec in (1, 0):
+                reset()
+                S.set_option("max_lds_bytes", 160 * 1024)
+                if tile == "tl12":
+                    S.set_option("tile_log2", 12)
+                elif tile is not None:
+                    for i, v in enumerate(tile):
+                        S.set_option(f"tile_lg{i}", v)
+                S.set_option("tiled_vec", vec)
+                try:
+                    plan = S.make_plan(f, None, None, A.size, arrays)
+                    us = time_plan(plan, args.reps)
+                    d = plan.describe()
+                    print(f"{name:9s} tile={str(tile):16s} vec={vec} {us:9.2f} us {algb / us / 1e3:8.1f} GB/s  | "
+                          f"{d[d.find('tile='):d.find(' algbytes')] if 'tile=' in d else d}")
+                except Exception as e:  # noqa: BLE001
+                    print(f"{name:9s} tile={tile} vec={vec}: {type(e).__name__}: {e}")
+                sys.stdout.flush()
     # generic-kernel reference point
-    for i in range(8):
-        S.set_option(f"tile_lg{i}", -1)
-    S.set_option("tiled_vec", 1)
-    S.set_option("xcd_swizzle", 0)
+    reset()
     S.set_option("force_family", 1)
     for name, (f, arrays) in work.items():
         plan = S.make_plan(f, None, None, A.size, arrays)
         us = time_plan(plan, max(5, args.reps // 10))
         print(f"{name:9s} GENERIC fallback {us:9.2f} us {algb / us / 1e3:8.1f} GB/s")
-    S.set_option("force_family", 0)
+    reset()
 
 
 if __name__ == "__main__":
