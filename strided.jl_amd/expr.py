@@ -79,6 +79,9 @@ class Const(Expr):
             self.dtype = None                  # weak (Julia Bool/Int do not widen floats)
         elif isinstance(value, numbers.Integral):
             self.dtype = None
+        elif isinstance(value, numbers.Rational):
+            self.dtype = None                  # Fraction ~ Julia Rational: takes the array's float type
+            value = value.numerator / value.denominator
         elif isinstance(value, numbers.Real):
             self.dtype = np.dtype(np.float64)  # a Python float is Julia's Float64
         elif isinstance(value, numbers.Complex):

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/strided_golden.npz: inputs and expected outputs of the reference's
+headline operations, computed with plain NumPy as an independent ground truth.
+
+The reference (Strided.jl) cannot run here (no Julia runtime) and its own test-suite stores no
+vectors -- every assertion is `Base-Julia(x) == Strided(x)` evaluated at run time.  These
+fixtures restate the Base-Julia side of those assertions (test/othertests.jl:1-128,253-333 and
+README.md:56-105) with NumPy, whose elementwise semantics for + - * / conj transpose sum are the
+same IEEE operations.  Column-major ("F") arrays throughout, like Julia.
+
+    python tests/golden/make_golden.py        # rewrites the .npz (deterministic)
+"""
+import os
+
+import numpy as np
+
+rng = np.random.default_rng(20240927)
+G = {}
+
+
+def F(a):
+    return np.asfortranarray(a)
+
+
+# permutedims! on index-valued data (A[i] = linear index: exact, transpose-detecting)
+A = F(np.arange(7 * 5 * 6 * 4, dtype=np.float64).reshape((7, 5, 6, 4), order="F"))
+G["perm_in"] = A
+for name, p in (("4321", (3, 2, 1, 0)), ("2341", (1, 2, 3, 0)), ("3412", (2, 3, 0, 1))):
+    G[f"perm_{name}"] = F(A.transpose(p))
+# README.md:72,83  symmetrise and scaled transpose
+S_ = F(rng.standard_normal((33, 33)))
+G["sym_in"] = S_
+G["sym_out"] = F((S_ + S_.T) / 2)
+G["scaledT_out"] = F(3 * S_.T)
+# README.md:104  4-way permuted sum, left-to-right association
+C4 = F(rng.standard_normal((6, 6, 6, 6)))
+G["sum4_in"] = C4
+G["sum4_out"] = F(((C4 + C4.transpose(1, 2, 3, 0)) + C4.transpose(2, 3, 0, 1)) + C4.transpose(3, 0, 1, 2))
+# conj! / adjoint!  (test/othertests.jl:10-11)
+Z = F(rng.standard_normal((5, 7)) + 1j * rng.standard_normal((5, 7)))
+G["cplx_in"] = Z
+G["conj_out"] = F(np.conj(Z))
+G["adjoint_out"] = F(np.conj(Z.T))
+# partial reductions with initop (test/othertests.jl:71-102)
+R = F(rng.random((4, 5, 6)) + 1j * rng.random((4, 5, 6)))
+O = F(rng.random((4, 1, 6)) + 1j * rng.random((4, 1, 6)))
+beta = 0.3 - 0.7j
+red = np.sin(R).sum(axis=1, keepdims=True)
+G["red_in"], G["red_dest"], G["red_beta"] = R, O, np.array([beta])
+G["red_none"] = F(red + O)            # initop = nothing / identity
+G["red_zero"] = F(red)                # x -> 0
+G["red_scale"] = F(red + beta * O)    # x -> beta*x
+G["red_const"] = F(red + beta)        # x -> beta
+G["red_conj"] = F(red + np.conj(O))   # conj
+# complete reductions (test/othertests.jl:113-116,125)
+X = F(rng.standard_normal((10, 9, 8)))
+G["full_in"] = X
+G["full_sum"] = np.array([X.sum()])
+G["full_maxabs"] = np.array([np.abs(X).max()])
+G["full_min"] = np.array([X.min()])
+G["full_count_neg"] = np.array([(X < 0).sum()], dtype=np.int64)
+G["full_abs2"] = np.array([(X * X).sum()])
+P = F(rng.random((5, 5, 5)))
+G["prod_in"] = P
+G["prod_exp"] = np.array([np.exp(P.sum())])
+# README.md:89 compute-bound map in Float32: float64 truth rounded once
+E32 = F(rng.random((64, 48)).astype(np.float32))
+e64 = E32.astype(np.float64)
+G["expr_in"] = E32
+G["expr_out"] = F((e64 * np.exp(-2 * e64) + np.sin(e64 * e64)).astype(np.float32))
+G["expr_scale"] = F((np.abs(e64 * np.exp(-2 * e64)) + np.abs(np.sin(e64 * e64))).astype(np.float32))
+# generic matmul on integer-valued complex data (test/othertests.jl:253-296): exact
+M1 = F(rng.integers(-100, 101, (9, 9)) + 1j * rng.integers(-100, 101, (9, 9)))
+M2 = F(rng.integers(-100, 101, (9, 9)) + 1j * rng.integers(-100, 101, (9, 9)))
+M3 = F(rng.integers(-100, 101, (9, 9)) + 1j * rng.integers(-100, 101, (9, 9)))
+al, be = 2 + 1j, 3 - 1j
+G["mm_a"], G["mm_b"], G["mm_c"] = M1, M2, M3
+G["mm_alpha_beta"] = np.array([al, be])
+G["mm_out"] = F(be * M3 + al * (M1.conj().T @ M2.T))          # C = beta*C + alpha*A'*transpose(B)
+G["mm_out_conjdest"] = F(np.conj(be) * M3 + np.conj(al * (M1 @ M2)))  # mul!(conj(C), A, B, alpha, beta)
+
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "strided_golden.npz")
+np.savez_compressed(out, **G)
+print("wrote", out, os.path.getsize(out), "bytes,", len(G), "arrays")

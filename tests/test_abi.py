@@ -1,0 +1,137 @@
+"""The C-ABI boundary (include/strided_hip.h <-> strided.jl_amd/libstrided_hip.so), CPU-only:
+the library loads, exports every declared symbol, validates problems with the documented status
+codes, plans without a device, shards with the reference's offset arithmetic, and REFUSES to
+compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import strided_jl_amd as S
+from strided_jl_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "strided_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = _declared_functions()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/strided_hip.h but not exported"
+    assert sorted(L.EXPORTS) == names
+    assert lib.smr_abi_version() == 1
+
+
+def test_struct_layout_matches_the_header():
+    # sizes computed from the header's field list (LP64)
+    assert C.sizeof(L.smr_operand) == 8 + 8 + 8 * 8 + 4 + 4
+    assert C.sizeof(L.smr_problem) == 4 + 4 + 8 * 8 + 8 * C.sizeof(L.smr_operand) + 8 + 4 + 4 + 8 + 4 + 4 + 16 + 8
+
+
+def _views(dims, strides, dtype=np.float64):
+    out = []
+    for st in strides:
+        span = 1 + sum((d - 1) * abs(s) for d, s in zip(dims, st))
+        out.append(S.StridedView(np.zeros(span, dtype=dtype), dims, st, 0))
+    return tuple(out)
+
+
+def test_planning_needs_no_device_and_picks_the_expected_family():
+    x = S.StridedView(np.zeros((32, 32, 32, 32), order="F"))
+    y = x.similar()
+    d = S.make_plan(lambda v: v, None, None, x.size, (y, x.permutedims((3, 2, 1, 0)))).describe()
+    assert "family=tiled" in d and "f=ident" in d and "tile=d0:32,d3:32" in d and "algbytes=16777216" in d
+    ps = [x.permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]
+    d = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps)).describe()
+    assert "family=tiled" in d and "f=add4" in d and "staged=3" in d and "algbytes=16777216" in d
+    d = S.make_plan(lambda a: a * S.fn.exp(-2 * a) + S.fn.sin(a * a), None, None, x.size, (y, x)).describe()
+    assert "family=stream" in d and "f=expr5" in d and "N=1" in d  # 4 dims fuse into one
+    o = x.similar(size=(1,))
+    d = S.make_plan(S.fn.abs2, "+", None, x.size, S.promoteshape(x.size, o.sreshape((1, 1, 1, 1)), x)).describe()
+    assert "family=reduce_all" in d and "f=abs2" in d
+    # the four appearances of A in the README's compute-bound expression are deduplicated
+    d = S.make_plan(lambda a, b, c, e: a * S.fn.exp(-2 * b) + S.fn.sin(c * e), None, None, x.size, (y, x, x, x, x)).describe()
+    assert "M=2" in d and "f=expr5" in d
+
+
+def test_invalid_problems_return_einval():
+    x, y = _views((8, 8), [(1, 8), (1, 8)])
+    p, keep = S.build_problem(lambda v: v, None, None, (8, 8), (x, y), stream=0)
+    h = C.c_void_p()
+    lib = L.load()
+    p.N = 0
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EINVAL
+    p.N = 2
+    p.dims[1] = 0
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EINVAL
+    assert b">= 1" in lib.smr_last_error()
+    p.dims[1] = 8
+    p.ops[1].dtype = 99
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EINVAL
+    p.ops[1].dtype = L.SMR_F64
+    p.initop = L.SMR_INIT_ZERO  # initop without a reduction
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EINVAL
+    p.initop = 0
+    bad = (C.c_uint8 * 2)(L.OPCODES["ADD"], 0)  # stack underflow
+    p.fprog = C.cast(bad, C.POINTER(C.c_uint8))
+    p.fprog_len = 1
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EINVAL
+    assert lib.smr_set_option(b"no_such_option", 1) == L.SMR_EINVAL
+
+
+def test_map_into_zero_stride_destination_is_unsupported():
+    x, y = _views((8, 8), [(1, 0), (1, 8)])
+    with pytest.raises(L.UnsupportedOnDevice):
+        S.make_plan(lambda v: v, None, None, (8, 8), (x, y))
+
+
+def test_compute_without_a_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    x, y = _views((8, 8), [(1, 8), (8, 1)])
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        S.copy_(x, y)  # host views never reach the engine
+    plan = S.make_plan(lambda v: v, None, None, (8, 8), (x, y))
+    with pytest.raises(L.StridedHIPError) as e:
+        plan.execute()
+    assert e.value.code == L.SMR_ENODEVICE
+
+
+def test_shard_follows_the_reference_offset_arithmetic():
+    from strided_jl_amd import distributed as D
+    dims = (4096, 4096, 64)
+    A, = _views(dims, [(1, 4096, 4096 * 4096)], np.float32)
+    out = S.StridedView(np.zeros(1, np.float32), dims, (0, 0, 0), 0)
+    total = 0
+    for r in range(8):
+        sdims, (so, sa), need, sinit = D.shard(S.fn.abs2, "+", "zero", dims, (out, A), 8, r)
+        assert need  # complete reduction: a reduced dim is split -> all-reduce of the partial
+        assert sdims == (4096, 4096, 8)
+        assert sa.offset == r * 8 * 4096 * 4096 and so.offset == 0
+        assert (sinit == "zero") == (r == 0)  # initop exactly once
+        total += sdims[2]
+    assert total == 64
+    # map: split the slowest destination dim, offsets += start * stride for every operand
+    x, y = _views((100, 30, 7), [(1, 100, 3000), (210, 7, 1)])
+    covered = 0
+    for r in range(3):
+        sdims, (sx, sy), need, _ = D.shard(lambda v: v, None, None, (100, 30, 7), (x, y), 3, r)
+        assert not need and sdims[:2] == (100, 30)
+        start = 7 * r // 3
+        assert sx.offset == start * 3000 and sy.offset == start * 1
+        covered += sdims[2]
+    assert covered == 7
+    # partial reduction with a long kept dim: split that one, no collective
+    o, a = _views((64, 50), [(1, 0), (1, 64)])
+    sdims, _, need, _ = D.shard(lambda v: v, "+", None, (64, 50), (o, a), 4, 1)
+    assert not need and sdims == (16, 50)

@@ -1,0 +1,142 @@
+"""The N>1 path on CPU: two ranks over gloo.  The sharding arithmetic (smr_shard) and the
+collective step (one all-reduce of the partial destinations, initop applied once) are the
+product's; the per-shard compute is delegated to the CPU oracle (test infrastructure) because
+there is no GPU here."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException as e:  # noqa: BLE001 -- report instead of leaving the parent waiting
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise e
+
+
+def _worker_body(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import oraclelib
+    import strided_jl_amd as S
+    from strided_jl_amd import distributed as D
+    from strided_jl_amd import fn
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def funnel(f, op, initop, dims, arrays):  # the oracle stands in for the missing GPU
+        p, keep = S.build_problem(f, op, initop, dims, arrays, stream=0)
+        oraclelib.mapreduce(p, 1)
+        return arrays[0]
+
+    sys.modules["strided_jl_amd.mapreduce"]._mapreduce_fuse_ = funnel
+    rng = np.random.default_rng(1234)  # same data on every rank (replicated inputs)
+    res = {}
+
+    def F(a):
+        return S.StridedView(np.asfortranarray(a).copy(order="F"))
+
+    # 1. map: permutedims -- each rank fills its own slab only
+    A = rng.standard_normal((6, 5, 8, 7))
+    B = F(np.full((7, 8, 5, 6), np.nan))
+    D.mapreduce_sharded_(lambda x: x, None, None, B.size, (B, F(A).permutedims((3, 2, 1, 0))))
+    dim, slabs = D.shard_slices(B.size, B.strides, world)
+    mine = B.toarray()
+    lo, hi = slabs[rank]
+    sl = [slice(None)] * 4
+    sl[dim] = slice(lo, hi)
+    ref = A.transpose(3, 2, 1, 0)
+    assert np.array_equal(mine[tuple(sl)], ref[tuple(sl)])
+    other = np.ones(mine.shape, bool)
+    other[tuple(sl)] = False
+    assert np.isnan(mine[other]).all()  # nothing outside the slab was written
+    res["map"] = True
+
+    # 2. complete reduction: split a reduced dim, all-reduce, initop (x -> 2x) exactly once
+    X = rng.standard_normal((40, 30, 8)).astype(np.float64)
+    out = F(np.array([10.0]))
+    O = S.StridedView(out.parent, X.shape, (0, 0, 0), 0)
+    D.mapreduce_sharded_(fn.abs2, "+", (lambda x: 2 * x), X.shape, (O, F(X)))
+    res["sum"] = float(out.toarray()[0])
+    res["sum_ref"] = float(2 * 10.0 + (X * X).sum())
+
+    # 3. max reduction through the same path
+    out = F(np.array([-np.inf]))
+    O = S.StridedView(out.parent, X.shape, (0, 0, 0), 0)
+    D.mapreduce_sharded_(fn.abs, "max", None, X.shape, (O, F(X)))
+    res["max"] = float(out.toarray()[0])
+    res["max_ref"] = float(np.abs(X).max())
+
+    # 4. partial reduction whose kept dim is long enough: no collective, each rank owns rows
+    Y = rng.standard_normal((64, 50))
+    dest = F(np.zeros((64, 1)))
+    Dv = S.StridedView(dest.parent, (64, 50), (1, 0), 0)
+    D.mapreduce_sharded_(lambda x: x, "+", None, (64, 50), (Dv, F(Y)))
+    rows = slice(64 * rank // world, 64 * (rank + 1) // world)
+    got = dest.toarray()[:, 0]
+    assert np.allclose(got[rows], Y.sum(axis=1)[rows], rtol=1e-12)
+    res["partial"] = True
+
+    # 5. partial reduction, kept dims (3, 2): with 2 ranks the slowest kept dim (extent 2) is split,
+    #    initop (x -> 3x) is applied to each rank's own column exactly once, no collective
+    Z = rng.standard_normal((3, 2, 400))
+    dest = F(np.ones((3, 2, 1)))
+    Dv = S.StridedView(dest.parent, (3, 2, 400), (1, 3, 0), 0)
+    D.mapreduce_sharded_(fn.sin, "+", (lambda x: 3 * x), (3, 2, 400), (Dv, F(Z)))
+    got = dest.toarray()[:, :, 0]
+    assert np.allclose(got[:, rank], 3.0 + np.sin(Z).sum(axis=2)[:, rank], rtol=1e-12)
+    assert np.array_equal(got[:, 1 - rank], np.ones(3))
+    # 6. a single kept element per rank is impossible (kept extent 1): the reduced dim is split,
+    #    partials are all-reduced, conj initop once -- complex data
+    W = rng.standard_normal((1, 600)) + 1j * rng.standard_normal((1, 600))
+    dest = F(np.array([[1 + 2j]]))
+    Dv = S.StridedView(dest.parent, (1, 600), (1, 0), 0)
+    D.mapreduce_sharded_(lambda x: x, "+", "conj", (1, 600), (Dv, F(W)))
+    res["part_all"] = [dest.toarray()[0, 0].real, dest.toarray()[0, 0].imag]
+    ref = (1 - 2j) + W.sum()
+    res["part_all_ref"] = [ref.real, ref.imag]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, res))
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_sharding_and_allreduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in procs:
+        rank, res = q.get(timeout=240)
+        results[rank] = res
+    for p in procs:
+        p.join(timeout=60)
+    for rank in (0, 1):
+        r = results[rank]
+        assert "error" not in r, r.get("error")
+        assert r["map"] and r["partial"]
+        assert abs(r["sum"] - r["sum_ref"]) <= 1e-10 * abs(r["sum_ref"])
+        assert r["max"] == r["max_ref"]
+        assert np.allclose(r["part_all"], r["part_all_ref"], rtol=1e-12)

@@ -1,0 +1,138 @@
+"""Host-side mirror of the reference's interface: StridedView algebra (StridedViews.jl
+semantics), broadcast lowering (src/broadcast.jl), f-program serialisation, result-eltype
+inference, argument errors raised before the funnel (src/mapreduce.jl:38-53,74-96)."""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import strided_jl_amd as S
+from strided_jl_amd import expr as E
+from strided_jl_amd import fn
+from strided_jl_amd._lib import OPCODES as OP
+
+
+def F(a):
+    return S.StridedView(np.asfortranarray(a))
+
+
+def test_lazy_view_algebra_matches_numpy():
+    rng = np.random.default_rng(0)
+    a0 = np.asfortranarray(rng.standard_normal((4, 5, 6)) + 1j * rng.standard_normal((4, 5, 6)))
+    a = F(a0)
+    assert a.strides == (1, 4, 20) and a.offset == 0
+    assert np.array_equal(a.permutedims((2, 0, 1)).toarray(), a0.transpose(2, 0, 1))
+    assert np.array_equal(a.conj().toarray(), a0.conj())
+    m = F(a0[:, :, 0])
+    assert m.adjoint().op == "conj" and m.adjoint().strides == (4, 1)
+    assert np.array_equal(m.adjoint().toarray(), a0[:, :, 0].conj().T)
+    assert m.adjoint().adjoint().op == "identity"
+    v = a[1:4:2, ::-1, 5]
+    assert v.size == (2, 5) and v.strides == (2, -4) and np.array_equal(v.toarray(), a0[1:4:2, ::-1, 5])
+    assert np.array_equal(a[3:4, 2:3, :].toarray(), a0[3:4, 2:3, :])
+    assert a[1, 2, 3] == a0[1, 2, 3]
+    # real views ignore conj (Base.conj!(a::StridedView{<:Real}) = a)
+    r = F(np.zeros((3, 3)))
+    assert r.conj().op == "identity" and r.adjoint().op == "identity"
+
+
+def test_sreshape_only_merges_contiguous_dims():
+    a0 = np.asfortranarray(np.arange(10 * 10 * 10.).reshape(10, 10, 10))
+    a = F(a0)
+    assert np.array_equal(a.sreshape((100, 10)).toarray(), a0.reshape((100, 10), order="F"))
+    assert np.array_equal(a.sreshape((10, 2, 5, 10)).toarray(), a0.reshape((10, 2, 5, 10), order="F"))
+    assert np.array_equal(a.sreshape((10, 1, 10, 1, 10)).toarray(), a0.reshape((10, 1, 10, 1, 10), order="F"))
+    assert np.array_equal(a[0:5, :, :].sreshape((5, 10, 5, 2)).toarray(), a0[0:5].reshape((5, 10, 5, 2), order="F"))
+    with pytest.raises(ValueError):
+        a[0:5, :, :].sreshape((50, 10))  # dims 1,2 of the view are not jointly contiguous
+    with pytest.raises(S.DimensionMismatch):
+        a.sreshape((7, 7))
+    assert a.permutedims((1, 0, 2)).sreshape((10, 10, 5, 2)).strides == (10, 1, 100, 500)
+
+
+def test_promoteshape_gives_broadcast_dims_stride_zero():
+    b1, b2 = F(np.zeros(10)), F(np.zeros((10, 10)))
+    p1, p2 = S.promoteshape((10, 10, 10), b1, b2)
+    assert p1.strides == (1, 0, 0) and p2.strides == (1, 10, 0) and p1.size == (10, 10, 10)
+    with pytest.raises(S.DimensionMismatch):
+        S.promoteshape((10, 9), b2)
+    one = F(np.zeros((1, 10)))
+    assert S.promoteshape1((7, 10), one).strides == (0, 1)
+
+
+def test_capture_order_is_depth_first_left_to_right():
+    a, b, c = F(np.zeros((4, 4))), F(np.zeros((4, 4))), F(np.zeros(4))
+    bc = a.adjoint() * b - fn.max(fn.abs(c), fn.real(b))
+    leaves = S.capturestridedargs(bc)
+    assert [l.strides for l in leaves] == [(4, 1), (1, 4), (1,), (1, 4)]
+    cap = S.make_capture(bc)
+    assert repr(cap) == "sub(mul(a1, a2), max(abs(a3), real(a4)))"
+    code, consts = E.serialize(cap)
+    assert list(code) == [OP["ARG"], 1, OP["ARG"], 2, OP["MUL"], 0, OP["ARG"], 3, OP["ABS"], 0, OP["ARG"], 4,
+                          OP["REAL"], 0, OP["MAX"], 0, OP["SUB"], 0]
+    assert consts == []
+    assert S.broadcast_shape(bc) == (4, 4)
+
+
+def test_nary_plus_folds_left_and_scalars_are_captured():
+    x = [E.Arg(i) for i in (1, 2, 3, 4)]
+    code, consts = E.serialize(E.Call("add", tuple(x)))
+    assert list(code) == [0, 1, 0, 2, OP["ADD"], 0, 0, 3, OP["ADD"], 0, 0, 4, OP["ADD"], 0]
+    code, consts = E.serialize(E.trace(lambda a, b: (a + b) / 2, 2))
+    assert list(code) == [0, 1, 0, 2, OP["ADD"], 0, OP["CONST"], 0, OP["DIV"], 0] and consts == [2 + 0j]
+    code, consts = E.serialize(E.trace(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), 1))
+    assert consts == [-2 + 0j] and len(code) // 2 == 11
+    # Ref / Rational / complex constants
+    c = S.make_capture(F(np.zeros(3)) * S.Ref(0.5) + Fraction(1, 3) + 2j)
+    _, consts = E.serialize(c)
+    assert consts[0] == 0.5 and abs(consts[1] - 1 / 3) < 1e-16 and consts[2] == 2j
+    with pytest.raises(NotImplementedError):
+        E.Call("erf", (E.Arg(1),))
+
+
+def test_result_eltype_follows_julia_promotion():
+    f32, c64 = np.dtype(np.float32), np.dtype(np.complex64)
+    t = lambda f, *dts: E.result_dtype(E.trace(f, len(dts)), dts)  # noqa: E731
+    assert t(lambda a: a * 2, f32) == f32                  # Int literal does not widen
+    assert t(lambda a: a * 2.0, f32) == np.float64         # Float64 literal does
+    assert t(lambda a: a * Fraction(1, 3), f32) == f32     # Rational takes the array's type
+    assert t(lambda a: a * np.float32(2), f32) == f32
+    assert t(lambda a, b: a + b, f32, c64) == c64
+    assert t(fn.abs, c64) == f32 and t(fn.real, np.complex128) == np.float64 and t(fn.abs2, c64) == f32
+    assert t(lambda a: fn.real(a) < 0, c64) == np.bool_
+    assert t(lambda a: a + 1j, f32) == np.complex128
+    assert t(fn.sin, np.int32) == np.float64
+
+
+def test_errors_are_raised_before_the_funnel():
+    a, b = F(np.zeros((3, 4))), F(np.zeros((4, 3)))
+    with pytest.raises(S.DimensionMismatch):
+        S.map_(lambda x: x, a, b)
+    with pytest.raises(S.DimensionMismatch):
+        S.mapreducedim_(lambda x: x, "+", F(np.zeros((2, 1))), a)
+    with pytest.raises(S.DimensionMismatch):
+        S.mul_(F(np.zeros((3, 3))), a, a)
+    with pytest.raises(ValueError, match="unknown reduction"):
+        S.mapreduce(lambda x: x, (lambda p, q: p - q), a)
+    with pytest.raises(TypeError):
+        a + np.zeros((3, 4))   # StridedArrayStyle x DefaultArrayStyle has no device path
+    # zero-size map! returns the destination untouched without touching the engine
+    z = F(np.zeros((0, 4)))
+    assert S.map_(lambda x: x, z, z) is z
+    assert S.sum(z) == 0 and S.prod(z) == 1
+    with pytest.raises(ValueError):
+        S.maximum(z)
+
+
+def test_initop_tracing_covers_the_five_reference_forms():
+    from strided_jl_amd.mapreduce import _initop_code
+    from strided_jl_amd import _lib as L
+    assert _initop_code(None) == (L.SMR_INIT_NONE, 0j)
+    assert _initop_code("identity")[0] == L.SMR_INIT_IDENTITY and _initop_code(lambda x: x)[0] == L.SMR_INIT_IDENTITY
+    assert _initop_code("zero")[0] == L.SMR_INIT_ZERO and _initop_code(lambda x: 0)[0] == L.SMR_INIT_ZERO
+    assert _initop_code(lambda x: x * (2 - 1j)) == (L.SMR_INIT_SCALE, 2 - 1j)
+    assert _initop_code(lambda x: 0.25 * x) == (L.SMR_INIT_SCALE, 0.25 + 0j)
+    assert _initop_code(lambda x: 3.5) == (L.SMR_INIT_CONST, 3.5 + 0j)
+    assert _initop_code("conj")[0] == L.SMR_INIT_CONJ and _initop_code(fn.conj)[0] == L.SMR_INIT_CONJ
+    with pytest.raises(NotImplementedError):
+        _initop_code(lambda x: x * x)
