@@ -122,6 +122,7 @@ struct Plan {
     size_t scratch_bytes = 0;
     int red_blocks = 0;
     int part_tr = 1;    // REDUCE_PART: lanes cooperating on one output
+    int part_split = 1; // REDUCE_PART: chunks of the reduced range (two-pass when > 1)
     std::string desc;
 };
 

@@ -27,6 +27,9 @@ struct RedArgs {
     double beta[2];
     void* partials;
     int32_t nparts;
+    int32_t nsplit;   // REDUCE_PART: the reduced range is cut into nsplit chunks (one workgroup each)
+    int32_t ngroups;  // REDUCE_PART: workgroups along the output index
+    i64 chunk;        // reduced elements per chunk (multiple of tr)
 };
 
 template <class T>
@@ -206,15 +209,19 @@ __global__ void __launch_bounds__(256) k_reduce_part(RedArgs a, F f) {
     const int ob = 256 >> a.trlog;
     const int rl = threadIdx.x & (tr_ - 1);
     const int ol = threadIdx.x >> a.trlog;
-    const i64 o = (i64)blockIdx.x * ob + ol;
+    const i64 sp = (i64)blockIdx.x / a.ngroups;  // which chunk of the reduced range
+    const i64 og = (i64)blockIdx.x - sp * a.ngroups;
+    const i64 o = og * ob + ol;
     const bool live = o < a.nout;
+    const i64 rbeg = sp * a.chunk;
+    const i64 rend = (rbeg + a.chunk < a.nred) ? rbeg + a.chunk : a.nred;
     i64 ooff[MAXM];
 #pragma unroll
     for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
     if (live) decompose(a, o, 0, a.NK, ooff);
     T acc = neutral<T>(a.redop);
     if (live) {
-        for (i64 r = rl; r < a.nred; r += tr_) {
+        for (i64 r = rbeg + rl; r < rend; r += tr_) {
             i64 off[MAXM];
 #pragma unroll
             for (int k = 0; k < MAXM; ++k) off[k] = ooff[k];
@@ -239,7 +246,34 @@ __global__ void __launch_bounds__(256) k_reduce_part(RedArgs a, F f) {
             }
         }
     }
-    if (live && rl == 0) epilogue<T, MIXED>(a, ooff[0], acc);
+    if (live && rl == 0) {
+        if (a.nsplit == 1)
+            epilogue<T, MIXED>(a, ooff[0], acc);
+        else
+            ((T*)a.partials)[o * a.nsplit + sp] = acc;
+    }
+}
+
+// second pass of a split partial reduction: one thread folds the nsplit partials of its output
+template <class T, bool MIXED>
+__global__ void __launch_bounds__(256) k_reduce_part_final(RedArgs a) {
+    const i64 o = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (o >= a.nout) return;
+    i64 ooff[MAXM];
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
+    decompose(a, o, 0, a.NK, ooff);
+    const T* p = (const T*)a.partials + o * a.nsplit;
+    T acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = neutral<T>(a.redop);
+    for (int i = 0; i < a.nsplit; i += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + j < a.nsplit) acc[j] = red_apply<T>(a.redop, acc[j], p[i + j]);
+    }
+    epilogue<T, MIXED>(a, ooff[0],
+                       red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3])));
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
@@ -304,11 +338,19 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.trlog = 0;
     while ((1 << a.trlog) < a.tr) ++a.trlog;
     const int ob = 256 / a.tr;
-    const i64 blocks = (c.nout + ob - 1) / ob;
-    if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
+    const i64 groups = (c.nout + ob - 1) / ob;
+    int nsplit = (plan.part_split > 1 && plan.scratch) ? plan.part_split : 1;
+    a.nsplit = nsplit;
+    a.ngroups = (int32_t)groups;
+    a.chunk = ((a.nred + nsplit - 1) / nsplit + a.tr - 1) / a.tr * a.tr;
+    const i64 blocks = groups * nsplit;
+    if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
     clear_sticky_error();
     hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
-    return check_launch("k_reduce_part");
+    int rc = check_launch("k_reduce_part");
+    if (rc || nsplit == 1) return rc;
+    hipLaunchKernelGGL((k_reduce_part_final<T, MIXED>), dim3((unsigned)((c.nout + 255) / 256)), dim3(256), 0, s, a);
+    return check_launch("k_reduce_part_final");
 }
 
 template <>

@@ -513,6 +513,20 @@ int make_plan(const smr_problem* p, Plan& plan) {
             }
             if (red_fast && tr < 16 && red >= 16) tr = 16;
             plan.part_tr = tr;
+            // few destination elements, long reductions: cut the reduced range so that ~2048
+            // workgroups are in flight, partials folded by a second launch (also keeps the
+            // serial per-lane accumulation short, which is what bounds the rounding error)
+            const i64 groups = (c.nout + (256 / tr) - 1) / (256 / tr);
+            i64 split = 1;
+            if (groups < 1024 && red >= (i64)tr * 256) {
+                split = std::min<i64>(2048 / std::max<i64>(1, groups), red / ((i64)tr * 64));
+                split = std::max<i64>(1, std::min<i64>(split, 4096));
+            }
+            plan.part_split = (int)split;
+            if (split > 1) {
+                plan.scratch_bytes = (size_t)c.nout * (size_t)split * es;
+                plan.red_blocks = (int)split;  // > 1: the API allocates the partials buffer
+            }
         }
     }
     describe(plan);
@@ -539,7 +553,8 @@ void describe(Plan& plan) {
     } else if (plan.family == FAM_REDUCE_ALL) {
         n += std::snprintf(buf + n, sizeof buf - n, " blocks=%d", plan.red_blocks);
     } else if (plan.family == FAM_REDUCE_PART) {
-        n += std::snprintf(buf + n, sizeof buf - n, " nout=%lld lanes_per_out=%d", (long long)c.nout, plan.part_tr);
+        n += std::snprintf(buf + n, sizeof buf - n, " nout=%lld lanes_per_out=%d split=%d", (long long)c.nout, plan.part_tr,
+                           plan.part_split);
     }
     std::snprintf(buf + n, sizeof buf - n, " algbytes=%lld", (long long)c.algbytes);
     plan.desc = buf;
