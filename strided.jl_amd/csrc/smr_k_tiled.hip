@@ -63,7 +63,8 @@ template <bool WIDE>
 struct TiledArgs {
     // header + tile decode: everything the first instructions need, contiguous, so that it
     // arrives with one batch of scalar loads
-    int32_t M, ng, tilelog, nstaged, base32, nt, ablate, pad1;  // ablate: profiling only (bit0 no loads, bit1 no LDS, bit2 no stores)
+    int32_t M, ng, tilelog, nstaged, base32, nt, ablate, xmlog;  // ablate: profiling only (bit0 no loads, bit1 no LDS, bit2 no stores)
+    uint32_t xm, nt0, total_q, pad2;  // XCD classes (xm = 0: off), see the decode below
     uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
     OpDesc<WIDE> dst;            // destination (destination order)
     OpDesc<WIDE> in[MAXIN];      // inputs 1..M-1: staged ones in their own order, direct ones in dst order
@@ -126,14 +127,25 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
 
     // ---- which tile -----------------------------------------------------------------------------
     uint32_t b = blockIdx.x;
+    uint32_t xclass = 0;
+    if (a.xm) {
+        // XCD classes.  Workgroup b runs on XCD b % 8 (own, non-coherent L2).  When several inputs
+        // are dim-permuted views of ONE array (A .+ A', the 4-way permuted sum), tiles whose
+        // coordinates are permutations of each other read the same lines of that array.  Any
+        // symmetric function of the tile coordinates is invariant under those permutations, so
+        // tiles are dealt to XCDs by (sum of tile coordinates) mod xm: every line of the shared
+        // array is then fetched into one L2 instead of up to 8.
+        const uint32_t x = b & 7u;
+        xclass = x & (a.xm - 1u);
+        b = ((b >> 3) << (3 - a.xmlog)) + (x >> a.xmlog);
+        if (b >= a.total_q) return;  // padding workgroup (before any barrier)
+    }
     uint32_t tc[MAXN];
-    uint32_t emin = 0xffffffffu;  // becomes 0 iff some grid coordinate sits on a ragged last tile
 #pragma unroll
     for (int g = 0; g < NG; ++g) {  // unused grid dims are padded with ntiles = 1
         const uint32_t q = fastdiv(b, a.div_m[g], a.div_s[g]);
         tc[g] = b - q * a.ntiles[g];
         b = q;
-        emin = min(emin, tc[g] ^ a.last_ragged[g]);
     }
 #pragma unroll
     for (int g = NG; g < MAXN; ++g) tc[g] = 0;
@@ -143,9 +155,17 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
             const uint32_t q = fastdiv(b, a.div_m[g], a.div_s[g]);
             tc[g] = b - q * a.ntiles[g];
             b = q;
-            emin = min(emin, tc[g] ^ a.last_ragged[g]);
         }
     }
+    if (a.xm) {  // tc[0] held the class-local index j: t0 = ((class - sum of the others) mod xm) + xm * j
+        const uint32_t t0 = ((xclass - tc[1] - tc[2] - tc[3]) & (a.xm - 1u)) + (tc[0] << a.xmlog);
+        if (t0 >= a.nt0) return;
+        tc[0] = t0;
+    }
+    uint32_t emin = 0xffffffffu;  // becomes 0 iff some grid coordinate sits on a ragged last tile
+#pragma unroll
+    for (int g = 0; g < MAXN; ++g)
+        if (g < NG || a.ng > NG) emin = min(emin, tc[g] ^ a.last_ragged[g]);
     // EDGE = false is instantiated for problems without any ragged dim: no bounds code at all
     // (smaller kernel: the per-launch instruction fetch is part of a ~4 us launch)
     const bool edge = EDGE && emin == 0;
@@ -465,6 +485,40 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         a.staged[k - 1] = t.staged[k];
 
     }
+    // XCD classes: when two or more inputs are views of the same buffer (see the kernel's decode)
+    i64 grid = t.grid;
+    {
+        bool aliased = false;
+        for (int k = 1; k < c.M; ++k)
+            for (int l = k + 1; l < c.M; ++l)
+                if (c.base[k] == c.base[l]) aliased = true;
+        if (aliased && options().xcd_classes && ng >= 2 && ng <= NG) {
+            const uint32_t nt0 = a.ntiles[0];
+            uint32_t xm = 1, xl = 0;
+            while (xm < 8 && xm < nt0) { xm <<= 1; ++xl; }
+            if (xm >= 2) {
+                const uint32_t njb = (nt0 + xm - 1) / xm;
+                i64 tq = njb;
+                for (int g = 1; g < ng; ++g) tq *= a.ntiles[g];
+                const i64 perx = (tq + (8 / xm) - 1) / (8 / xm);
+                if (perx * 8 < 0x7fffffffLL) {
+                    a.xm = xm;
+                    a.xmlog = (int32_t)xl;
+                    a.nt0 = nt0;
+                    a.total_q = (uint32_t)tq;
+                    a.ntiles[0] = njb;  // the decode extracts j in [0, njb) first
+                    if (njb <= 1) { a.div_m[0] = 0; a.div_s[0] = 0; }
+                    else {
+                        int l2 = 0;
+                        while ((1ull << l2) < njb) ++l2;
+                        a.div_m[0] = (uint32_t)((((1ull << 32) * ((1ull << l2) - njb)) / njb) + 1);
+                        a.div_s[0] = (uint32_t)l2;
+                    }
+                    grid = perx * 8;
+                }
+            }
+        }
+    }
     size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
     auto kern = k_tiled_map<T, F, MIXED, WIDE, V, NREP, EDGE, THRLOG>;
     clear_sticky_error();
@@ -472,7 +526,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3(1u << THRLOG), lds, s, a, f);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1u << THRLOG), lds, s, a, f);
     return check_launch("k_tiled_map");
 }
 
@@ -544,6 +598,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     // 32^4 f64: 2048/4096-element tiles on 256 threads are 10-40 % slower (serial per-lane work),
     // 4096-element tiles on 1024 threads gain <= 7 % on the 4-axis sum and lose 8 % on permutes.
     if (t.tilelog == 10) return go_tl<T, F, MIXED, 10, 8>(plan, s, f, tab, narrow);
+    if (t.tilelog == 12) return go_tl<T, F, MIXED, 12, 10>(plan, s, f, tab, narrow);  // experiments (tile_log2 = 12)
     return set_error(SMR_EINVAL, "tiled: the planner must pick 1024-element tiles");
 }
 

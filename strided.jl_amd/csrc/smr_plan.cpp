@@ -375,8 +375,20 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     // The tiled kernel is specialised for 1024-element tiles (256 lanes x 4 elements): measured
     // on MI355X, 1024-element tiles beat 4096-element ones at 32^4 (more workgroups in flight)
     // and tie at 128^4.
+    // Three or more distinct unit axes and a big problem: 4096-element tiles on 1024 threads (the
+    // same 4 elements per lane) keep every operand's contiguous run at >= 64 B.  Measured on the
+    // 4-way permuted sum: 64^4 141 vs 175 us, 128^4 3.24 vs 4.64 ms; at 32^4 (only 256 such tiles)
+    // the small tile is 4 % faster, so it needs >= 1024 big tiles.
     int tl_cap = 10;
-    if ((size_t)nst * ((size_t)1 << tl_cap) * es > (size_t)o.max_lds_bytes) return false;
+    if (o.tile_log2 == 12) tl_cap = 12;
+    else if (o.tile_log2 == 0 && na >= 3 && (size_t)nst * 4096 * es <= (size_t)128 * 1024 && c.total >= (i64)4096 * 1024) {
+        bool fits = true;  // every axis must be able to reach its share of the 12 bits
+        int bits = 0;
+        for (int a = 0; a < na; ++a) bits += std::min(nextpow2_log(c.dims[axes[a]]), 12);
+        if (bits < 12) fits = false;
+        if (fits) tl_cap = 12;
+    }
+    if ((size_t)nst * ((size_t)1 << tl_cap) * es > std::max<size_t>((size_t)o.max_lds_bytes, tl_cap == 12 ? (size_t)128 * 1024 : 0)) return false;
     int lg[MAXN] = {0};
     int total = 0;
     // grow the axes round-robin towards the run target
@@ -412,7 +424,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
             ++lg[i];
             ++total;
         }
-    if (total != 10) return false;  // smaller problems go to the generic family
+    if (total != 10 && total != 12) return false;  // smaller problems go to the generic family
     t.nt = 0;
     t.tilelog = total;
     for (int i = 0; i < c.N; ++i)
@@ -437,7 +449,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
         for (int j = 0; j < t.nt; ++j) t.order[k][j] = idx[j];
     }
     for (int j = 0; j < t.nt; ++j) t.order[0][j] = j;
-    t.threads = 256;
+    t.threads = (total == 12) ? 1024 : 256;
     t.grid = 1;
     for (int i = 0; i < c.N; ++i) {
         i64 e = (i64)1 << lg[i];

@@ -23,6 +23,13 @@ work = {
     "bcast4": (lambda a, b, c, d: a + b + c + d, (B,) + tuple(A.permutedims(q) for q in perms)),
     "sym": (lambda x, y: (x + y) / 2, (B.sreshape((1024, 1024)), A.sreshape((1024, 1024)), A.sreshape((1024, 1024)).adjoint())),
 }
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] == "big":   # 4096-element tiles on 1024 threads
+    S.set_option("max_lds_bytes", 160 * 1024)
+    S.set_option("tile_log2", 12)
+    for i, v in enumerate((3, 3, 3, 3)):
+        S.set_option(f"tile_lg{i}", v)
+    work = {"bcast4": work["bcast4"]}
 names = {0: "full", 4: "no-store", 2: "no-lds", 1: "no-load", 6: "loads only", 5: "lds only", 3: "stores only", 7: "prologue only"}
 for name, (f, arrays) in work.items():
     for ab in (0, 4, 2, 1, 6, 5, 3, 7):
