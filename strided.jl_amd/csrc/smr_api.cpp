@@ -341,8 +341,6 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "stream_unroll") o.stream_unroll = value;
     else if (n == "xcd_swizzle") o.xcd_swizzle = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
-    else if (n == "xcd_classes") o.xcd_classes = value;
-    else if (n == "tiled_ablate") o.tiled_ablate = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
     else if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') o.tile_lg[n[7] - '0'] = value;
     else ok = false;

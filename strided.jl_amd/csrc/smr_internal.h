@@ -134,8 +134,6 @@ struct Options {
     i64 stream_unroll = 4;
     i64 tiled_minrun_bytes = 64;
     i64 xcd_swizzle = 0;
-    i64 tiled_ablate = 0;    // profiling only: skip phases of the tiled kernel (wrong results!)
-    i64 xcd_classes = 0;     // deal permutation-related tiles of aliased inputs to the same XCD (measured: no gain)
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 max_lds_bytes = 65536;
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override

@@ -48,10 +48,9 @@ struct OpDesc {
     typedef typename off_t_of<WIDE>::type O;
     void* base;  // element offset already applied
     int32_t dtype, conj;
-    int32_t vecok, pad_;
+    int32_t pad0_, pad1_;
     O Gt[MAXTH];
     O Gr[MAXREP];
-    O Gh[MAXV];            // byte offset of sub-element h (only used when !vecok)
     uint32_t Lt[MAXTH];    // staged: swizzled LDS index contributions (own order)
     uint32_t Lr[MAXREP];
     uint32_t Lh[MAXV];
@@ -63,12 +62,11 @@ template <bool WIDE>
 struct TiledArgs {
     // header + tile decode: everything the first instructions need, contiguous, so that it
     // arrives with one batch of scalar loads
-    int32_t M, ng, tilelog, nstaged, base32, nt, ablate, xmlog;  // ablate: profiling only (bit0 no loads, bit1 no LDS, bit2 no stores)
-    uint32_t xm, nt0, total_q, pad2;  // XCD classes (xm = 0: off), see the decode below
+    int32_t M, ng, tilelog, nstaged, base32, nt, pad0, pad1;
+    int32_t staged[MAXIN];       // LDS slot of input i or -1
     uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
     OpDesc<WIDE> dst;            // destination (destination order)
     OpDesc<WIDE> in[MAXIN];      // inputs 1..M-1: staged ones in their own order, direct ones in dst order
-    int32_t staged[MAXIN];       // LDS slot of input i or -1
     uint32_t Ltd[MAXTH], Lrd[MAXREP], Lhd[MAXV];  // destination-order LDS index tables
     // edge tiles only
     int32_t tgrid[MAXT], tlog[MAXT];  // grid dim / log2 extent of tiled dim j
@@ -127,19 +125,6 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
 
     // ---- which tile -----------------------------------------------------------------------------
     uint32_t b = blockIdx.x;
-    uint32_t xclass = 0;
-    if (a.xm) {
-        // XCD classes.  Workgroup b runs on XCD b % 8 (own, non-coherent L2).  When several inputs
-        // are dim-permuted views of ONE array (A .+ A', the 4-way permuted sum), tiles whose
-        // coordinates are permutations of each other read the same lines of that array.  Any
-        // symmetric function of the tile coordinates is invariant under those permutations, so
-        // tiles are dealt to XCDs by (sum of tile coordinates) mod xm: every line of the shared
-        // array is then fetched into one L2 instead of up to 8.
-        const uint32_t x = b & 7u;
-        xclass = x & (a.xm - 1u);
-        b = ((b >> 3) << (3 - a.xmlog)) + (x >> a.xmlog);
-        if (b >= a.total_q) return;  // padding workgroup (before any barrier)
-    }
     uint32_t tc[MAXN];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {  // unused grid dims are padded with ntiles = 1
@@ -156,11 +141,6 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
             tc[g] = b - q * a.ntiles[g];
             b = q;
         }
-    }
-    if (a.xm) {  // tc[0] held the class-local index j: t0 = ((class - sum of the others) mod xm) + xm * j
-        const uint32_t t0 = ((xclass - tc[1] - tc[2] - tc[3]) & (a.xm - 1u)) + (tc[0] << a.xmlog);
-        if (t0 >= a.nt0) return;
-        tc[0] = t0;
     }
     uint32_t emin = 0xffffffffu;  // becomes 0 iff some grid coordinate sits on a ragged last tile
 #pragma unroll
@@ -242,17 +222,12 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
             for (int r = 0; r < NREP; ++r) {
                 bool ok = okd[r];
                 if (edge && stg) ok = in_bounds(1 + i, (((uint32_t)r << THRLOG) | tid) << VLOG);
-                if (ok && !(a.ablate & 1)) {
+                if (ok) {
                     const char* p = bp + (gt + d.Gr[r]);
                     if constexpr (V == 1) {
                         x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
                     } else {
-                        if (d.vecok) {
-                            x[i][r] = *reinterpret_cast<const VT*>(p);
-                        } else {  // direct input, broadcast / non-unit stride along the destination axis
-#pragma unroll
-                            for (int h = 0; h < V; ++h) x[i][r].v[h] = *reinterpret_cast<const T*>(p + d.Gh[h]);
-                        }
+                        x[i][r] = *reinterpret_cast<const VT*>(p);
                         if constexpr (tr<T>::cx) {
                             if (d.conj) {
 #pragma unroll
@@ -277,7 +252,7 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
     // ---- phase B: staged inputs -> LDS, destination order, XOR-swizzled -----------------------------
 #pragma unroll
     for (int i = 0; i < NINMAX; ++i) {
-        if (i < nin && a.staged[i] >= 0 && !(a.ablate & 2)) {
+        if (i < nin && a.staged[i] >= 0) {
             const OpDesc<WIDE>& d = a.in[i];
             T* L = lds + ((size_t)a.staged[i] << a.tilelog);
 #pragma unroll
@@ -291,12 +266,12 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
             }
         }
     }
-    if (!(a.ablate & 2)) __syncthreads();
+    __syncthreads();
 
     // ---- phase C: read back in destination order, apply f, store ---------------------------------------
 #pragma unroll
     for (int i = 0; i < NINMAX; ++i) {
-        if (i < nin && a.staged[i] >= 0 && !(a.ablate & 2)) {
+        if (i < nin && a.staged[i] >= 0) {
             const T* L = lds + ((size_t)a.staged[i] << a.tilelog);
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
@@ -309,7 +284,7 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
     }
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
-        if (okd[r] && !(a.ablate & 4)) {
+        if (okd[r]) {
             VT out;
 #pragma unroll
             for (int h = 0; h < V; ++h) {
@@ -357,7 +332,6 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     a.nt = t.nt;
     a.tilelog = t.tilelog;
     a.nstaged = t.nstaged;
-    a.ablate = (int32_t)options().tiled_ablate;
     // swizzle width: the 128 B an LDS write group spans, in elements
     int w = 0;
     while ((sizeof(T) << w) < 128) ++w;
@@ -455,7 +429,6 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             uint32_t l = 0;
             for (int bit = 0; bit < vlog; ++bit)
                 if ((h >> bit) & 1) { g += gbit[bit]; l ^= lbit[bit]; }
-            d.Gh[h] = (O)g;
             d.Lh[h] = l;
         }
         for (int bit = 0; bit < THRLOG; ++bit) {
@@ -470,9 +443,6 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             d.Gr[r] = (O)g;
             d.Lr[r] = l;
         }
-        // one V-wide access is possible when the operand is unit-stride along its first axis
-        const int j0 = own ? t.order[k][0] : 0;
-        d.vecok = (c.strides[k][t.tdim[j0]] == 1) ? 1 : 0;
     };
     fill(a.dst, 0, false);
     for (int bit = 0; bit < THRLOG; ++bit) a.Ltd[bit] = a.dst.Lt[bit];
@@ -485,40 +455,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         a.staged[k - 1] = t.staged[k];
 
     }
-    // XCD classes: when two or more inputs are views of the same buffer (see the kernel's decode)
-    i64 grid = t.grid;
-    {
-        bool aliased = false;
-        for (int k = 1; k < c.M; ++k)
-            for (int l = k + 1; l < c.M; ++l)
-                if (c.base[k] == c.base[l]) aliased = true;
-        if (aliased && options().xcd_classes && ng >= 2 && ng <= NG) {
-            const uint32_t nt0 = a.ntiles[0];
-            uint32_t xm = 1, xl = 0;
-            while (xm < 8 && xm < nt0) { xm <<= 1; ++xl; }
-            if (xm >= 2) {
-                const uint32_t njb = (nt0 + xm - 1) / xm;
-                i64 tq = njb;
-                for (int g = 1; g < ng; ++g) tq *= a.ntiles[g];
-                const i64 perx = (tq + (8 / xm) - 1) / (8 / xm);
-                if (perx * 8 < 0x7fffffffLL) {
-                    a.xm = xm;
-                    a.xmlog = (int32_t)xl;
-                    a.nt0 = nt0;
-                    a.total_q = (uint32_t)tq;
-                    a.ntiles[0] = njb;  // the decode extracts j in [0, njb) first
-                    if (njb <= 1) { a.div_m[0] = 0; a.div_s[0] = 0; }
-                    else {
-                        int l2 = 0;
-                        while ((1ull << l2) < njb) ++l2;
-                        a.div_m[0] = (uint32_t)((((1ull << 32) * ((1ull << l2) - njb)) / njb) + 1);
-                        a.div_s[0] = (uint32_t)l2;
-                    }
-                    grid = perx * 8;
-                }
-            }
-        }
-    }
+    const i64 grid = t.grid;
     size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
     auto kern = k_tiled_map<T, F, MIXED, WIDE, V, NREP, EDGE, THRLOG>;
     clear_sticky_error();
@@ -555,7 +492,7 @@ static bool vector_ok(const Plan& plan, const OpTab& tab, int V) {
         const int d0 = t.tdim[j0];
         const i64 s0 = c.strides[k][d0];
         if (t.tlog[j0] < vlog) return false;
-        if (!staged && k > 0 && s0 != 1) continue;  // direct, not unit stride: read per element
+        // a direct input that is not unit-stride along dim 0 (broadcast, odd stride) has no V-wide form
         if (s0 != 1) return false;
         if (c.dims[d0] % V) return false;
         if (((uintptr_t)tab.base[k]) % vb) return false;
