@@ -106,6 +106,11 @@ static int ensure_scratch(smr_plan* h) {
 static void plan_free(smr_plan* h) {
     if (!h) return;
     if (h->plan.scratch) (void)hipFree(h->plan.scratch);
+    for (void*& p : h->plan.lanetab)
+        if (p) {
+            (void)hipFree(p);
+            p = nullptr;
+        }
     delete h;
 }
 

@@ -123,6 +123,8 @@ struct Plan {
     int red_blocks = 0;
     int part_tr = 1;    // REDUCE_PART: lanes cooperating on one output
     int part_split = 1; // REDUCE_PART: chunks of the reduced range (two-pass when > 1)
+    // TILED: per-lane index tables in device memory, one per kernel variant (built on first use)
+    mutable void* lanetab[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string desc;
 };
 

@@ -3,27 +3,32 @@
 //
 // MI355X design (not the reference's L1-blocked loop nest, src/mapreduce.jl:385-401):
 //   * a workgroup owns one N-d tile whose extents are powers of two and which is long enough
-//     along EVERY operand's unit-stride axis;
-//   * phase 1: each transposed input is read from HBM in ITS OWN stride order (consecutive
-//     lanes walk that input's unit-stride axis -> coalesced, 16 bytes per lane) and scattered
-//     into an LDS tile laid out in DESTINATION order, XOR-swizzled so that the strided LDS
-//     writes of a lane group fall on distinct banks; every load is issued before the first
-//     LDS write (memory-level parallelism);
-//   * phase 2: the tile is walked in destination order: staged inputs come from LDS
-//     (conflict-free linear reads), inputs that already share the destination's unit axis
-//     come straight from HBM, f is applied in registers, the store is coalesced (16 B/lane).
+//     along EVERY operand's unit-stride axis (1024 elements on 256 lanes; 4096 on 1024 lanes
+//     for big problems with three or more distinct unit axes: always 4 elements per lane);
+//   * phase A: every global load of the tile is issued up front: transposed inputs in THEIR
+//     OWN stride order (consecutive lanes walk that input's unit-stride axis -> coalesced,
+//     16 bytes per lane), direct inputs in destination order;
+//   * phase B: transposed inputs are scattered into an LDS tile laid out in DESTINATION
+//     order, XOR-swizzled so that the strided LDS writes of a lane group fall on distinct
+//     banks;
+//   * phase C: linear (conflict-free) LDS reads, f applied in registers, 16-byte coalesced
+//     stores.
 //
 // Index arithmetic.  Tile extents are powers of two, so the position e of an element inside a
 // tile (in any operand's enumeration order) is a bit string, and both its global byte offset
 // and its swizzled LDS index are ADD/XOR-linear in those bits.  A lane owns NREP vectors of V
-// consecutive elements: e = ((r*256 + tid) << vlog) + h.  The host ships, per operand,
-//     Gt[b], Lt[b]  b < 8      contribution of bit b of tid   (8 masked VALU adds per phase)
-//     Gr[r], Lr[r]  r < NREP   contribution of repeat index r (pre-combined: no ALU at all)
-//     Lh[h]         h < V      LDS index of sub-element h
-// so the loops contain no scalar arithmetic.  Measured history (32^4 f64 permutedims!, kernel
-// time): generic per-dim decode with dependent kernarg loads 11.5 us (~2000 SALU
-// instructions per wave: bound by the CU's single scalar unit) -> per-bit tables 6.0 us
-// (~430 SALU) -> this version.
+// consecutive elements: e = ((r*T + tid) << vlog) + h.  The host precomputes
+//     lane table  (device memory, one row per lane and operand): byte offset + LDS index of
+//                 the tid bits -- ONE 8-byte vector load per operand, issued first thing;
+//     Gr[r], Lr[r], Lh[h] (kernel arguments): contribution of repeat index r / sub-element h,
+// so the kernel contains no index arithmetic beyond one add (address) and one xor (LDS) per
+// access.  Tile coordinates come from multiply-shift division of the workgroup id.
+// Measured history (32^4 f64, permutedims! / 4-way sum, us per launch): generic per-dim decode
+// with dependent kernarg loads 11.5 / 28.5 (~2000 scalar instructions per wave: bound by the
+// CU's single scalar unit) -> per-bit tables 6.0 / 14.6 -> 16-B vectors + repeat tables
+// 4.4 / 9.9 -> all loads first, branch-free variants 4.1 / 8.9 -> lane tables: this version.
+#include <vector>
+
 #include "smr_dispatch.h"
 
 #ifndef SMR_CT
@@ -33,54 +38,46 @@
 namespace smr {
 
 constexpr int MAXT = 5;
-constexpr int MAXTH = 10;   // log2 of the largest workgroup (256 or 1024 threads)
-constexpr int NG = 4;       // grid dims decoded branch-free; further ones in a (rare) loop
-constexpr int MAXREP = 16;  // max vectors per lane
-constexpr int MAXV = 16;    // max elements per vector (1-byte elements)
+constexpr int NG = 4;   // grid dims decoded branch-free; further ones in a (rare) loop
+constexpr int EPL = 4;  // elements per lane (tile elements / workgroup size)
 
 template <bool WIDE> struct off_t_of { typedef uint32_t type; };
 template <> struct off_t_of<true> { typedef i64 type; };
 
-// One operand as the kernel sees it.  Staged inputs are enumerated in their own stride order,
-// the destination and direct inputs in destination order.
+// one row of the per-lane table
+template <bool WIDE> struct LaneRow { uint32_t g; uint32_t l; };
+template <> struct alignas(16) LaneRow<true> { i64 g; uint32_t l; uint32_t pad; };
+
+// Wave-uniform description of one operand (a few wide scalar loads).
 template <bool WIDE>
 struct OpDesc {
     typedef typename off_t_of<WIDE>::type O;
-    void* base;  // element offset already applied
+    void* base;            // element offset already applied
+    uint32_t tstep32[NG];  // byte offset of one tile step along grid dim g (when base32)
+    O Gr[EPL];             // byte offset of repeat index r (own order if staged, else dst order)
+    uint32_t Lr[EPL];      // staged: swizzled LDS index of repeat index r (own order)
+    uint32_t Lh[EPL];      // staged: ... of sub-element h
     int32_t dtype, conj;
-    int32_t pad0_, pad1_;
-    O Gt[MAXTH];
-    O Gr[MAXREP];
-    uint32_t Lt[MAXTH];    // staged: swizzled LDS index contributions (own order)
-    uint32_t Lr[MAXREP];
-    uint32_t Lh[MAXV];
-    i64 tstep[MAXN];       // byte offset of one tile step along grid dim g
-    uint32_t tstep32[NG];
 };
 
 template <bool WIDE>
 struct TiledArgs {
-    // header + tile decode: everything the first instructions need, contiguous, so that it
-    // arrives with one batch of scalar loads
+    // header + tile decode first: they arrive with the first batch of scalar loads
     int32_t M, ng, tilelog, nstaged, base32, nt, pad0, pad1;
-    int32_t staged[MAXIN];       // LDS slot of input i or -1
+    int32_t staged[MAXM];  // [1 + i]: LDS slot of input i or -1 ([0] unused)
     uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
-    OpDesc<WIDE> dst;            // destination (destination order)
-    OpDesc<WIDE> in[MAXIN];      // inputs 1..M-1: staged ones in their own order, direct ones in dst order
-    uint32_t Ltd[MAXTH], Lrd[MAXREP], Lhd[MAXV];  // destination-order LDS index tables
+    const LaneRow<WIDE>* lanetab;  // [(operand k) * T + tid], k = 0 destination
+    OpDesc<WIDE> op[MAXM];         // [0] destination, [1 + i] input i
+    uint32_t Lrd[EPL], Lhd[EPL];   // destination-order LDS index of repeat r / sub-element h
+    i64 tstep[MAXM][MAXN];         // 64-bit tile steps (only read when !base32)
     // edge tiles only
     int32_t tgrid[MAXT], tlog[MAXT];  // grid dim / log2 extent of tiled dim j
-    int32_t esh[MAXM][MAXT];          // [0] = destination order, [1+i] = input i's order
+    int32_t esh[MAXM][MAXT];          // bit position of tiled dim j in operand k's enumeration
     i64 gdims[MAXN];
     int32_t glog[MAXN];
 };
 
 SMR_DEV uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s) { return (__umulhi(m, n) + n) >> s; }
-
-// all-ones / zero 32-bit mask widened to the offset type
-template <class O> SMR_DEV O m_ext(uint32_t m);
-template <> SMR_DEV uint32_t m_ext<uint32_t>(uint32_t m) { return m; }
-template <> SMR_DEV i64 m_ext<i64>(uint32_t m) { return (i64)(int32_t)m; }
 
 template <class T, int V>
 struct alignas(sizeof(T) * V) TVec {
@@ -110,12 +107,14 @@ SMR_DEV void store_at(char* p, int dtype, int conj, T v) {
         *reinterpret_cast<T*>(p) = v;
 }
 
-// V > 1 implies !MIXED && !WIDE (enforced by the launcher).
-template <class T, class F, bool MIXED, bool WIDE, int V, int NREP, bool EDGE, int THRLOG>
+// V > 1 implies !MIXED && !WIDE and every direct operand unit-stride along dim 0 (launcher).
+template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
 __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE> a, F f) {
     typedef typename off_t_of<WIDE>::type O;
     typedef TVec<T, V> VT;
-    constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : (V == 4 ? 2 : (V == 8 ? 3 : 4)));
+    constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : 2);
+    constexpr int NREP = EPL / V;
+    constexpr int NT = 1 << THRLOG;
     constexpr int NIN_STATIC = F::NIN;
     constexpr int NINMAX = (NIN_STATIC >= 0) ? NIN_STATIC : MAXIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -123,7 +122,16 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
     const int nin = (NIN_STATIC >= 0) ? NIN_STATIC : a.M - 1;
     const uint32_t tid = threadIdx.x;
 
-    // ---- which tile -----------------------------------------------------------------------------
+    // ---- per-lane table rows: the very first memory instructions of the kernel ----------------------
+    LaneRow<WIDE> row[NINMAX + 1];
+#pragma unroll
+    for (int k = 0; k <= NINMAX; ++k) {
+        row[k].g = 0;
+        row[k].l = 0;
+        if (k <= nin) row[k] = a.lanetab[k * NT + tid];
+    }
+
+    // ---- which tile ---------------------------------------------------------------------------------
     uint32_t b = blockIdx.x;
     uint32_t tc[MAXN];
 #pragma unroll
@@ -142,57 +150,53 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
             b = q;
         }
     }
-    uint32_t emin = 0xffffffffu;  // becomes 0 iff some grid coordinate sits on a ragged last tile
-#pragma unroll
-    for (int g = 0; g < MAXN; ++g)
-        if (g < NG || a.ng > NG) emin = min(emin, tc[g] ^ a.last_ragged[g]);
     // EDGE = false is instantiated for problems without any ragged dim: no bounds code at all
-    // (smaller kernel: the per-launch instruction fetch is part of a ~4 us launch)
-    const bool edge = EDGE && emin == 0;
+    // (code size is part of the latency of a ~4 us launch)
+    bool edge = false;
     uint32_t lim[MAXT];
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) lim[j] = 0x7fffffffu;
-    if (edge) {
+    if constexpr (EDGE) {
+        uint32_t emin = 0xffffffffu;  // 0 iff some grid coordinate sits on a ragged last tile
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j)
-            if (j < a.nt && a.tgrid[j] >= 0) {
-                const int g = a.tgrid[j];
-                i64 left = a.gdims[g];
+        for (int g = 0; g < MAXN; ++g)
+            if (g < NG || a.ng > NG) emin = min(emin, tc[g] ^ a.last_ragged[g]);
+        edge = emin == 0;
+        if (edge) {
 #pragma unroll
-                for (int gg = 0; gg < MAXN; ++gg)
-                    if (gg == g) left -= (i64)tc[gg] << a.glog[gg];
-                lim[j] = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
-            }
+            for (int j = 0; j < MAXT; ++j)
+                if (j < a.nt && a.tgrid[j] >= 0) {
+                    const int g = a.tgrid[j];
+                    i64 left = a.gdims[g];
+#pragma unroll
+                    for (int gg = 0; gg < MAXN; ++gg)
+                        if (gg == g) left -= (i64)tc[gg] << a.glog[gg];
+                    lim[j] = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
+                }
+        }
     }
-    auto in_bounds = [&](int row, uint32_t e) {
+    auto in_bounds = [&](int k, uint32_t e) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < MAXT; ++j)
-            if (j < a.nt) ok = ok && (((e >> a.esh[row][j]) & ((1u << a.tlog[j]) - 1u)) < lim[j]);
+            if (j < a.nt) ok = ok && (((e >> a.esh[k][j]) & ((1u << a.tlog[j]) - 1u)) < lim[j]);
         return ok;
     };
-    auto tile_base = [&](const OpDesc<WIDE>& d) -> char* {
-        if (a.base32) {  // whole operand spans < 4 GiB and no negative tile step
+    auto tile_base = [&](int k) -> char* {
+        if (a.base32) {  // every tile origin of every operand is below 4 GiB, steps non-negative
             uint32_t o = 0;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) o += tc[g] * d.tstep32[g];
-            return (char*)d.base + o;
+            for (int g = 0; g < NG; ++g) o += tc[g] * a.op[k].tstep32[g];
+            return (char*)a.op[k].base + o;
         }
         i64 o = 0;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) o += (i64)tc[g] * d.tstep[g];
-        if (a.ng > NG) {
-#pragma unroll
-            for (int g = NG; g < MAXN; ++g) o += (i64)tc[g] * d.tstep[g];
-        }
-        return (char*)d.base + o;
+        for (int g = 0; g < MAXN; ++g)
+            if (g < NG || a.ng > NG) o += (i64)tc[g] * a.tstep[k][g];
+        return (char*)a.op[k].base + o;
     };
-    uint32_t tm[THRLOG];  // all-ones where the tid bit is set
-#pragma unroll
-    for (int bit = 0; bit < THRLOG; ++bit) tm[bit] = 0u - ((tid >> bit) & 1u);
 
-    // ---- phase A: issue EVERY global load of the tile (staged inputs in their own order, direct
-    // inputs in destination order) before anything waits: one round of memory latency per tile.
+    // ---- phase A: issue EVERY global load of the tile before anything waits ------------------------
     VT x[NINMAX > 0 ? NINMAX : 1][NREP];
     bool okd[NREP];  // destination-order validity of repeat r (edge tiles)
 #pragma unroll
@@ -200,30 +204,22 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
         okd[r] = true;
         if (edge) okd[r] = in_bounds(0, (((uint32_t)r << THRLOG) | tid) << VLOG);
     }
-    uint32_t lts[NINMAX > 0 ? NINMAX : 1];  // staged: per-lane swizzled LDS index (own order)
 #pragma unroll
     for (int i = 0; i < NINMAX; ++i) {
-        lts[i] = 0;
 #pragma unroll
         for (int r = 0; r < NREP; ++r)
 #pragma unroll
             for (int h = 0; h < V; ++h) x[i][r].v[h] = T{};
         if (i < nin) {
-            const OpDesc<WIDE>& d = a.in[i];
-            const char* bp = tile_base(d);
-            const bool stg = a.staged[i] >= 0;
-            O gt = 0;
-#pragma unroll
-            for (int bit = 0; bit < THRLOG; ++bit) {
-                gt += d.Gt[bit] & m_ext<O>(tm[bit]);
-                lts[i] ^= d.Lt[bit] & tm[bit];
-            }
+            const OpDesc<WIDE>& d = a.op[i + 1];
+            const char* bp = tile_base(i + 1);
+            const bool stg = a.staged[i + 1] >= 0;
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
                 bool ok = okd[r];
-                if (edge && stg) ok = in_bounds(1 + i, (((uint32_t)r << THRLOG) | tid) << VLOG);
+                if (edge && stg) ok = in_bounds(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG);
                 if (ok) {
-                    const char* p = bp + (gt + d.Gr[r]);
+                    const char* p = bp + (O)(row[i + 1].g + d.Gr[r]);
                     if constexpr (V == 1) {
                         x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
                     } else {
@@ -239,29 +235,21 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
             }
         }
     }
-    // destination addressing (its table loads overlap the memory latency above)
-    char* bp0 = tile_base(a.dst);
-    O gt0 = 0;
-    uint32_t ltd = 0;
-#pragma unroll
-    for (int bit = 0; bit < THRLOG; ++bit) {
-        gt0 += a.dst.Gt[bit] & m_ext<O>(tm[bit]);
-        ltd ^= a.Ltd[bit] & tm[bit];
-    }
+    char* bp0 = tile_base(0);
 
     // ---- phase B: staged inputs -> LDS, destination order, XOR-swizzled -----------------------------
 #pragma unroll
     for (int i = 0; i < NINMAX; ++i) {
-        if (i < nin && a.staged[i] >= 0) {
-            const OpDesc<WIDE>& d = a.in[i];
-            T* L = lds + ((size_t)a.staged[i] << a.tilelog);
+        if (i < nin && a.staged[i + 1] >= 0) {
+            const OpDesc<WIDE>& d = a.op[i + 1];
+            T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
                 bool ok = true;
-                if (edge) ok = in_bounds(1 + i, (((uint32_t)r << THRLOG) | tid) << VLOG);
+                if (edge) ok = in_bounds(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG);
                 if (ok) {
 #pragma unroll
-                    for (int h = 0; h < V; ++h) L[lts[i] ^ d.Lr[r] ^ d.Lh[h]] = x[i][r].v[h];
+                    for (int h = 0; h < V; ++h) L[row[i + 1].l ^ d.Lr[r] ^ d.Lh[h]] = x[i][r].v[h];
                 }
             }
         }
@@ -271,13 +259,13 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
     // ---- phase C: read back in destination order, apply f, store ---------------------------------------
 #pragma unroll
     for (int i = 0; i < NINMAX; ++i) {
-        if (i < nin && a.staged[i] >= 0) {
-            const T* L = lds + ((size_t)a.staged[i] << a.tilelog);
+        if (i < nin && a.staged[i + 1] >= 0) {
+            const T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
                 if (okd[r]) {
 #pragma unroll
-                    for (int h = 0; h < V; ++h) x[i][r].v[h] = L[ltd ^ a.Lrd[r] ^ a.Lhd[h]];
+                    for (int h = 0; h < V; ++h) x[i][r].v[h] = L[row[0].l ^ a.Lrd[r] ^ a.Lhd[h]];
                 }
             }
         }
@@ -296,12 +284,12 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
                 }
                 out.v[h] = f(arg);
             }
-            char* p = bp0 + (gt0 + a.dst.Gr[r]);
+            char* p = bp0 + (O)(row[0].g + a.op[0].Gr[r]);
             if constexpr (V == 1) {
-                store_at<T, MIXED>(p, a.dst.dtype, a.dst.conj, out.v[0]);
+                store_at<T, MIXED>(p, a.op[0].dtype, a.op[0].conj, out.v[0]);
             } else {
                 if constexpr (tr<T>::cx) {
-                    if (a.dst.conj) {
+                    if (a.op[0].conj) {
 #pragma unroll
                         for (int h = 0; h < V; ++h) out.v[h] = cj(out.v[h]);
                     }
@@ -319,9 +307,11 @@ static uint32_t host_swizzle(uint32_t l, int w) {
     return l ^ f;
 }
 
-template <class T, class F, bool MIXED, bool WIDE, int V, int NREP, bool EDGE, int THRLOG>
+template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
 static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     typedef typename off_t_of<WIDE>::type O;
+    constexpr int NREP = EPL / V;
+    constexpr int NT = 1 << THRLOG;
     const Canon& c = plan.c;
     const TilePlan& t = plan.tile;
     int vlog = 0;
@@ -399,15 +389,25 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     }
     a.base32 = base32 ? 1 : 0;
 
-    auto fill = [&](OpDesc<WIDE>& d, int k, bool own) {
+    // per-lane table: built once per (plan, kernel variant), kept in device memory
+    constexpr int variant = (WIDE ? 2 : 0) + (V > 1 ? 1 : 0);
+    const bool build_tab = plan.lanetab[variant] == nullptr;
+    std::vector<LaneRow<WIDE>> rows;
+    if (build_tab) rows.assign((size_t)c.M * NT, LaneRow<WIDE>{});
+
+    for (int k = 0; k < MAXM; ++k) a.staged[k] = -1;
+    for (int k = 0; k < c.M; ++k) {
+        const bool own = k > 0 && t.staged[k] >= 0;
+        OpDesc<WIDE>& d = a.op[k];
         const i64 es = c.esize[k];
+        a.staged[k] = own ? t.staged[k] : -1;
         d.base = tab.base[k];
         d.dtype = tab.dtype[k];
         d.conj = tab.conj[k];
         for (int dd = 0; dd < c.N; ++dd)
             if (gof[dd] >= 0) {
                 const i64 st = c.strides[k][dd] * ((i64)1 << tlogdim[dd]) * es;
-                d.tstep[gof[dd]] = st;
+                a.tstep[k][gof[dd]] = st;
                 if (gof[dd] < NG) d.tstep32[gof[dd]] = (uint32_t)st;
             }
         // per-bit contributions in this operand's enumeration order
@@ -416,8 +416,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         int pos = 0;
         for (int jj = 0; jj < t.nt; ++jj) {
             const int j = own ? t.order[k][jj] : jj;
-            a.esh[own ? k : 0][j] = pos;
-            if (!own && k > 0) a.esh[k][j] = pos;
+            a.esh[k][j] = pos;
             for (int bit = 0; bit < t.tlog[j]; ++bit) {
                 gbit[pos + bit] = c.strides[k][t.tdim[j]] * ((i64)1 << bit) * es;
                 lbit[pos + bit] = host_swizzle(1u << (lsh[j] + bit), w);
@@ -425,57 +424,73 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             pos += t.tlog[j];
         }
         for (int h = 0; h < V; ++h) {
-            i64 g = 0;
             uint32_t l = 0;
             for (int bit = 0; bit < vlog; ++bit)
-                if ((h >> bit) & 1) { g += gbit[bit]; l ^= lbit[bit]; }
+                if ((h >> bit) & 1) l ^= lbit[bit];
             d.Lh[h] = l;
-        }
-        for (int bit = 0; bit < THRLOG; ++bit) {
-            d.Gt[bit] = (O)gbit[vlog + bit];
-            d.Lt[bit] = lbit[vlog + bit];
         }
         for (int r = 0; r < NREP; ++r) {
             i64 g = 0;
             uint32_t l = 0;
             for (int bit = 0; bit < 5; ++bit)
-                if ((r >> bit) & 1) { g += gbit[vlog + THRLOG + bit]; l ^= lbit[vlog + THRLOG + bit]; }
+                if ((r >> bit) & 1) {
+                    g += gbit[vlog + THRLOG + bit];
+                    l ^= lbit[vlog + THRLOG + bit];
+                }
             d.Gr[r] = (O)g;
             d.Lr[r] = l;
         }
-    };
-    fill(a.dst, 0, false);
-    for (int bit = 0; bit < THRLOG; ++bit) a.Ltd[bit] = a.dst.Lt[bit];
-    for (int r = 0; r < NREP; ++r) a.Lrd[r] = a.dst.Lr[r];
-    for (int h = 0; h < V; ++h) a.Lhd[h] = a.dst.Lh[h];
-    for (int i = 0; i < MAXIN; ++i) a.staged[i] = -1;
-    for (int k = 1; k < c.M; ++k) {
-        const bool own = t.staged[k] >= 0;
-        fill(a.in[k - 1], k, own);
-        a.staged[k - 1] = t.staged[k];
-
+        if (build_tab)
+            for (int tid = 0; tid < NT; ++tid) {
+                i64 g = 0;
+                uint32_t l = 0;
+                for (int bit = 0; bit < THRLOG; ++bit)
+                    if ((tid >> bit) & 1) {
+                        g += gbit[vlog + bit];
+                        l ^= lbit[vlog + bit];
+                    }
+                rows[(size_t)k * NT + tid].g = (O)g;
+                rows[(size_t)k * NT + tid].l = l;
+            }
     }
-    const i64 grid = t.grid;
-    size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
-    auto kern = k_tiled_map<T, F, MIXED, WIDE, V, NREP, EDGE, THRLOG>;
+    for (int r = 0; r < NREP; ++r) a.Lrd[r] = a.op[0].Lr[r];
+    for (int h = 0; h < V; ++h) a.Lhd[h] = a.op[0].Lh[h];
+    if (build_tab) {
+        void* dptr = nullptr;
+        const size_t bytes = rows.size() * sizeof(LaneRow<WIDE>);
+        hipError_t e = hipMalloc(&dptr, bytes);
+        if (e != hipSuccess) return hip_error(e, "hipMalloc(lane table)");
+        // synchronous upload, once per plan and kernel variant (must not happen inside a stream
+        // capture: execute a plan once before capturing it into a hipGraph)
+        e = hipMemcpy(dptr, rows.data(), bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(dptr);
+            return hip_error(e, "hipMemcpy(lane table)");
+        }
+        plan.lanetab[variant] = dptr;
+    }
+    a.lanetab = reinterpret_cast<const LaneRow<WIDE>*>(plan.lanetab[variant]);
+
+    const size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
+    auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
     clear_sticky_error();
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1u << THRLOG), lds, s, a, f);
+    hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3(1u << THRLOG), lds, s, a, f);
     return check_launch("k_tiled_map");
 }
 
-template <class T, class F, bool MIXED, bool WIDE, int V, int NREP, int THRLOG>
+template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
 static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     const Canon& c = plan.c;
     const TilePlan& t = plan.tile;
     bool ragged = false;
     for (int j = 0; j < t.nt; ++j)
         if (c.dims[t.tdim[j]] & (((i64)1 << t.tlog[j]) - 1)) ragged = true;
-    if (ragged) return go3e<T, F, MIXED, WIDE, V, NREP, true, THRLOG>(plan, s, f, tab);
-    return go3e<T, F, MIXED, WIDE, V, NREP, false, THRLOG>(plan, s, f, tab);
+    if (ragged) return go3e<T, F, MIXED, WIDE, V, true, THRLOG>(plan, s, f, tab);
+    return go3e<T, F, MIXED, WIDE, V, false, THRLOG>(plan, s, f, tab);
 }
 
 // Can every operand be accessed V elements at a time (V * sizeof(T) <= 16 bytes)?
@@ -490,10 +505,9 @@ static bool vector_ok(const Plan& plan, const OpTab& tab, int V) {
         const bool staged = k > 0 && t.staged[k] >= 0;
         const int j0 = staged ? t.order[k][0] : 0;  // first axis of this operand's enumeration
         const int d0 = t.tdim[j0];
-        const i64 s0 = c.strides[k][d0];
         if (t.tlog[j0] < vlog) return false;
         // a direct input that is not unit-stride along dim 0 (broadcast, odd stride) has no V-wide form
-        if (s0 != 1) return false;
+        if (c.strides[k][d0] != 1) return false;
         if (c.dims[d0] % V) return false;
         if (((uintptr_t)tab.base[k]) % vb) return false;
         for (int d = 0; d < c.N; ++d)
@@ -502,17 +516,15 @@ static bool vector_ok(const Plan& plan, const OpTab& tab, int V) {
     return true;
 }
 
-template <class T, class F, bool MIXED, int TL, int THRLOG>
+template <class T, class F, bool MIXED, int THRLOG>
 static int go_tl(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool narrow) {
-    constexpr int EPL = 1 << (TL - THRLOG);  // elements per lane
-    if (!narrow) return go3<T, F, MIXED, true, 1, EPL, THRLOG>(plan, s, f, tab);
+    if (!narrow) return go3<T, F, MIXED, true, 1, THRLOG>(plan, s, f, tab);
     if constexpr (!MIXED && sizeof(T) < 16) {
-        // a lane's elements as 16-byte vectors (8-byte for 1/2-byte element types)
+        // a lane's 4 elements as 16-byte vectors (8-byte for 1/2-byte element types)
         constexpr int VMAX = (16 / sizeof(T)) > 4 ? 4 : (int)(16 / sizeof(T));
-        if (options().tiled_vec && vector_ok<T>(plan, tab, VMAX))
-            return go3<T, F, false, false, VMAX, EPL / VMAX, THRLOG>(plan, s, f, tab);
+        if (options().tiled_vec && vector_ok<T>(plan, tab, VMAX)) return go3<T, F, false, false, VMAX, THRLOG>(plan, s, f, tab);
     }
-    return go3<T, F, MIXED, false, 1, EPL, THRLOG>(plan, s, f, tab);
+    return go3<T, F, MIXED, false, 1, THRLOG>(plan, s, f, tab);
 }
 
 template <class T, class F, bool MIXED>
@@ -531,12 +543,11 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         }
         if (span >= 4294967296.0L) narrow = false;
     }
-    // 1024-element tiles on 256 threads (4 elements per lane).  Measured alternatives on MI355X,
-    // 32^4 f64: 2048/4096-element tiles on 256 threads are 10-40 % slower (serial per-lane work),
-    // 4096-element tiles on 1024 threads gain <= 7 % on the 4-axis sum and lose 8 % on permutes.
-    if (t.tilelog == 10) return go_tl<T, F, MIXED, 10, 8>(plan, s, f, tab, narrow);
-    if (t.tilelog == 12) return go_tl<T, F, MIXED, 12, 10>(plan, s, f, tab, narrow);  // experiments (tile_log2 = 12)
-    return set_error(SMR_EINVAL, "tiled: the planner must pick 1024-element tiles");
+    // always 4 elements per lane: 1024-element tiles on 256 lanes, 4096-element tiles on 1024 lanes.
+    // Measured alternatives (32^4 f64): 2048/4096-element tiles on 256 lanes are 10-40 % slower.
+    if (t.tilelog == 10) return go_tl<T, F, MIXED, 8>(plan, s, f, tab, narrow);
+    if (t.tilelog == 12) return go_tl<T, F, MIXED, 10>(plan, s, f, tab, narrow);
+    return set_error(SMR_EINVAL, "tiled: the planner must pick 1024- or 4096-element tiles");
 }
 
 template <>
