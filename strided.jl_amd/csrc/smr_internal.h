@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/strided_hip.h"
 
@@ -125,6 +126,7 @@ struct Plan {
     int part_split = 1; // REDUCE_PART: chunks of the reduced range (two-pass when > 1)
     // TILED: per-lane index tables in device memory, one per kernel variant (built on first use)
     mutable void* lanetab[4] = {nullptr, nullptr, nullptr, nullptr};
+    mutable std::vector<unsigned char> tiled_args[4];  // fully built kernel arguments per variant
     std::string desc;
 };
 

@@ -27,6 +27,8 @@
 // with dependent kernarg loads 11.5 / 28.5 (~2000 scalar instructions per wave: bound by the
 // CU's single scalar unit) -> per-bit tables 6.0 / 14.6 -> 16-B vectors + repeat tables
 // 4.4 / 9.9 -> all loads first, branch-free variants 4.1 / 8.9 -> lane tables: this version.
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "smr_dispatch.h"
@@ -300,11 +302,84 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
     }
 }
 
-static uint32_t host_swizzle(uint32_t l, int w) {
-    if (w == 0) return l;
-    const uint32_t x = l >> w;
-    const uint32_t f = (x ^ (x >> w) ^ (x >> (2 * w)) ^ (x >> (3 * w)) ^ (x >> (4 * w))) & ((1u << w) - 1u);
-    return l ^ f;
+// ---- LDS swizzle ------------------------------------------------------------------------------------
+// l' = l ^ XOR_{b >= w, bit b of l set} mask[b]: the low w index bits (the 128 B one LDS write
+// group spans, in elements) are XORed with one w-bit mask per higher index bit.  A lane group's
+// accesses are conflict-free iff the slot images of the index bits its lanes toggle are linearly
+// independent over GF(2).  The masks are searched on the host (a small hill climb, once per plan)
+// against the write pattern of every staged operand and the destination-order read pattern; the
+// start point is the plain fold mask[b] = 1 << ((b - w) mod w).
+struct Swizzle {
+    int w;
+    uint32_t mask[32];
+    uint32_t apply(uint32_t l) const {
+        uint32_t r = l;
+        for (int b = w; b < 32; ++b)
+            if ((l >> b) & 1u) r ^= mask[b];
+        return r;
+    }
+};
+
+static int gf2_rank(const uint32_t* v, int n) {
+    uint32_t basis[32];
+    int r = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t x = v[i];
+        for (int j = 0; j < r; ++j)
+            if ((x ^ basis[j]) < x) x ^= basis[j];
+        if (x) {
+            basis[r++] = x;
+            for (int j = r - 1; j > 0 && basis[j] > basis[j - 1]; --j) std::swap(basis[j], basis[j - 1]);
+        }
+    }
+    return r;
+}
+
+// the index bits one hardware lane group toggles + the width of the bank-slot space it lands in
+struct LanePattern {
+    int n;
+    int bits[8];
+    int slotbits;
+};
+
+static Swizzle choose_swizzle(int tilelog, int w, const std::vector<LanePattern>& pats, int* cost0 = nullptr, int* cost1 = nullptr) {
+    Swizzle sw;
+    sw.w = (w > 0 && tilelog > w) ? w : 32;
+    for (int b = 0; b < 32; ++b) sw.mask[b] = 0;
+    if (sw.w == 32) return sw;
+    for (int b = w; b < tilelog; ++b) sw.mask[b] = 1u << ((b - w) % w);
+    auto cost = [&](const Swizzle& s) {
+        int c = 0;
+        for (const LanePattern& p : pats) {
+            uint32_t img[8];
+            const uint32_t sm = (1u << p.slotbits) - 1u;
+            for (int i = 0; i < p.n; ++i) {
+                const int b = p.bits[i];
+                uint32_t v = 1u << b;          // the bit itself (dropped below if outside the slot space)
+                if (b >= w) v ^= s.mask[b];   // its swizzle mask (acts on the low w bits)
+                img[i] = v & sm;
+            }
+            c += (1 << (p.n - gf2_rank(img, p.n))) - 1;
+        }
+        return c;
+    };
+    int best = cost(sw);
+    if (cost0) *cost0 = best;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    for (int it = 0; it < 6000 && best > 0; ++it) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        const int b = w + (int)((rng >> 33) % (uint64_t)(tilelog - w));
+        const uint32_t m = (uint32_t)((rng >> 20) & ((1u << w) - 1u));
+        Swizzle t = sw;
+        t.mask[b] = m;
+        const int c = cost(t);
+        if (c <= best) {
+            best = c;
+            sw = t;
+        }
+    }
+    if (cost1) *cost1 = best;
+    return sw;
 }
 
 template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
@@ -316,16 +391,24 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     const TilePlan& t = plan.tile;
     int vlog = 0;
     while ((1 << vlog) < V) ++vlog;
+    constexpr int variant = (WIDE ? 2 : 0) + (V > 1 ? 1 : 0);
+    const size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
+    auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
     TiledArgs<WIDE> a;
+    // the arguments depend on the plan only, except for the operand addresses: built once
+    std::vector<unsigned char>& cached = plan.tiled_args[variant];
+    if (cached.size() == sizeof a) {
+        std::memcpy(&a, cached.data(), sizeof a);
+        for (int k = 0; k < c.M; ++k) a.op[k].base = tab.base[k];
+        clear_sticky_error();
+        hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3(1u << THRLOG), lds, s, a, f);
+        return check_launch("k_tiled_map");
+    }
     std::memset(&a, 0, sizeof a);
     a.M = c.M;
     a.nt = t.nt;
     a.tilelog = t.tilelog;
     a.nstaged = t.nstaged;
-    // swizzle width: the 128 B an LDS write group spans, in elements
-    int w = 0;
-    while ((sizeof(T) << w) < 128) ++w;
-    if (t.tilelog <= w) w = 0;
     int tlogdim[MAXN] = {0};
     int lsh[MAXT];
     int sh = 0;
@@ -334,6 +417,36 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         tlogdim[t.tdim[j]] = t.tlog[j];
         sh += t.tlog[j];
     }
+    // LDS swizzle: slot width = the 128 B an LDS write group spans, in elements
+    int w = 0;
+    while ((sizeof(T) << w) < 128) ++w;
+    std::vector<LanePattern> pats;
+    if (sizeof(T) >= 4 && t.tilelog > w) {
+        const int nread = sizeof(T) == 16 ? 4 : 5;  // ds_read_b32/b64: 32 lanes, b128: 16 lanes per pass
+        for (int k = 1; k < c.M; ++k) {
+            if (t.staged[k] < 0) continue;
+            // operand k's enumeration: its bit (vlog + i) is lane bit i of the write group
+            int bitpos[32], pos = 0;
+            for (int jj = 0; jj < t.nt; ++jj) {
+                const int j = t.order[k][jj];
+                for (int bit = 0; bit < t.tlog[j]; ++bit) bitpos[pos++] = lsh[j] + bit;
+            }
+            LanePattern p;
+            p.n = w;
+            p.slotbits = w;
+            for (int i2 = 0; i2 < w; ++i2) p.bits[i2] = bitpos[vlog + i2];
+            pats.push_back(p);
+        }
+        LanePattern r;
+        r.n = nread;
+        r.slotbits = nread;
+        for (int i2 = 0; i2 < nread; ++i2) r.bits[i2] = vlog + i2;
+        pats.push_back(r);
+    }
+    int cost0 = 0, cost1 = 0;
+    const Swizzle swz = choose_swizzle(t.tilelog, w, pats, &cost0, &cost1);
+    if (std::getenv("SMR_DEBUG_SWIZZLE"))
+        std::fprintf(stderr, "[smr] tiled swizzle: w=%d V=%d patterns=%zu conflict cost fold=%d searched=%d\n", w, V, pats.size(), cost0, cost1);
     // grid dims: canonical dims with more than one tile, in canonical order
     int gof[MAXN], ng = 0;
     for (int d = 0; d < c.N; ++d) {
@@ -390,7 +503,6 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     a.base32 = base32 ? 1 : 0;
 
     // per-lane table: built once per (plan, kernel variant), kept in device memory
-    constexpr int variant = (WIDE ? 2 : 0) + (V > 1 ? 1 : 0);
     const bool build_tab = plan.lanetab[variant] == nullptr;
     std::vector<LaneRow<WIDE>> rows;
     if (build_tab) rows.assign((size_t)c.M * NT, LaneRow<WIDE>{});
@@ -419,7 +531,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             a.esh[k][j] = pos;
             for (int bit = 0; bit < t.tlog[j]; ++bit) {
                 gbit[pos + bit] = c.strides[k][t.tdim[j]] * ((i64)1 << bit) * es;
-                lbit[pos + bit] = host_swizzle(1u << (lsh[j] + bit), w);
+                lbit[pos + bit] = swz.apply(1u << (lsh[j] + bit));
             }
             pos += t.tlog[j];
         }
@@ -471,13 +583,13 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     }
     a.lanetab = reinterpret_cast<const LaneRow<WIDE>*>(plan.lanetab[variant]);
 
-    const size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
-    auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
     clear_sticky_error();
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
     }
+    cached.resize(sizeof a);
+    std::memcpy(cached.data(), &a, sizeof a);
     hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3(1u << THRLOG), lds, s, a, f);
     return check_launch("k_tiled_map");
 }

@@ -32,11 +32,19 @@ def reset():
     S.set_option("force_family", 0)
 
 
+def compositions(total, parts, lo=1, hi=5):
+    """All `parts`-tuples of log2 tile extents in [lo, hi] that sum to `total`."""
+    if parts == 1:
+        return [(total,)] if lo <= total <= hi else []
+    return [(v,) + rest for v in range(lo, hi + 1) for rest in compositions(total - v, parts - 1, lo, hi)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--sweep", type=int, default=0, help="sweep every tile shape of 2^SWEEP elements (10 or 12) on bcast4")
     args = ap.parse_args()
     n = args.n
     dt = {"f64": torch.float64, "f32": torch.float32, "c64": torch.complex64, "c128": torch.complex128}[args.dtype]
@@ -51,10 +59,10 @@ def main():
         "bcast4": (lambda a, b, c, d: a + b + c + d, (B,) + tuple(A.permutedims(q) for q in perms)),
     }
     tiles = {
-        "perm4321": [None, "tl12", (5, 1, 1, 5)],
-        "perm2341": [None, "tl12"],
+        "perm4321": [None],
+        "perm2341": [None],
         "perm3412": [None],
-        "bcast4": [None, "tl12", (3, 3, 2, 2), (3, 3, 3, 3), (4, 3, 3, 2), (4, 4, 2, 2), (4, 2, 3, 3), (4, 3, 2, 3), (5, 3, 2, 2), (4, 4, 3, 1)],
+        "bcast4": [None, "tl10", "tl12"] + (compositions(args.sweep, 4, 2 if args.sweep == 12 else 1) if args.sweep else []),
     }
     elem = tA.element_size()
     algb = 2 * elem * n ** 4
@@ -72,12 +80,14 @@ def main():
     sys.stdout.flush()
     for name, (f, arrays) in work.items():
         for tile in tiles[name]:
-            for vec in (1, 0):
+            for vec in (1,):
                 reset()
                 S.set_option("max_lds_bytes", 160 * 1024)
-                if tile == "tl12":
-                    S.set_option("tile_log2", 12)
+                if tile in ("tl10", "tl12"):
+                    S.set_option("tile_log2", int(tile[2:]))
                 elif tile is not None:
+                    if sum(tile) == 12:
+                        S.set_option("tile_log2", 12)
                     for i, v in enumerate(tile):
                         S.set_option(f"tile_lg{i}", v)
                 S.set_option("tiled_vec", vec)
