@@ -110,6 +110,9 @@ struct TilePlan {
     i64 ntiles[MAXN];    // tiles per canonical dim
     i64 grid = 1;
     size_t lds_bytes = 0;
+    // locality-aware execution order (empty = natural): workgroup b runs tile ord[b], 0xffffffff = idle
+    std::vector<uint32_t> ord;
+    int ord_groups = 0;
 };
 
 struct Plan {
@@ -126,6 +129,7 @@ struct Plan {
     int part_split = 1; // REDUCE_PART: chunks of the reduced range (two-pass when > 1)
     // TILED: per-lane index tables in device memory, one per kernel variant (built on first use)
     mutable void* lanetab[4] = {nullptr, nullptr, nullptr, nullptr};
+    mutable void* ordtab = nullptr;  // TILED: tile-order table in device memory (large grids)
     mutable std::vector<unsigned char> tiled_args[4];  // fully built kernel arguments per variant
     std::string desc;
 };
@@ -137,7 +141,7 @@ struct Options {
     i64 block_threads = 256;
     i64 stream_unroll = 4;
     i64 tiled_minrun_bytes = 64;
-    i64 xcd_swizzle = 0;
+    i64 tile_order = 1;      // orbit-major tile order for inputs that are permuted views of one buffer
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 max_lds_bytes = 65536;
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override

@@ -42,6 +42,7 @@ namespace smr {
 constexpr int MAXT = 5;
 constexpr int NG = 4;   // grid dims decoded branch-free; further ones in a (rare) loop
 constexpr int EPL = 4;  // elements per lane (tile elements / workgroup size)
+constexpr int NORD16 = 512;  // tile-order entries that fit into the kernel arguments
 
 template <bool WIDE> struct off_t_of { typedef uint32_t type; };
 template <> struct off_t_of<true> { typedef i64 type; };
@@ -65,10 +66,11 @@ struct OpDesc {
 template <bool WIDE>
 struct TiledArgs {
     // header + tile decode first: they arrive with the first batch of scalar loads
-    int32_t M, ng, tilelog, nstaged, base32, nt, pad0, pad1;
+    int32_t M, ng, tilelog, nstaged, base32, nt, ordmode, pad1;
     int32_t staged[MAXM];  // [1 + i]: LDS slot of input i or -1 ([0] unused)
     uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
     const LaneRow<WIDE>* lanetab;  // [(operand k) * T + tid], k = 0 destination
+    const uint32_t* ordtab;        // ordmode 2: tile executed by workgroup b (0xffffffff = none)
     OpDesc<WIDE> op[MAXM];         // [0] destination, [1 + i] input i
     uint32_t Lrd[EPL], Lhd[EPL];   // destination-order LDS index of repeat r / sub-element h
     i64 tstep[MAXM][MAXN];         // 64-bit tile steps (only read when !base32)
@@ -77,6 +79,7 @@ struct TiledArgs {
     int32_t esh[MAXM][MAXT];          // bit position of tiled dim j in operand k's enumeration
     i64 gdims[MAXN];
     int32_t glog[MAXN];
+    uint32_t ord16[NORD16 / 2];  // ordmode 1: the same as 16-bit entries inside the kernel arguments
 };
 
 SMR_DEV uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s) { return (__umulhi(m, n) + n) >> s; }
@@ -135,6 +138,18 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
 
     // ---- which tile ---------------------------------------------------------------------------------
     uint32_t b = blockIdx.x;
+    {
+        // locality-aware tile order (smr_plan.cpp: plan_tile_order).  The in-kernarg lookup is
+        // issued unconditionally so that it travels with the first batch of scalar loads.
+        const uint32_t pair = a.ord16[(b & (NORD16 - 1)) >> 1];
+        if (a.ordmode == 1) {
+            const uint32_t v = (b & 1u) ? (pair >> 16) : (pair & 0xffffu);
+            b = (v == 0xffffu) ? 0xffffffffu : v;
+        } else if (a.ordmode == 2) {
+            b = a.ordtab[b];
+        }
+        if (b == 0xffffffffu) return;  // padding workgroup (whole workgroup: no barrier is skipped)
+    }
     uint32_t tc[MAXN];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {  // unused grid dims are padded with ntiles = 1
@@ -394,6 +409,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     constexpr int variant = (WIDE ? 2 : 0) + (V > 1 ? 1 : 0);
     const size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
     auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
+    const unsigned grid = t.ord.empty() ? (unsigned)t.grid : (unsigned)t.ord.size();
     TiledArgs<WIDE> a;
     // the arguments depend on the plan only, except for the operand addresses: built once
     std::vector<unsigned char>& cached = plan.tiled_args[variant];
@@ -401,10 +417,31 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         std::memcpy(&a, cached.data(), sizeof a);
         for (int k = 0; k < c.M; ++k) a.op[k].base = tab.base[k];
         clear_sticky_error();
-        hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3(1u << THRLOG), lds, s, a, f);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1u << THRLOG), lds, s, a, f);
         return check_launch("k_tiled_map");
     }
     std::memset(&a, 0, sizeof a);
+    if (!t.ord.empty() && t.ord.size() <= (size_t)NORD16 && t.grid < 0xffff) {
+        a.ordmode = 1;
+        for (size_t i = 0; i < t.ord.size(); ++i) {
+            const uint32_t v = t.ord[i] == 0xffffffffu ? 0xffffu : t.ord[i];
+            a.ord16[i >> 1] |= v << (16 * (i & 1));
+        }
+    } else if (!t.ord.empty()) {
+        a.ordmode = 2;
+        if (!plan.ordtab) {
+            void* dptr = nullptr;
+            hipError_t e = hipMalloc(&dptr, t.ord.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return hip_error(e, "hipMalloc(tile order)");
+            e = hipMemcpy(dptr, t.ord.data(), t.ord.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(dptr);
+                return hip_error(e, "hipMemcpy(tile order)");
+            }
+            plan.ordtab = dptr;
+        }
+        a.ordtab = reinterpret_cast<const uint32_t*>(plan.ordtab);
+    }
     a.M = c.M;
     a.nt = t.nt;
     a.tilelog = t.tilelog;
@@ -590,7 +627,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     }
     cached.resize(sizeof a);
     std::memcpy(cached.data(), &a, sizeof a);
-    hipLaunchKernelGGL(kern, dim3((unsigned)t.grid), dim3(1u << THRLOG), lds, s, a, f);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1u << THRLOG), lds, s, a, f);
     return check_launch("k_tiled_map");
 }
 

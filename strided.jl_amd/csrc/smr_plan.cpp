@@ -12,6 +12,7 @@
 // the LDS budget and the number of workgroups.  The faithful restatement of the CPU planner
 // lives in oracle/ as test infrastructure.
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -344,6 +345,131 @@ static int fast_axis(const Canon& c, int k) {
     return -1;
 }
 
+// ---- locality-aware tile order ------------------------------------------------------------------------
+// When several inputs are differently permuted views of ONE buffer (B .= (A .+ A')./2, the 4-way
+// permuted sum), the tiles T, pi(T), pi^2(T), ... read the same regions of that buffer.  MI355X has
+// eight XCDs with private L2s and dispatches workgroup b to XCD b mod 8, so in natural tile order
+// every XCD fetches every region it touches by itself: the buffer crosses the fabric once per
+// permutation.  Here the tiles are grouped into super-tiles whose extents are invariant under the
+// permutations, the super-tiles into orbits of the permutation group, and the orbit-major list is
+// cut into eight contiguous runs, one per XCD (workgroup 8*slot + x executes entry slot of run x):
+// the members of an orbit meet in one L2 at about the same time.
+static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
+    constexpr int NX = 8;  // XCDs
+    if (t.grid < 2 * NX || t.grid > ((i64)1 << 22)) return;
+    // generators: input k reads through strides that are a permutation of input j's
+    std::vector<std::array<int, MAXN>> gens;
+    for (int j = 1; j < c.M; ++j)
+        for (int k = j + 1; k < c.M; ++k) {
+            if (c.esize[j] != c.esize[k]) continue;
+            if ((char*)c.base[j] + c.offsets[j] * c.esize[j] != (char*)c.base[k] + c.offsets[k] * c.esize[k]) continue;
+            std::array<int, MAXN> pi;
+            bool used[MAXN] = {false}, ok = true, ident = true;
+            for (int d = 0; d < c.N && ok; ++d) {
+                int hit = -1;
+                if (c.strides[j][d] == c.strides[k][d] && !used[d]) hit = d;  // prefer fixed points
+                for (int e = 0; e < c.N && hit < 0; ++e)
+                    if (!used[e] && c.strides[j][e] == c.strides[k][d] && c.dims[e] == c.dims[d]) hit = e;
+                if (hit < 0) ok = false;
+                else {
+                    used[hit] = true;
+                    pi[d] = hit;
+                    if (hit != d) ident = false;
+                }
+            }
+            if (ok && !ident) gens.push_back(pi);
+        }
+    if (gens.empty()) return;
+    // super-tile extents: equal along every cycle of every generator
+    int E[MAXN];
+    for (int d = 0; d < c.N; ++d) E[d] = lg[d];
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (const auto& pi : gens)
+            for (int d = 0; d < c.N; ++d) {
+                const int m = std::max(E[d], E[pi[d]]);
+                if (E[d] != m || E[pi[d]] != m) {
+                    E[d] = E[pi[d]] = m;
+                    changed = true;
+                }
+            }
+    }
+    i64 sg[MAXN], ns = 1;
+    for (int d = 0; d < c.N; ++d) {
+        sg[d] = (c.dims[d] + ((i64)1 << E[d]) - 1) >> E[d];
+        ns *= sg[d];
+    }
+    // orbits of super-tile coordinates (breadth first), largest orbits first
+    std::vector<char> seen((size_t)ns, 0);
+    std::vector<std::vector<uint32_t>> orbits;
+    auto decode = [&](i64 id, i64* sc) {
+        for (int d = 0; d < c.N; ++d) {
+            sc[d] = id % sg[d];
+            id /= sg[d];
+        }
+    };
+    auto encode = [&](const i64* sc) {
+        i64 id = 0;
+        for (int d = c.N - 1; d >= 0; --d) id = id * sg[d] + sc[d];
+        return id;
+    };
+    for (i64 s0 = 0; s0 < ns; ++s0) {
+        if (seen[(size_t)s0]) continue;
+        std::vector<uint32_t> orb{(uint32_t)s0};
+        seen[(size_t)s0] = 1;
+        for (size_t head = 0; head < orb.size(); ++head) {
+            i64 sc[MAXN], sp[MAXN];
+            decode(orb[head], sc);
+            for (const auto& pi : gens) {
+                // input k at box coordinate sc touches what input j touches at sp, sp[pi[d]] = sc[d]
+                for (int d = 0; d < c.N; ++d) sp[pi[d]] = sc[d];
+                const i64 id = encode(sp);
+                if (!seen[(size_t)id]) {
+                    seen[(size_t)id] = 1;
+                    orb.push_back((uint32_t)id);
+                }
+            }
+        }
+        orbits.push_back(std::move(orb));
+    }
+    std::stable_sort(orbits.begin(), orbits.end(), [](const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) { return a.size() > b.size(); });
+    // tiles of a super-tile, natural order; linear tile id as the kernel decodes it
+    i64 tmul[MAXN], acc = 1;
+    for (int d = 0; d < c.N; ++d) {
+        tmul[d] = acc;
+        acc *= t.ntiles[d];
+    }
+    std::vector<uint32_t> list;
+    list.reserve((size_t)t.grid);
+    for (const auto& orb : orbits)
+        for (uint32_t sid : orb) {
+            i64 sc[MAXN], lo[MAXN], n[MAXN], cnt = 1;
+            decode(sid, sc);
+            for (int d = 0; d < c.N; ++d) {
+                lo[d] = sc[d] << (E[d] - lg[d]);
+                n[d] = std::min<i64>((i64)1 << (E[d] - lg[d]), t.ntiles[d] - lo[d]);
+                cnt *= n[d];
+            }
+            for (i64 q = 0; q < cnt; ++q) {
+                i64 r = q, id = 0;
+                for (int d = 0; d < c.N; ++d) {
+                    id += (lo[d] + r % n[d]) * tmul[d];
+                    r /= n[d];
+                }
+                list.push_back((uint32_t)id);
+            }
+        }
+    if ((i64)list.size() != t.grid) return;  // cannot happen; keep the natural order if it does
+    const i64 cs = (t.grid + NX - 1) / NX;
+    t.ord.assign((size_t)(cs * NX), 0xffffffffu);
+    for (i64 x = 0; x < NX; ++x)
+        for (i64 slot = 0; slot < cs; ++slot) {
+            const i64 at = x * cs + slot;
+            if (at < t.grid) t.ord[(size_t)(slot * NX + x)] = list[(size_t)at];
+        }
+    t.ord_groups = (int)orbits.size();
+}
+
 static bool plan_tiles(const Canon& c, TilePlan& t) {
     if (c.redop != SMR_RED_NONE) return false;
     if (c.N < 2 || c.strides[0][0] != 1) return false;
@@ -469,6 +595,9 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     }
     t.lds_bytes = (size_t)nst * ((size_t)1 << total) * es;
     if (t.grid > 0x7fffffffLL) return false;
+    t.ord.clear();
+    t.ord_groups = 0;
+    if (o.tile_order) plan_tile_order(c, t, lg);
     return true;
 }
 
@@ -571,6 +700,7 @@ void describe(Plan& plan) {
             n += std::snprintf(buf + n, sizeof buf - n, "%sd%d:%d", j ? "," : "", plan.tile.tdim[j], 1 << plan.tile.tlog[j]);
         n += std::snprintf(buf + n, sizeof buf - n, " staged=%d lds=%zu grid=%lld threads=%d", plan.tile.nstaged,
                            plan.tile.lds_bytes, (long long)plan.tile.grid, plan.tile.threads);
+        if (!plan.tile.ord.empty()) n += std::snprintf(buf + n, sizeof buf - n, " order=orbits:%d", plan.tile.ord_groups);
     } else if (plan.family == FAM_STREAM) {
         n += std::snprintf(buf + n, sizeof buf - n, " vec=%d", plan.vec);
     } else if (plan.family == FAM_REDUCE_ALL) {
