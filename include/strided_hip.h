@@ -203,6 +203,12 @@ int smr_plan_describe(const smr_plan* plan, char* buf, size_t buflen);
 /* Algorithmic bytes of one execution: every distinct operand footprint counted once
  * (SURVEY.md section 8d).                                                                 */
 int64_t smr_plan_algorithmic_bytes(const smr_plan* plan);
+/* Introspection of the TILED family's execution order (no reference counterpart: the
+ * reference walks its blocks in loop order, src/mapreduce.jl:385-401).  Returns the number
+ * of workgroups n of the launch, or 0 when tiles run in natural order; writes
+ * min(n, cap) entries: out[b] = linear tile id executed by workgroup b, 0xffffffff = idle
+ * padding.  Workgroup b runs on XCD b mod 8.                                              */
+int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap);
 
 /* Block-partition a problem over `nshards` devices/ranks exactly like the reference's
  * task bisection splits the iteration box (src/mapreduce.jl:203-222): sub-box `shard`

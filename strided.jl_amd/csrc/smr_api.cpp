@@ -243,6 +243,14 @@ int smr_plan_describe(const smr_plan* plan, char* buf, size_t buflen) {
 
 int64_t smr_plan_algorithmic_bytes(const smr_plan* plan) { return plan ? plan->plan.c.algbytes : 0; }
 
+int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
+    if (!plan || plan->plan.family != FAM_TILED) return 0;
+    const std::vector<uint32_t>& ord = plan->plan.tile.ord;
+    if (out)
+        for (size_t i = 0; i < ord.size() && i < cap; ++i) out[i] = ord[i];
+    return (int64_t)ord.size();
+}
+
 int smr_mapreduce(const smr_problem* problem) {
     if (!problem) return set_error(SMR_EINVAL, "null problem");
     if (problem->N < 1 || problem->N > SMR_MAXN || problem->M < 1 || problem->M > SMR_MAXM)

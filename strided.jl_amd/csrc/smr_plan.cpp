@@ -381,6 +381,7 @@ static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
         }
     if (gens.empty()) return;
     // super-tile extents: equal along every cycle of every generator
+    // (measured: widening the super-tiles to a full 128-B line along every permuted dim does not help)
     int E[MAXN];
     for (int d = 0; d < c.N; ++d) E[d] = lg[d];
     for (bool changed = true; changed;) {
@@ -441,7 +442,9 @@ static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
     }
     std::vector<uint32_t> list;
     list.reserve((size_t)t.grid);
-    for (const auto& orb : orbits)
+    const bool interleave = false;  // members of an orbit one after the other (interleaving them measured the same)
+    for (const auto& orb : orbits) {
+        std::vector<std::vector<uint32_t>> per;  // tiles of each member super-tile
         for (uint32_t sid : orb) {
             i64 sc[MAXN], lo[MAXN], n[MAXN], cnt = 1;
             decode(sid, sc);
@@ -450,15 +453,26 @@ static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
                 n[d] = std::min<i64>((i64)1 << (E[d] - lg[d]), t.ntiles[d] - lo[d]);
                 cnt *= n[d];
             }
+            per.emplace_back();
             for (i64 q = 0; q < cnt; ++q) {
                 i64 r = q, id = 0;
                 for (int d = 0; d < c.N; ++d) {
                     id += (lo[d] + r % n[d]) * tmul[d];
                     r /= n[d];
                 }
-                list.push_back((uint32_t)id);
+                per.back().push_back((uint32_t)id);
             }
         }
+        if (!interleave) {
+            for (const auto& v : per) list.insert(list.end(), v.begin(), v.end());
+        } else {
+            size_t mx = 0;
+            for (const auto& v : per) mx = std::max(mx, v.size());
+            for (size_t q = 0; q < mx; ++q)
+                for (const auto& v : per)
+                    if (q < v.size()) list.push_back(v[q]);
+        }
+    }
     if ((i64)list.size() != t.grid) return;  // cannot happen; keep the natural order if it does
     const i64 cs = (t.grid + NX - 1) / NX;
     t.ord.assign((size_t)(cs * NX), 0xffffffffu);
@@ -586,7 +600,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
         for (int j = 0; j < t.nt; ++j) t.order[k][j] = idx[j];
     }
     for (int j = 0; j < t.nt; ++j) t.order[0][j] = j;
-    t.threads = (total == 12) ? 1024 : 256;
+    t.threads = (total == 12) ? 1024 : 256;  // (2048 elements on 512 lanes measured: never the best)
     t.grid = 1;
     for (int i = 0; i < c.N; ++i) {
         i64 e = (i64)1 << lg[i];

@@ -24,7 +24,7 @@ def _declared_functions():
 def test_library_exports_every_declared_symbol():
     lib = L.load()
     names = _declared_functions()
-    assert len(names) >= 19
+    assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/strided_hip.h but not exported"
     assert sorted(L.EXPORTS) == names
@@ -61,6 +61,59 @@ def test_planning_needs_no_device_and_picks_the_expected_family():
     # the four appearances of A in the README's compute-bound expression are deduplicated
     d = S.make_plan(lambda a, b, c, e: a * S.fn.exp(-2 * b) + S.fn.sin(c * e), None, None, x.size, (y, x, x, x, x)).describe()
     assert "M=2" in d and "f=expr5" in d
+
+
+def _sym_plan(m, dtype=np.float64):
+    a = S.StridedView(np.zeros((m, m), dtype=dtype, order="F"))
+    b = a.similar()
+    return S.make_plan(lambda x, y: (x + y) / 2, None, None, a.size, (b, a, a.permutedims((1, 0))))
+
+
+@pytest.mark.parametrize("m", [200, 1000, 4000])
+def test_tile_order_is_a_permutation_that_keeps_transposed_partners_on_one_xcd(m):
+    """B .= (A .+ A')./2: tile (i, j) and tile (j, i) read the same two regions of A; the planner
+    must run them back to back on one XCD (workgroup b -> XCD b mod 8) and every tile once."""
+    plan = _sym_plan(m)
+    d = plan.describe()
+    assert "order=orbits:" in d
+    nt = -(-m // 32)
+    assert f"grid={nt * nt} " in d
+    ord_ = np.array(plan.tile_order(), dtype=np.int64)
+    assert len(ord_) % 8 == 0 and len(ord_) - nt * nt < 8
+    real = ord_[ord_ != 0xFFFFFFFF]
+    assert sorted(real.tolist()) == list(range(nt * nt))          # every tile exactly once
+    assert int(plan.describe().split("order=orbits:")[1].split()[0]) == nt * (nt + 1) // 2
+    where = np.full(nt * nt, -1, dtype=np.int64)
+    where[real] = np.nonzero(ord_ != 0xFFFFFFFF)[0]
+    i, j = np.meshgrid(np.arange(nt), np.arange(nt), indexing="ij")
+    t, tt = (i + nt * j).ravel(), (j + nt * i).ravel()
+    off = t != tt
+    same_xcd = (where[t[off]] % 8) == (where[tt[off]] % 8)
+    adjacent = np.abs(where[t[off]] // 8 - where[tt[off]] // 8) == 1
+    # only pairs cut by one of the 7 run boundaries may be separated
+    assert (~(same_xcd & adjacent)).sum() <= 2 * 7
+
+
+def test_tile_order_four_way_permuted_sum_and_opt_out():
+    x = S.StridedView(np.zeros((32, 32, 32, 32), order="F"))
+    y = x.similar()
+    ps = [x.permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]
+    plan = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps))
+    assert "order=orbits:6" in plan.describe()  # necklaces of {0,1}^4: 16^4 super-tiles of a 32^4 box
+    ord_ = plan.tile_order()
+    assert sorted(ord_) == list(range(256))
+    # a plain permutedims! has one input: nothing to co-locate, natural order
+    plan = S.make_plan(lambda v: v, None, None, x.size, (y, x.permutedims((3, 2, 1, 0))))
+    assert plan.tile_order() == [] and "order=" not in plan.describe()
+    # distinct buffers with permuted strides are not aliases
+    z = x.similar()
+    plan = S.make_plan(lambda a, b: a + b, None, None, x.size, (y, x.permutedims((1, 2, 3, 0)), z.permutedims((2, 3, 0, 1))))
+    assert plan.tile_order() == []
+    S.set_option("tile_order", 0)
+    try:
+        assert _sym_plan(1000).tile_order() == []
+    finally:
+        S.set_option("tile_order", 1)
 
 
 def test_invalid_problems_return_einval():

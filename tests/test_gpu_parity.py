@@ -105,6 +105,45 @@ def test_arithmetic_maps_are_bit_identical_to_the_oracle(monkeypatch):
                     assert np.array_equal(g, w), f"{np.dtype(T).name} N={N} step {i}"
 
 
+@pytest.mark.parametrize("T", [np.float32, np.float64, np.complex128])
+@pytest.mark.parametrize("shape", [(200, 200), (1000, 1000), (20, 20, 20, 20), (48, 16, 48, 16), (33, 65, 33)])
+def test_aliased_permuted_inputs_with_orbit_tile_order(shape, T):
+    """Inputs that are permuted views of ONE buffer take the orbit-major tile order (in-kernarg
+    table for small grids, device table for big ones, ragged edge tiles, padding workgroups):
+    results must equal NumPy bit for bit, with the option on and off."""
+    import torch
+    rng = np.random.default_rng(11)
+    a = cases._rand(rng, shape, T)
+    N = len(shape)
+    if N == 2:
+        perms = [(0, 1), (1, 0)]
+    elif N == 3:
+        perms = [(0, 1, 2), (2, 1, 0)]
+    else:
+        perms = [(0, 1, 2, 3), (2, 1, 0, 3), (0, 3, 2, 1), (2, 3, 0, 1)]
+    want = a.transpose(perms[0]).copy()
+    for q in perms[1:]:
+        want = want + a.transpose(q)
+    for order in (1, 0):
+        S.set_option("tile_order", order)
+        try:
+            A = dview(a)
+            B = A.similar()
+            views = [A.permutedims(q) for q in perms]
+            e = views[0]
+            for v in views[1:]:
+                e = e + v
+            B.assign(e)
+            plan = S.make_plan((lambda *xs: sum(xs[1:], xs[0])), None, None, B.size, (B, *views))
+            d = plan.describe()
+            assert "family=tiled" in d
+            assert ("order=orbits" in d) == (order == 1 and bool(plan.tile_order()))
+            torch.cuda.synchronize()
+            assert np.array_equal(B.toarray(), want), f"{shape} {np.dtype(T).name} tile_order={order}: {d}"
+        finally:
+            S.set_option("tile_order", 1)
+
+
 def test_every_kernel_family_is_exercised():
     """Plans for representative problems pick the intended family (guards against a silent
     fallback to the generic kernel)."""

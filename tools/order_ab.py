@@ -40,14 +40,16 @@ def main():
         A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
         rows.append((f"sym {m}^2 f64", lambda x, y: (x + y) / 2, (B, A, A.permutedims((1, 0))), 16 * m * m, reps))
     for name, f, arrays, algb, reps in rows:
-        for order in (0, 1):
+        for order, tl in ((0, 0), (1, 0)):
             S.set_option("tile_order", order)
+            S.set_option("tile_log2", tl)
             plan = S.make_plan(f, None, None, arrays[0].size, arrays)
             us = time_plan(plan, reps)
             d = plan.describe()
-            print(f"{name:18s} tile_order={order} {us:10.2f} us {algb / us / 1e3:8.1f} GB/s | {d[d.find('tile='):d.find(' algbytes')]}")
+            print(f"{name:18s} tile_order={order} tl={tl:2d} {us:10.2f} us {algb / us / 1e3:8.1f} GB/s | {d[d.find('tile='):d.find(' algbytes')]}")
             sys.stdout.flush()
     S.set_option("tile_order", 1)
+    S.set_option("tile_log2", 0)
 
 
 if __name__ == "__main__":
