@@ -354,6 +354,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "block_threads") o.block_threads = value;
     else if (n == "stream_unroll") o.stream_unroll = value;
     else if (n == "tile_order") o.tile_order = value;
+    else if (n == "reduce_blocks") o.reduce_blocks = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
     else if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') o.tile_lg[n[7] - '0'] = value;
@@ -375,6 +376,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "block_threads") return o.block_threads;
     if (n == "stream_unroll") return o.stream_unroll;
     if (n == "tile_order") return o.tile_order;
+    if (n == "reduce_blocks") return o.reduce_blocks;
     if (n == "tiled_vec") return o.tiled_vec;
     if (n == "max_lds_bytes") return o.max_lds_bytes;
     if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') return o.tile_lg[n[7] - '0'];

@@ -142,6 +142,7 @@ struct Options {
     i64 stream_unroll = 4;
     i64 tiled_minrun_bytes = 64;
     i64 tile_order = 1;      // orbit-major tile order for inputs that are permuted views of one buffer
+    i64 reduce_blocks = 2048;  // cap on the workgroups (= partials) of a complete reduction
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 max_lds_bytes = 65536;
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override

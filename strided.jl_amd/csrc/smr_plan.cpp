@@ -662,7 +662,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
         if (fam == FAM_REDUCE_ALL) {
             i64 per_block = 256 * 16;
             i64 nb = (c.total + per_block - 1) / per_block;
-            nb = std::max<i64>(1, std::min<i64>(nb, 2048));
+            nb = std::max<i64>(1, std::min<i64>(nb, std::max<i64>(1, o.reduce_blocks)));
             plan.red_blocks = (int)nb;
             plan.scratch_bytes = (size_t)nb * es;
         } else {
