@@ -287,6 +287,29 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
     p = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (B,) + tuple(A.permutedims(q) for q in perms))
     rec("broadcast4_128^4_f64", p, timed(p, 5))
     del tA, tB
+    # "cold" variant of the headline kernels: rotate through 40 distinct (A, B) pairs =
+    # 640 MiB > the 256 MiB Infinity Cache, so every launch really reads HBM
+    n, npair = 32, 40
+    poolA = torch.randn(npair, n ** 4, dtype=torch.float64, device=dev)
+    poolB = torch.empty_like(poolA)
+    A, B = colmajor_view(S, poolA[0], (n,) * 4), colmajor_view(S, poolB[0], (n,) * 4)
+    esz = poolA.element_size() * n ** 4
+    for name, f, srcs in (("permutedims_32^4_f64_cold", lambda x: x, (A.permutedims((3, 2, 1, 0)),)),
+                          ("broadcast4_32^4_f64_cold", lambda a, b, c, d: a + b + c + d, tuple(A.permutedims(q) for q in perms))):
+        p = S.make_plan(f, None, None, A.size, (B,) + srcs)
+        p.execute(cur())
+        state = {"i": 0}
+
+        def rot():
+            i = state["i"] % npair
+            state["i"] += 1
+            p.execute(cur(), bases=[poolB.data_ptr() + i * esz] + [poolA.data_ptr() + i * esz] * len(srcs))
+
+        g = graph_of(torch, rot, 4 * npair)
+        g.replay()
+        torch.cuda.synchronize()
+        rec(name, p, min(event_time_ms(torch, g.replay, 2) for _ in range(3)) / (4 * npair))
+    del poolA, poolB
     # C5 compute-bound map 8192^2 f32
     m = 8192
     tA = torch.rand(m * m, dtype=torch.float32, device=dev)

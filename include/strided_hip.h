@@ -190,6 +190,11 @@ int smr_stream_sync(void* stream);
 /* One-shot replacement of _mapreduce_fuse! (src/mapreduce.jl:98): canonicalise, pick the
  * kernel family, launch on problem->stream.  Plans are cached per problem signature.    */
 int smr_mapreduce(const smr_problem* problem);
+/* Complete reduction returning its value to the host: runs `problem` (whose destination is
+ * ONE device element: every destination stride 0 or dim 1), waits for problem->stream and
+ * copies the destination element (its own dtype) to host_result.  The synchronous tail of
+ * `_mapreduce` (src/mapreduce.jl:70-71: `return out[ParentIndex(1)]`).                    */
+int smr_mapreduce_scalar(const smr_problem* problem, void* host_result);
 
 /* Planned form (the planner is the analogue of _mapreduce_order!/_mapreduce_block!/
  * _computeblocks, src/mapreduce.jl:119-180,452-500, evaluated once and reused).          */

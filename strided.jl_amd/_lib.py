@@ -73,7 +73,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_shard", "smr_set_option",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_mapreduce_scalar", "smr_shard", "smr_set_option",
     "smr_get_option",
 ]
 
@@ -131,6 +131,7 @@ def load():
     lib.smr_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.smr_plan_algorithmic_bytes.argtypes = [C.c_void_p]
     lib.smr_plan_algorithmic_bytes.restype = C.c_int64
+    lib.smr_mapreduce_scalar.argtypes = [C.c_void_p, C.c_void_p]
     lib.smr_plan_tile_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t]
     lib.smr_plan_tile_order.restype = C.c_int64
     lib.smr_shard.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.POINTER(smr_problem),

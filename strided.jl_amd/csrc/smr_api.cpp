@@ -243,6 +243,23 @@ int smr_plan_describe(const smr_plan* plan, char* buf, size_t buflen) {
 
 int64_t smr_plan_algorithmic_bytes(const smr_plan* plan) { return plan ? plan->plan.c.algbytes : 0; }
 
+int smr_mapreduce_scalar(const smr_problem* problem, void* host_result) {
+    if (!problem || !host_result) return set_error(SMR_EINVAL, "null argument");
+    if (problem->N < 1 || problem->N > SMR_MAXN) return set_error(SMR_EINVAL, "rank out of range");
+    for (int i = 0; i < problem->N; ++i)
+        if (problem->dims[i] != 1 && problem->ops[0].strides[i] != 0)
+            return set_error(SMR_EINVAL, "smr_mapreduce_scalar: the destination must be a single element");
+    int rc = smr_mapreduce(problem);
+    if (rc) return rc;
+    const smr_operand& d = problem->ops[0];
+    const size_t es = (size_t)dtype_size(d.dtype);
+    hipError_t e = hipMemcpyAsync(host_result, (const char*)d.base + d.offset * (int64_t)es, es, hipMemcpyDeviceToHost,
+                                  (hipStream_t)problem->stream);
+    if (e != hipSuccess) return hip_error(e, "hipMemcpyAsync(scalar result)");
+    e = hipStreamSynchronize((hipStream_t)problem->stream);
+    return e == hipSuccess ? SMR_OK : hip_error(e, "hipStreamSynchronize");
+}
+
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
     if (!plan || plan->plan.family != FAM_TILED) return 0;
     const std::vector<uint32_t>& ord = plan->plan.tile.ord;

@@ -144,6 +144,27 @@ def test_aliased_permuted_inputs_with_orbit_tile_order(shape, T):
             S.set_option("tile_order", 1)
 
 
+def test_mapreduce_scalar_returns_the_complete_reduction_to_the_host():
+    """smr_mapreduce_scalar = the synchronous tail of `_mapreduce` (src/mapreduce.jl:70-71)."""
+    import ctypes as C
+    from strided_jl_amd import _lib as L
+    rng = np.random.default_rng(3)
+    a = cases._rand(rng, (37, 41, 13), np.float64)
+    A = dview(a).permutedims((2, 0, 1))
+    out = A.similar(np.float64, (1,))
+    S.copyto_(out, 0.0)
+    p, keep = S.build_problem(S.fn.abs2, "+", None, A.size, S.promoteshape(A.size, out.sreshape((1, 1, 1)), A),
+                              stream=0)
+    host = C.c_double(-1.0)
+    L.check(L.load().smr_mapreduce_scalar(C.byref(p), C.byref(host)))
+    assert abs(host.value - float((a * a).sum())) <= 1e-12 * float((a * a).sum())
+    assert out.item() == host.value
+    # a destination with more than one element is refused
+    big = A.similar()
+    p, keep = S.build_problem(S.fn.abs2, "+", None, A.size, (big, A), stream=0)
+    assert L.load().smr_mapreduce_scalar(C.byref(p), C.byref(host)) == L.SMR_EINVAL
+
+
 def test_every_kernel_family_is_exercised():
     """Plans for representative problems pick the intended family (guards against a silent
     fallback to the generic kernel)."""
