@@ -215,6 +215,17 @@ int64_t smr_plan_algorithmic_bytes(const smr_plan* plan);
  * padding.  Workgroup b runs on XCD b mod 8.                                              */
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap);
 
+/* Runtime compilation.  An `f` without a natively compiled functor is specialised the way
+ * Julia specialises the reference's @generated kernel per closure (src/mapreduce.jl:229-425):
+ * the f-program is turned into a C++ functor and the plan's kernel is compiled for it with
+ * hiprtc on first execution (cached per process; option "jit" = 0 keeps the bytecode
+ * interpreter, which is also the fallback when hiprtc is unavailable).
+ * smr_plan_jit_compile: generate + compile now, without a device (warms the compiler cache;
+ * *code_size = bytes of the code object, 0 when the plan's kernel needs no compilation).
+ * smr_plan_jit_source: the generated functor as text.                                     */
+int smr_plan_jit_compile(smr_plan* plan, size_t* code_size);
+int smr_plan_jit_source(const smr_plan* plan, char* buf, size_t buflen);
+
 /* Block-partition a problem over `nshards` devices/ranks exactly like the reference's
  * task bisection splits the iteration box (src/mapreduce.jl:203-222): sub-box `shard`
  * gets its dims and per-operand offsets in *out.  Pure host arithmetic.  For reductions

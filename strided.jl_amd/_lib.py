@@ -73,7 +73,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_mapreduce_scalar", "smr_shard", "smr_set_option",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_shard", "smr_set_option",
     "smr_get_option",
 ]
 
@@ -131,6 +131,8 @@ def load():
     lib.smr_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.smr_plan_algorithmic_bytes.argtypes = [C.c_void_p]
     lib.smr_plan_algorithmic_bytes.restype = C.c_int64
+    lib.smr_plan_jit_compile.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.smr_plan_jit_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.smr_mapreduce_scalar.argtypes = [C.c_void_p, C.c_void_p]
     lib.smr_plan_tile_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t]
     lib.smr_plan_tile_order.restype = C.c_int64
@@ -180,6 +182,18 @@ class Plan:
     def describe(self) -> str:
         buf = C.create_string_buffer(1024)
         check(self._lib.smr_plan_describe(self._h, buf, 1024))
+        return buf.value.decode()
+
+    def jit_compile(self) -> int:
+        """Compile the plan's kernel for its f-program now (no device needed); returns the size of
+        the code object, 0 when the kernel is one of the precompiled ones."""
+        n = C.c_size_t(0)
+        check(self._lib.smr_plan_jit_compile(self._h, C.byref(n)))
+        return int(n.value)
+
+    def jit_source(self) -> str:
+        buf = C.create_string_buffer(16384)
+        check(self._lib.smr_plan_jit_source(self._h, buf, 16384))
         return buf.value.decode()
 
     def tile_order(self):

@@ -260,6 +260,26 @@ int smr_mapreduce_scalar(const smr_problem* problem, void* host_result) {
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipStreamSynchronize");
 }
 
+int smr_plan_jit_compile(smr_plan* plan, size_t* code_size) {
+    if (!plan) return set_error(SMR_EINVAL, "null plan");
+    if (code_size) *code_size = 0;
+    if (plan->plan.c.bitcopy) return SMR_OK;
+    jit_set_dry_run(true);
+    const int rc = execute(plan->plan, nullptr, nullptr);
+    const size_t n = jit_dry_code_size();
+    jit_set_dry_run(false);
+    if (rc == SMR_OK && code_size) *code_size = n;
+    return rc;
+}
+
+int smr_plan_jit_source(const smr_plan* plan, char* buf, size_t buflen) {
+    if (!plan || !buf || buflen == 0) return set_error(SMR_EINVAL, "null argument");
+    static const char* names[] = {"float", "double", "smr::c32", "smr::c64"};
+    const Canon& c = plan->plan.c;
+    std::snprintf(buf, buflen, "%s", jit_functor_source(c, names[c.ct & 3]).c_str());
+    return SMR_OK;
+}
+
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
     if (!plan || plan->plan.family != FAM_TILED) return 0;
     const std::vector<uint32_t>& ord = plan->plan.tile.ord;
@@ -372,6 +392,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "stream_unroll") o.stream_unroll = value;
     else if (n == "tile_order") o.tile_order = value;
     else if (n == "reduce_blocks") o.reduce_blocks = value;
+    else if (n == "jit") o.jit = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
     else if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') o.tile_lg[n[7] - '0'] = value;
@@ -394,6 +415,11 @@ int64_t smr_get_option(const char* name) {
     if (n == "stream_unroll") return o.stream_unroll;
     if (n == "tile_order") return o.tile_order;
     if (n == "reduce_blocks") return o.reduce_blocks;
+    if (n == "jit") return o.jit;
+    if (n == "jit_compiles") return jit_stats().compiles;
+    if (n == "jit_hits") return jit_stats().hits;
+    if (n == "jit_failures") return jit_stats().failures;
+    if (n == "jit_compile_ms") return (int64_t)jit_stats().compile_ms;
     if (n == "tiled_vec") return o.tiled_vec;
     if (n == "max_lds_bytes") return o.max_lds_bytes;
     if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') return o.tile_lg[n[7] - '0'];

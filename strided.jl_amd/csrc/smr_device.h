@@ -6,7 +6,9 @@
 // the map results must match the reference bit-for-bit for + - * / (SURVEY section 7).
 #pragma once
 
+#ifndef SMR_JIT
 #include <hip/hip_runtime.h>
+#endif
 
 #include "smr_internal.h"
 

@@ -6,8 +6,10 @@
 // launch_<family>_ct<CT>.
 #pragma once
 
+#ifndef SMR_JIT
 #include <algorithm>
 #include <cstring>
+#endif
 
 #include "smr_device.h"
 
@@ -19,11 +21,42 @@ template <> struct ct_type<SMR_F64> { typedef double type; };
 template <> struct ct_type<SMR_C32> { typedef c32 type; };
 template <> struct ct_type<SMR_C64> { typedef c64 type; };
 
+#ifndef SMR_JIT
 template <class T> inline T hostmk(double re, double im);
 template <> inline float hostmk<float>(double re, double) { return (float)re; }
 template <> inline double hostmk<double>(double re, double) { return re; }
 template <> inline c32 hostmk<c32>(double re, double im) { return c32{(float)re, (float)im}; }
 template <> inline c64 hostmk<c64>(double re, double im) { return c64{re, im}; }
+
+// Host-side stand-in for the functor that smr_jit.cpp generates from the f-program: selects the
+// jit_launch() path inside the launchers (no device code is instantiated for it).
+template <class T> struct FJitTag {
+    static constexpr int NIN = -1;
+};
+template <class F> struct is_jit {
+    static constexpr bool value = false;
+};
+template <class T> struct is_jit<FJitTag<T>> {
+    static constexpr bool value = true;
+};
+template <class T> inline const char* tname();
+template <> inline const char* tname<float>() { return "float"; }
+template <> inline const char* tname<double>() { return "double"; }
+template <> inline const char* tname<c32>() { return "smr::c32"; }
+template <> inline const char* tname<c64>() { return "smr::c64"; }
+template <> inline const char* tname<b8>() { return "smr::b8"; }
+template <> inline const char* tname<b16>() { return "smr::b16"; }
+
+// f-programs without a native functor: runtime-compiled when possible, interpreted otherwise
+template <class T, class Fn>
+int with_prog(const Canon& c, Fn&& fn) {
+    if (options().jit) {
+        const int rc = fn(FJitTag<T>{});
+        if (rc != SMR_JIT_UNAVAILABLE) return rc;
+        if (jit_dry_run()) return set_error(SMR_EUNSUPPORTED, "runtime compilation is unavailable (hiprtc missing or the generated source failed to compile)");
+    }
+    return fn(FProg<T>{c.prog});
+}
 
 constexpr unsigned fbit(int k) { return 1u << k; }
 constexpr unsigned FMASK_ALL = 0xffffffffu;
@@ -49,7 +82,7 @@ int with_functor(const Canon& c, unsigned mask, Fn&& fn) {
             break;
         default: break;
     }
-    return fn(FProg<T>{c.prog});
+    return with_prog<T>(c, fn);
 }
 
 // Per-type launch entry points (explicitly specialised in the -DSMR_CT objects).
@@ -84,5 +117,7 @@ inline int check_launch(const char* what) {
     if (e != hipSuccess) return hip_error(e, what);
     return SMR_OK;
 }
+
+#endif  // !SMR_JIT
 
 }  // namespace smr

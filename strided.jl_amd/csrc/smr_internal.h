@@ -2,13 +2,20 @@
 // launchers of libstrided_hip.so.  Not part of the public ABI (that is include/strided_hip.h).
 #pragma once
 
+// The top part (types, ProgD, enums) is also compiled by hiprtc (SMR_JIT, see smr_jit.cpp): device
+// code only there, everything host-side sits behind #ifndef SMR_JIT.
+#ifndef SMR_JIT
 #include <hip/hip_runtime.h>
 
-#include <cstdint>
 #include <string>
 #include <vector>
 
 #include "../../include/strided_hip.h"
+#else
+#include "strided_hip.h"
+#endif
+
+#include <cstdint>
 
 namespace smr {
 
@@ -18,8 +25,10 @@ constexpr int MAXM = SMR_MAXM;
 constexpr int MAXIN = SMR_MAXM - 1;
 constexpr int STACK = 8;  // device evaluator stack depth (register-rotated)
 
+#ifndef SMR_JIT
 int set_error(int code, const std::string& msg);  // returns code
 int hip_error(hipError_t e, const char* what);
+#endif
 
 inline int dtype_size(int dt) {
     switch (dt) {
@@ -70,6 +79,7 @@ enum Family : int {
     FAM_REDUCE_PART = 5
 };
 
+#ifndef SMR_JIT
 // Canonical problem: size-1 dims dropped, dims sorted (kept dims by destination stride,
 // then reduced dims), destination strides made positive, jointly contiguous dims fused,
 // identical inputs deduplicated.  GPU analogue of _mapreduce_fuse! + _mapreduce_order!
@@ -142,6 +152,7 @@ struct Options {
     i64 stream_unroll = 4;
     i64 tiled_minrun_bytes = 64;
     i64 tile_order = 1;      // orbit-major tile order for inputs that are permuted views of one buffer
+    i64 jit = 1;             // compile unrecognised f-programs with hiprtc (0 = always interpret)
     i64 reduce_blocks = 2048;  // cap on the workgroups (= partials) of a complete reduction
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 max_lds_bytes = 65536;
@@ -153,11 +164,43 @@ int canonicalise(const smr_problem* p, Canon& c);
 int make_plan(const smr_problem* p, Plan& plan);
 void describe(Plan& plan);
 
+// ---- runtime compilation of f-programs without a natively compiled functor (smr_jit.cpp) ------------
+// The kernel family's own source file is compiled by hiprtc with the f-program turned into a
+// C++ functor (straight-line code over the same mathx<T> primitives the interpreter calls, so
+// results are bit-identical) and ONE extern "C" kernel instantiating the family's body template
+// for exactly the variant the launcher picked.  Modules are cached per (source, device).
+constexpr int SMR_JIT_UNAVAILABLE = 1000;  // internal status: fall back to the interpreter
+struct JitLaunch {
+    const char* family;  // "generic" | "stream" | "tiled" | "reduce": source file smr_k_<family>.hip
+    const char* tname;   // compute type as spelled in device code
+    std::string entry;   // body of the extern "C" kernel: a call of the family's body template
+    const char* argtype; // type of the single kernel argument `a`
+    unsigned grid = 1, block = 256;
+    size_t lds = 0;
+    const void* args = nullptr;
+    size_t argsize = 0;
+};
+int jit_launch(const Canon& c, const JitLaunch& l, hipStream_t s);
+// Generates + compiles without loading or launching (no device needed): plan-time check and tests.
+int jit_compile_only(const Canon& c, const JitLaunch& l, size_t* code_size);
+std::string jit_functor_source(const Canon& c, const char* tname);
+// dry run (thread-local): jit_launch() compiles only; launchers skip device allocations
+bool jit_dry_run();
+void jit_set_dry_run(bool on);
+size_t jit_dry_code_size();
+struct JitStats {
+    long compiles = 0, hits = 0, failures = 0;
+    double compile_ms = 0;
+};
+JitStats jit_stats();
+
 // launchers (one per kernel TU)
 int launch_generic_map(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_stream_map(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_tiled_map(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_reduce_all(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s);
+
+#endif  // !SMR_JIT
 
 }  // namespace smr

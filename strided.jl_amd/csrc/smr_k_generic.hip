@@ -20,7 +20,7 @@ struct GenArgs {
 };
 
 template <class T, class F, bool MIXED>
-__global__ void __launch_bounds__(256) k_generic_map(GenArgs a, F f) {
+SMR_DEV void generic_map_body(const GenArgs& a, F f) {
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     const i64 step = (i64)gridDim.x * 256;
     const bool small = a.total <= 0x7fffffffLL;
@@ -66,6 +66,12 @@ __global__ void __launch_bounds__(256) k_generic_map(GenArgs a, F f) {
     }
 }
 
+#ifndef SMR_JIT
+template <class T, class F, bool MIXED>
+__global__ void __launch_bounds__(256) k_generic_map(GenArgs a, F f) {
+    generic_map_body<T, F, MIXED>(a, f);
+}
+
 template <class T, class F, bool MIXED>
 static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     const Canon& c = plan.c;
@@ -79,9 +85,23 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M) ? c.strides[k][i] : 0;
     i64 blocks = (c.total + 255) / 256;
     blocks = std::min<i64>(blocks, 256 * 32);
-    clear_sticky_error();
-    hipLaunchKernelGGL((k_generic_map<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
-    return check_launch("k_generic_map");
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "generic";
+        l.tname = tname<T>();
+        l.argtype = "smr::GenArgs";
+        l.entry = std::string("smr::generic_map_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ">(a, smr::FJit{});";
+        l.grid = (unsigned)blocks;
+        l.block = 256;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(c, l, s);
+    } else {
+        if (jit_dry_run()) return SMR_OK;
+        clear_sticky_error();
+        hipLaunchKernelGGL((k_generic_map<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        return check_launch("k_generic_map");
+    }
 }
 
 template <>
@@ -102,8 +122,9 @@ int launch_generic_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStrea
         return set_error(SMR_EINVAL, "bitcopy is dispatched through the f32 object");
 #endif
     }
-    if (c.mixed) return go<T, FProg<T>, true>(plan, bases, s, FProg<T>{c.prog});
+    if (c.mixed) return with_prog<T>(c, [&](auto f) { return go<T, decltype(f), true>(plan, bases, s, f); });
     return with_functor<T>(c, fbit(FK_IDENT), [&](auto f) { return go<T, decltype(f), false>(plan, bases, s, f); });
 }
+#endif  // !SMR_JIT
 
 }  // namespace smr

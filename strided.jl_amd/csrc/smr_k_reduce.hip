@@ -37,8 +37,8 @@ SMR_DEV T neutral(int op) {
     typedef typename tr<T>::real R;
     switch (op) {
         case SMR_RED_MUL: return mk<T>(R(1), R(0));
-        case SMR_RED_MIN: return mk<T>(R(INFINITY), R(0));
-        case SMR_RED_MAX: return mk<T>(R(-INFINITY), R(0));
+        case SMR_RED_MIN: return mk<T>(R(__builtin_huge_val()), R(0));
+        case SMR_RED_MAX: return mk<T>(R(-__builtin_huge_val()), R(0));
     }
     return mk<T>(R(0), R(0));
 }
@@ -86,7 +86,7 @@ struct alignas(sizeof(T) * V) RVec {
 };
 
 template <class T, class F, bool MIXED, int V>
-__global__ void __launch_bounds__(256) k_reduce_all(RedArgs a, F f) {
+SMR_DEV void reduce_all_body(const RedArgs& a, F f) {
     __shared__ T wsum[4];
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     constexpr int ACC = 4;
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) k_reduce_final(RedArgs a) {
 // are consecutive threads, so when the inputs' unit-stride axis is a reduced dim the loads
 // coalesce; with TR == 1 consecutive threads own consecutive destination elements instead.
 template <class T, class F, bool MIXED>
-__global__ void __launch_bounds__(256) k_reduce_part(RedArgs a, F f) {
+SMR_DEV void reduce_part_body(const RedArgs& a, F f) {
     __shared__ T xbuf[256];
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     const int tr_ = a.tr;
@@ -286,7 +286,39 @@ __global__ void __launch_bounds__(256) k_reduce_part_final(RedArgs a) {
                        red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3])));
 }
 
+#ifndef SMR_JIT
+template <class T, class F, bool MIXED, int V>
+__global__ void __launch_bounds__(256) k_reduce_all(RedArgs a, F f) {
+    reduce_all_body<T, F, MIXED, V>(a, f);
+}
+template <class T, class F, bool MIXED>
+__global__ void __launch_bounds__(256) k_reduce_part(RedArgs a, F f) {
+    reduce_part_body<T, F, MIXED>(a, f);
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------
+template <class T, class F, bool MIXED, int V>
+static int launch_all(const Canon& c, const RedArgs& a, int blocks, hipStream_t s, F f) {
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "reduce";
+        l.tname = tname<T>();
+        l.argtype = "smr::RedArgs";
+        l.entry = std::string("smr::reduce_all_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ", " +
+                  std::to_string(V) + ">(a, smr::FJit{});";
+        l.grid = (unsigned)blocks;
+        l.block = 256;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(c, l, s);
+    } else {
+        if (jit_dry_run()) return SMR_OK;
+        clear_sticky_error();
+        hipLaunchKernelGGL((k_reduce_all<T, F, MIXED, V>), dim3(blocks), dim3(256), 0, s, a, f);
+        return check_launch("k_reduce_all");
+    }
+}
+
 static void fill_args(const Plan& plan, void* const* bases, RedArgs& a) {
     const Canon& c = plan.c;
     std::memset(&a, 0, sizeof a);
@@ -324,14 +356,17 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         if (c.strides[k][0] != 1) vec = false;
         if (((uintptr_t)a.ops.base[k]) % 16) vec = false;
     }
+    int rc = SMR_OK;
+    bool done = false;
     if constexpr (!MIXED && VMAX > 1) {
-        clear_sticky_error();
-        if (vec) hipLaunchKernelGGL((k_reduce_all<T, F, false, VMAX>), dim3(blocks), dim3(256), 0, s, a, f);
+        if (vec) {
+            rc = launch_all<T, F, false, VMAX>(c, a, blocks, s, f);
+            done = true;
+        }
     }
-    if (!vec) hipLaunchKernelGGL((k_reduce_all<T, F, MIXED, 1>), dim3(blocks), dim3(256), 0, s, a, f);
-    int rc = check_launch("k_reduce_all");
+    if (!done) rc = launch_all<T, F, MIXED, 1>(c, a, blocks, s, f);
     if (rc) return rc;
-    if (blocks > 1) {
+    if (blocks > 1 && !jit_dry_run()) {
         clear_sticky_error();
     hipLaunchKernelGGL((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
         rc = check_launch("k_reduce_final");
@@ -355,10 +390,25 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.chunk = ((a.nred + nsplit - 1) / nsplit + a.tr - 1) / a.tr * a.tr;
     const i64 blocks = groups * nsplit;
     if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
-    clear_sticky_error();
-    hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
-    int rc = check_launch("k_reduce_part");
-    if (rc || nsplit == 1) return rc;
+    int rc;
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "reduce";
+        l.tname = tname<T>();
+        l.argtype = "smr::RedArgs";
+        l.entry = std::string("smr::reduce_part_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ">(a, smr::FJit{});";
+        l.grid = (unsigned)blocks;
+        l.block = 256;
+        l.args = &a;
+        l.argsize = sizeof a;
+        rc = jit_launch(c, l, s);
+    } else {
+        if (jit_dry_run()) return SMR_OK;
+        clear_sticky_error();
+        hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        rc = check_launch("k_reduce_part");
+    }
+    if (rc || nsplit == 1 || jit_dry_run()) return rc;
     hipLaunchKernelGGL((k_reduce_part_final<T, MIXED>), dim3((unsigned)((c.nout + 255) / 256)), dim3(256), 0, s, a);
     return check_launch("k_reduce_part_final");
 }
@@ -367,7 +417,7 @@ template <>
 int launch_reduce_all_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
     typedef ct_type<SMR_CT>::type T;
     const Canon& c = plan.c;
-    if (c.mixed) return go_all<T, FProg<T>, true>(plan, bases, s, FProg<T>{c.prog});
+    if (c.mixed) return with_prog<T>(c, [&](auto f) { return go_all<T, decltype(f), true>(plan, bases, s, f); });
     const unsigned mask = fbit(FK_IDENT) | fbit(FK_ABS2) | fbit(FK_MUL2);
     return with_functor<T>(c, mask, [&](auto f) { return go_all<T, decltype(f), false>(plan, bases, s, f); });
 }
@@ -376,9 +426,10 @@ template <>
 int launch_reduce_part_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
     typedef ct_type<SMR_CT>::type T;
     const Canon& c = plan.c;
-    if (c.mixed) return go_part<T, FProg<T>, true>(plan, bases, s, FProg<T>{c.prog});
+    if (c.mixed) return with_prog<T>(c, [&](auto f) { return go_part<T, decltype(f), true>(plan, bases, s, f); });
     const unsigned mask = fbit(FK_IDENT) | fbit(FK_MUL2);
     return with_functor<T>(c, mask, [&](auto f) { return go_part<T, decltype(f), false>(plan, bases, s, f); });
 }
+#endif  // !SMR_JIT
 
 }  // namespace smr

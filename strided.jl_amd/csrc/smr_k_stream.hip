@@ -26,7 +26,7 @@ struct alignas(sizeof(T) * V) Vec {
 };
 
 template <class T, class F, bool MIXED, int V, int U>
-__global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f) {
+SMR_DEV void stream_map_body(const StreamArgs& a, F f) {
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     i64 row = 0, cb = blockIdx.x;
     if (a.rows > 1) {
@@ -108,6 +108,12 @@ __global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f) {
     }
 }
 
+#ifndef SMR_JIT
+template <class T, class F, bool MIXED, int V, int U>
+__global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f) {
+    stream_map_body<T, F, MIXED, V, U>(a, f);
+}
+
 template <class T, class F, bool MIXED, int V>
 static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     const Canon& c = plan.c;
@@ -126,9 +132,24 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
     const i64 grid = a.bpr * a.rows;
     if (grid > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "stream grid too large");
-    clear_sticky_error();
-    hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
-    return check_launch("k_stream_map");
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "stream";
+        l.tname = tname<T>();
+        l.argtype = "smr::StreamArgs";
+        l.entry = std::string("smr::stream_map_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ", " +
+                  std::to_string(V) + ", " + std::to_string(U) + ">(a, smr::FJit{});";
+        l.grid = (unsigned)grid;
+        l.block = 256;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(c, l, s);
+    } else {
+        if (jit_dry_run()) return SMR_OK;
+        clear_sticky_error();
+        hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
+        return check_launch("k_stream_map");
+    }
 }
 
 template <class T, class F>
@@ -157,8 +178,9 @@ int launch_stream_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream
         return set_error(SMR_EINVAL, "bitcopy is dispatched through the f32 object");
 #endif
     }
-    if (c.mixed) return go<T, FProg<T>, true, 1>(plan, bases, s, FProg<T>{c.prog});
+    if (c.mixed) return with_prog<T>(c, [&](auto f) { return go<T, decltype(f), true, 1>(plan, bases, s, f); });
     return with_functor<T>(c, FMASK_ALL, [&](auto f) { return go_vec<T>(plan, bases, s, f); });
 }
+#endif  // !SMR_JIT
 
 }  // namespace smr

@@ -27,9 +27,11 @@
 // with dependent kernarg loads 11.5 / 28.5 (~2000 scalar instructions per wave: bound by the
 // CU's single scalar unit) -> per-bit tables 6.0 / 14.6 -> 16-B vectors + repeat tables
 // 4.4 / 9.9 -> all loads first, branch-free variants 4.1 / 8.9 -> lane tables: this version.
+#ifndef SMR_JIT
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#endif
 
 #include "smr_dispatch.h"
 
@@ -114,7 +116,7 @@ SMR_DEV void store_at(char* p, int dtype, int conj, T v) {
 
 // V > 1 implies !MIXED && !WIDE and every direct operand unit-stride along dim 0 (launcher).
 template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
-__global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE> a, F f) {
+SMR_DEV void tiled_map_body(const TiledArgs<WIDE>& a, F f) {
     typedef typename off_t_of<WIDE>::type O;
     typedef TVec<T, V> VT;
     constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : 2);
@@ -317,6 +319,12 @@ __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE>
     }
 }
 
+#ifndef SMR_JIT
+template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
+__global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE> a, F f) {
+    tiled_map_body<T, F, MIXED, WIDE, V, EDGE, THRLOG>(a, f);
+}
+
 // ---- LDS swizzle ------------------------------------------------------------------------------------
 // l' = l ^ XOR_{b >= w, bit b of l set} mask[b]: the low w index bits (the 128 B one LDS write
 // group spans, in elements) are XORed with one w-bit mask per higher index bit.  A lane group's
@@ -408,17 +416,41 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     while ((1 << vlog) < V) ++vlog;
     constexpr int variant = (WIDE ? 2 : 0) + (V > 1 ? 1 : 0);
     const size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
-    auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
-    const unsigned grid = t.ord.empty() ? (unsigned)t.grid : (unsigned)t.ord.size();
+    const unsigned grid_ = t.ord.empty() ? (unsigned)t.grid : (unsigned)t.ord.size();
+    auto launch = [&](const TiledArgs<WIDE>& ka) -> int {
+        if constexpr (is_jit<F>::value) {
+            auto b2s = [](bool b) { return b ? "true" : "false"; };
+            JitLaunch l;
+            l.family = "tiled";
+            l.tname = tname<T>();
+            l.argtype = WIDE ? "smr::TiledArgs<true>" : "smr::TiledArgs<false>";
+            l.entry = std::string("smr::tiled_map_body<") + tname<T>() + ", smr::FJit, " + b2s(MIXED) + ", " + b2s(WIDE) + ", " +
+                      std::to_string(V) + ", " + b2s(EDGE) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
+            l.grid = grid_;
+            l.block = 1u << THRLOG;
+            l.lds = lds;
+            l.args = &ka;
+            l.argsize = sizeof ka;
+            return jit_launch(c, l, s);
+        } else {
+            if (jit_dry_run()) return SMR_OK;
+            auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
+            clear_sticky_error();
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+            }
+            hipLaunchKernelGGL(kern, dim3(grid_), dim3(1u << THRLOG), lds, s, ka, f);
+            return check_launch("k_tiled_map");
+        }
+    };
     TiledArgs<WIDE> a;
     // the arguments depend on the plan only, except for the operand addresses: built once
     std::vector<unsigned char>& cached = plan.tiled_args[variant];
     if (cached.size() == sizeof a) {
         std::memcpy(&a, cached.data(), sizeof a);
         for (int k = 0; k < c.M; ++k) a.op[k].base = tab.base[k];
-        clear_sticky_error();
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1u << THRLOG), lds, s, a, f);
-        return check_launch("k_tiled_map");
+        return launch(a);
     }
     std::memset(&a, 0, sizeof a);
     if (!t.ord.empty() && t.ord.size() <= (size_t)NORD16 && t.grid < 0xffff) {
@@ -429,7 +461,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         }
     } else if (!t.ord.empty()) {
         a.ordmode = 2;
-        if (!plan.ordtab) {
+        if (!plan.ordtab && !jit_dry_run()) {
             void* dptr = nullptr;
             hipError_t e = hipMalloc(&dptr, t.ord.size() * sizeof(uint32_t));
             if (e != hipSuccess) return hip_error(e, "hipMalloc(tile order)");
@@ -540,7 +572,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     a.base32 = base32 ? 1 : 0;
 
     // per-lane table: built once per (plan, kernel variant), kept in device memory
-    const bool build_tab = plan.lanetab[variant] == nullptr;
+    const bool build_tab = plan.lanetab[variant] == nullptr && !jit_dry_run();
     std::vector<LaneRow<WIDE>> rows;
     if (build_tab) rows.assign((size_t)c.M * NT, LaneRow<WIDE>{});
 
@@ -620,15 +652,11 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     }
     a.lanetab = reinterpret_cast<const LaneRow<WIDE>*>(plan.lanetab[variant]);
 
-    clear_sticky_error();
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+    if (!jit_dry_run()) {
+        cached.resize(sizeof a);
+        std::memcpy(cached.data(), &a, sizeof a);
     }
-    cached.resize(sizeof a);
-    std::memcpy(cached.data(), &a, sizeof a);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1u << THRLOG), lds, s, a, f);
-    return check_launch("k_tiled_map");
+    return launch(a);
 }
 
 template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
@@ -716,8 +744,8 @@ int launch_tiled_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_
         return set_error(SMR_EINVAL, "bitcopy is dispatched through the f32 object");
 #endif
     }
-    if (c.mixed) return go<T, FProg<T>, true>(plan, bases, s, FProg<T>{c.prog});
-    switch (c.fkind) {  // natively compiled functors of this family; everything else interprets
+    if (c.mixed) return with_prog<T>(c, [&](auto f) { return go<T, decltype(f), true>(plan, bases, s, f); });
+    switch (c.fkind) {  // natively compiled functors of this family; everything else is compiled at run time
         case FK_IDENT: return go<T, FIdent<T>, false>(plan, bases, s, FIdent<T>{});
         case FK_ADD2: return go<T, FAdd2<T>, false>(plan, bases, s, FAdd2<T>{});
         case FK_ADD3: return go<T, FAdd3<T>, false>(plan, bases, s, FAdd3<T>{});
@@ -729,7 +757,8 @@ int launch_tiled_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_
             return go<T, FAxpby<T>, false>(plan, bases, s, FAxpby<T>{hostmk<T>(c.fc[0], c.fc[1]), hostmk<T>(c.fc[2], c.fc[3])});
         default: break;
     }
-    return go<T, FProg<T>, false>(plan, bases, s, FProg<T>{c.prog});
+    return with_prog<T>(c, [&](auto f) { return go<T, decltype(f), false>(plan, bases, s, f); });
 }
+#endif  // !SMR_JIT
 
 }  // namespace smr

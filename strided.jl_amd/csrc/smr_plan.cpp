@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -23,7 +24,11 @@
 namespace smr {
 
 Options& options() {
-    static Options o;
+    static Options o = [] {
+        Options d;
+        if (const char* e = std::getenv("SMR_JIT")) d.jit = std::atoll(e);  // SMR_JIT=0: always interpret
+        return d;
+    }();
     return o;
 }
 

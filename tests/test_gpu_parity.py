@@ -165,6 +165,55 @@ def test_mapreduce_scalar_returns_the_complete_reduction_to_the_host():
     assert L.load().smr_mapreduce_scalar(C.byref(p), C.byref(host)) == L.SMR_EINVAL
 
 
+@pytest.mark.parametrize("T", cases.FLOATS)
+def test_runtime_compiled_functors_equal_the_interpreter_bit_for_bit(T):
+    """f-programs without a native functor are compiled by hiprtc into straight-line code over the
+    same primitives the bytecode interpreter calls: both paths must agree exactly, in every kernel
+    family (stream, tiled, tiled+ragged, generic, complete and partial reductions, mixed types)."""
+    import torch
+    fn = S.fn
+    rng = np.random.default_rng(5)
+    a, b, c = (cases._rand(rng, (48, 40, 12), T) for _ in range(3))
+    cplx = np.issubdtype(np.dtype(T), np.complexfloating)
+
+    def run():
+        A, B, C = dview(a), dview(b), dview(c)
+        out = []
+        D = A.similar()
+        D.assign(A * 2 + B / 3 - 1); out.append(D.toarray())                                  # stream
+        D.assign(fn.sqrt(fn.abs(A)) * B - fn.exp(C * 0.25)); out.append(D.toarray())
+        E = dview(np.zeros((40, 48, 12), dtype=T))
+        E.assign(A.permutedims((1, 0, 2)) * B.permutedims((1, 0, 2)) - C.permutedims((1, 0, 2)) / 7); out.append(E.toarray())  # tiled
+        F = dview(np.zeros((12, 40, 48), dtype=T))
+        F.assign(fn.abs2(A.permutedims((2, 1, 0))) - B.permutedims((2, 1, 0)) * 3); out.append(F.toarray())  # tiled, 3 axes, ragged
+        if not cplx:
+            D.assign(fn.select(A < B, A - C, B * C)); out.append(D.toarray())
+        G = A.sview(slice(0, 48, 2), slice(None), slice(None))                                 # generic (stride 2)
+        H = dview(np.zeros(G.size, dtype=T))
+        S.map_(lambda x, y: x * y - x, H, G, B.sview(slice(0, 48, 2), slice(None), slice(None))); out.append(H.toarray())
+        out.append(np.asarray(S.mapreduce(lambda x: fn.sin(x) * x, "+", A)))                  # reduce_all
+        out.append(S.mapreduce(lambda x: x * x - 1, "+", A, dims=(1,)).toarray())              # reduce_part
+        Dd = dview(np.zeros((48, 40, 12), dtype=np.complex128 if cplx else np.float64))
+        Dd.assign(A * B - 0.5); out.append(Dd.toarray())                                       # mixed
+        torch.cuda.synchronize()
+        return out
+
+    c0, f0 = S.get_option("jit_compiles"), S.get_option("jit_failures")
+    S.set_option("jit", 1)
+    jit = run()
+    assert S.get_option("jit_failures") == f0, "hiprtc failed on the GPU box"
+    assert S.get_option("jit_compiles") + S.get_option("jit_hits") > c0
+    S.set_option("jit", 0)
+    try:
+        interp = run()
+    finally:
+        S.set_option("jit", 1)
+    for i, (x, y) in enumerate(zip(jit, interp)):
+        assert np.array_equal(x, y, equal_nan=True), f"{np.dtype(T).name} expression {i}: JIT differs from the interpreter"
+    # and both agree with NumPy on the pure-arithmetic ones
+    assert np.array_equal(jit[0], a * 2 + b / 3 - 1) or cplx
+
+
 def test_every_kernel_family_is_exercised():
     """Plans for representative problems pick the intended family (guards against a silent
     fallback to the generic kernel)."""
