@@ -393,6 +393,9 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "tile_order") o.tile_order = value;
     else if (n == "reduce_blocks") o.reduce_blocks = value;
     else if (n == "jit") o.jit = value;
+    else if (n == "reduce_part_kind") o.reduce_part_kind = value;
+    else if (n == "reduce_col_txlog") o.reduce_col_txlog = value;
+    else if (n == "reduce_part_wgs") o.reduce_part_wgs = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
     else if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') o.tile_lg[n[7] - '0'] = value;
@@ -416,6 +419,9 @@ int64_t smr_get_option(const char* name) {
     if (n == "tile_order") return o.tile_order;
     if (n == "reduce_blocks") return o.reduce_blocks;
     if (n == "jit") return o.jit;
+    if (n == "reduce_part_kind") return o.reduce_part_kind;
+    if (n == "reduce_col_txlog") return o.reduce_col_txlog;
+    if (n == "reduce_part_wgs") return o.reduce_part_wgs;
     if (n == "jit_compiles") return jit_stats().compiles;
     if (n == "jit_hits") return jit_stats().hits;
     if (n == "jit_failures") return jit_stats().failures;

@@ -137,6 +137,13 @@ struct Plan {
     int red_blocks = 0;
     int part_tr = 1;    // REDUCE_PART: lanes cooperating on one output
     int part_split = 1; // REDUCE_PART: chunks of the reduced range (two-pass when > 1)
+    // REDUCE_PART, vectorised forms (see smr_k_reduce.hip): 1 = ROW (inputs unit-stride along the
+    // first reduced dim), 2 = COL (inputs unit-stride along kept dim 0), 0 = general
+    int part_kind = 0;
+    int part_g0log = 0, part_g1log = 0;  // ROW: lanes of a group along the inner reduced dim / the outer index
+                                         // COL: rows of a workgroup along the inner reduced dim / the outer index
+    int part_txlog = 0;                  // COL: lanes along kept dim 0
+    int part_xsplit = 1, part_qsplit = 1;  // split of the inner / outer reduced range over workgroups
     // TILED: per-lane index tables in device memory, one per kernel variant (built on first use)
     mutable void* lanetab[4] = {nullptr, nullptr, nullptr, nullptr};
     mutable void* ordtab = nullptr;  // TILED: tile-order table in device memory (large grids)
@@ -153,6 +160,9 @@ struct Options {
     i64 tiled_minrun_bytes = 64;
     i64 tile_order = 1;      // orbit-major tile order for inputs that are permuted views of one buffer
     i64 jit = 1;             // compile unrecognised f-programs with hiprtc (0 = always interpret)
+    i64 reduce_col_txlog = 5;   // COL form: log2 of the lanes along kept dim 0 (cap)
+    i64 reduce_part_wgs = 4096; // partial reductions with few outputs are split until about this many workgroups run
+    i64 reduce_part_kind = -1;  // -1 = planner's choice; 0/1/2 force general / ROW / COL when applicable
     i64 reduce_blocks = 2048;  // cap on the workgroups (= partials) of a complete reduction
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 max_lds_bytes = 65536;

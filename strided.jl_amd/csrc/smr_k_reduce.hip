@@ -30,6 +30,10 @@ struct RedArgs {
     int32_t nsplit;   // REDUCE_PART: the reduced range is cut into nsplit chunks (one workgroup each)
     int32_t ngroups;  // REDUCE_PART: workgroups along the output index
     i64 chunk;        // reduced elements per chunk (multiple of tr)
+    // vectorised forms (ROW / COL): reduced space = inner dim NK (extent L0) x outer index q in [0, Q)
+    int32_t g0log, g1log, txlog, xsplit, qsplit, pad_;
+    i64 L0, Q, xchunk, qchunk;
+    i64 nkb0;         // COL: workgroups along kept dim 0
 };
 
 template <class T>
@@ -264,26 +268,310 @@ SMR_DEV void reduce_part_body(const RedArgs& a, F f) {
     }
 }
 
-// second pass of a split partial reduction: one thread folds the nsplit partials of its output
-template <class T, bool MIXED>
-__global__ void __launch_bounds__(256) k_reduce_part_final(RedArgs a) {
-    const i64 o = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (o >= a.nout) return;
+
+// ---- partial reduction, vectorised forms -----------------------------------------------------------------
+// Both walk the reduced space as (inner dim NK) x (outer index q over dims NK+1..N-1): the outer
+// offsets are decomposed once per q, the inner dim advances by plain stride additions -- no
+// per-element index division (the general form above pays one 64-bit decompose per element).
+//
+// ROW: every input is unit-stride (or broadcast) along the inner reduced dim.  G = G0 x G1 consecutive
+// lanes cooperate on one destination element: G0 lanes walk the inner dim with V-element vector
+// loads, G1 lanes take different q.  sum(A; dims=1) of a column-major matrix is the model case.
+template <class T, class F, bool MIXED, int V>
+SMR_DEV void reduce_row_body(const RedArgs& a, F f) {
+    __shared__ T xbuf[256];
+    typedef RVec<T, V> VT;
+    constexpr int U = 4;  // vectors in flight per lane
+    const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
+    const int glog = a.g0log + a.g1log;
+    const int G0 = 1 << a.g0log, G1 = 1 << a.g1log;
+    const int gl = threadIdx.x & ((1 << glog) - 1);
+    const int ol = threadIdx.x >> glog;
+    const int l0 = gl & (G0 - 1), l1 = gl >> a.g0log;
+    const i64 sp = (i64)blockIdx.x / a.ngroups;
+    const i64 og = (i64)blockIdx.x - sp * a.ngroups;
+    const i64 o = og * (256 >> glog) + ol;
+    const bool live = o < a.nout;
+    const i64 sx = sp % a.xsplit, sq = sp / a.xsplit;
+    const i64 xbeg = sx * a.xchunk, xend = (xbeg + a.xchunk < a.L0) ? xbeg + a.xchunk : a.L0;
+    const i64 qbeg = sq * a.qchunk, qend = (qbeg + a.qchunk < a.Q) ? qbeg + a.qchunk : a.Q;
     i64 ooff[MAXM];
 #pragma unroll
     for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
-    decompose(a, o, 0, a.NK, ooff);
-    const T* p = (const T*)a.partials + o * a.nsplit;
+    if (live) decompose(a, o, 0, a.NK, ooff);
+    T acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = neutral<T>(a.redop);
+    // U loads in flight per lane: along the inner dim when it is long enough, else over q
+    const bool unroll_q = (xend - xbeg) <= (i64)G0 * V;
+    auto row_step = [&](const i64 (&off)[U][MAXM], const i64 (&xs)[U], const bool (&ok)[U]) {
+        VT in[U][MAXIN];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u]) {
+#pragma unroll
+                for (int k = 0; k < MAXIN; ++k)
+                    if (k < nin) {
+                        if (a.strides[k + 1][a.NK] == 0) {
+                            const T sv = load_op<T, MIXED>(a.ops, k + 1, off[u][k + 1]);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) in[u][k].v[e] = sv;
+                        } else if constexpr (MIXED || V == 1) {
+                            in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, off[u][k + 1] + xs[u]);
+                        } else {
+                            in[u][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + off[u][k + 1] + xs[u]);
+                            if constexpr (tr<T>::cx) {
+                                if (a.ops.conj[k + 1]) {
+#pragma unroll
+                                    for (int e = 0; e < V; ++e) in[u][k].v[e] = cj(in[u][k].v[e]);
+                                }
+                            }
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u]) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    T arg[MAXIN];
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k) {
+                        arg[k] = T{};
+                        if (k < nin) arg[k] = in[u][k].v[e];
+                    }
+                    acc[u] = red_apply<T>(a.redop, acc[u], f(arg));
+                }
+            }
+        }
+    };
+    if (live && !unroll_q) {
+        for (i64 q = qbeg + l1; q < qend; q += G1) {
+            i64 off[U][MAXM];
+#pragma unroll
+            for (int k = 0; k < MAXM; ++k) off[0][k] = ooff[k];
+            if (a.N > a.NK + 1) decompose(a, q, a.NK + 1, a.N, off[0]);
+#pragma unroll
+            for (int u = 1; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < MAXM; ++k) off[u][k] = off[0][k];
+            for (i64 x0 = xbeg + (i64)l0 * V; x0 < xend; x0 += (i64)G0 * V * U) {
+                i64 xs[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xs[u] = x0 + (i64)u * G0 * V;
+                    ok[u] = xs[u] < xend;
+                }
+                row_step(off, xs, ok);
+            }
+        }
+    } else if (live) {
+        const i64 x = xbeg + (i64)l0 * V;
+        if (x < xend) {
+            for (i64 q0 = qbeg + l1; q0 < qend; q0 += (i64)G1 * U) {
+                i64 off[U][MAXM], xs[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const i64 q = q0 + (i64)u * G1;
+                    ok[u] = q < qend;
+                    xs[u] = x;
+#pragma unroll
+                    for (int k = 0; k < MAXM; ++k) off[u][k] = ooff[k];
+                    if (ok[u] && a.N > a.NK + 1) decompose(a, q, a.NK + 1, a.N, off[u]);
+                }
+                row_step(off, xs, ok);
+            }
+        }
+    }
+    T v = red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3]));
+    const int G = 1 << glog;
+    v = wave_reduce(v, a.redop, G < 64 ? G : 64);
+    if (G > 64) {  // lanes of one output span several waves
+        xbuf[threadIdx.x] = v;
+        __syncthreads();
+        if (gl == 0)
+            for (int j = 64; j < G; j += 64) v = red_apply<T>(a.redop, v, xbuf[threadIdx.x + j]);
+    }
+    if (live && gl == 0) {
+        if (a.nsplit == 1)
+            epilogue<T, MIXED>(a, ooff[0], v);
+        else
+            ((T*)a.partials)[o * a.nsplit + sp] = v;
+    }
+}
+
+// COL: every input is unit-stride (or broadcast) along kept dim 0.  A workgroup = TX lanes along
+// dim 0 (V destination elements each, vector loads) x TY rows of the reduced space (Y0 rows along
+// the inner reduced dim x Y1 along q); the rows are folded through LDS.  sum(A; dims=2) of a
+// column-major matrix is the model case.
+template <class T, class F, bool MIXED, int V>
+SMR_DEV void reduce_col_body(const RedArgs& a, F f) {
+    __shared__ T xbuf[256 * V];
+    typedef RVec<T, V> VT;
+    constexpr int U = 4;
+    const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
+    const int TX = 1 << a.txlog;
+    const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> a.txlog;
+    const int Y0 = 1 << a.g0log, Y1 = 1 << a.g1log;
+    const int t0 = ty & (Y0 - 1), t1 = ty >> a.g0log;
+    const i64 sp = (i64)blockIdx.x / a.ngroups;
+    const i64 kb = (i64)blockIdx.x - sp * a.ngroups;
+    const i64 krest = kb / a.nkb0;
+    const i64 c0 = kb - krest * a.nkb0;
+    const i64 i0 = (c0 * TX + tx) * V;
+    const bool live = i0 < a.dims[0];
+    const i64 sx = sp % a.xsplit, sq = sp / a.xsplit;
+    const i64 jbeg = sx * a.xchunk, jend = (jbeg + a.xchunk < a.L0) ? jbeg + a.xchunk : a.L0;
+    const i64 qbeg = sq * a.qchunk, qend = (qbeg + a.qchunk < a.Q) ? qbeg + a.qchunk : a.Q;
+    i64 ooff[MAXM];
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) ooff[k] = (k < a.M) ? i0 * a.strides[k][0] : 0;
+    if (a.NK > 1) decompose(a, krest, 1, a.NK, ooff);
+    T acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = neutral<T>(a.redop);
+    // U loads in flight per lane: along the inner reduced dim when it is long enough, else over q
+    const bool unroll_q = (jend - jbeg) <= (i64)Y0;
+    auto col_step = [&](const i64 (&off)[U][MAXM], const bool (&ok)[U]) {
+        VT in[U][MAXIN];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u]) {
+#pragma unroll
+                for (int k = 0; k < MAXIN; ++k)
+                    if (k < nin) {
+                        const i64 oj = off[u][k + 1];
+                        if (a.strides[k + 1][0] == 0) {
+                            const T sv = load_op<T, MIXED>(a.ops, k + 1, oj);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) in[u][k].v[e] = sv;
+                        } else if constexpr (MIXED || V == 1) {
+                            in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, oj);
+                        } else {
+                            in[u][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + oj);
+                            if constexpr (tr<T>::cx) {
+                                if (a.ops.conj[k + 1]) {
+#pragma unroll
+                                    for (int e = 0; e < V; ++e) in[u][k].v[e] = cj(in[u][k].v[e]);
+                                }
+                            }
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u]) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    T arg[MAXIN];
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k) {
+                        arg[k] = T{};
+                        if (k < nin) arg[k] = in[u][k].v[e];
+                    }
+                    acc[e] = red_apply<T>(a.redop, acc[e], f(arg));
+                }
+            }
+        }
+    };
+    if (live && !unroll_q) {
+        for (i64 q = qbeg + t1; q < qend; q += Y1) {
+            i64 offq[MAXM];
+#pragma unroll
+            for (int k = 0; k < MAXM; ++k) offq[k] = ooff[k];
+            if (a.N > a.NK + 1) decompose(a, q, a.NK + 1, a.N, offq);
+            for (i64 j0 = jbeg + t0; j0 < jend; j0 += (i64)Y0 * U) {
+                i64 off[U][MAXM];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const i64 j = j0 + (i64)u * Y0;
+                    ok[u] = j < jend;
+#pragma unroll
+                    for (int k = 0; k < MAXM; ++k) off[u][k] = (k < a.M) ? offq[k] + j * a.strides[k][a.NK] : 0;
+                }
+                col_step(off, ok);
+            }
+        }
+    } else if (live) {
+        const i64 j = jbeg + t0;
+        if (j < jend) {
+            for (i64 q0 = qbeg + t1; q0 < qend; q0 += (i64)Y1 * U) {
+                i64 off[U][MAXM];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const i64 q = q0 + (i64)u * Y1;
+                    ok[u] = q < qend;
+#pragma unroll
+                    for (int k = 0; k < MAXM; ++k) off[u][k] = (k < a.M) ? ooff[k] + j * a.strides[k][a.NK] : 0;
+                    if (ok[u] && a.N > a.NK + 1) decompose(a, q, a.NK + 1, a.N, off[u]);
+                }
+                col_step(off, ok);
+            }
+        }
+    }
+    // fold the TY rows: LDS tree, halving the number of active rows
+    const int TY = 256 >> a.txlog;
+#pragma unroll
+    for (int e = 0; e < V; ++e) xbuf[threadIdx.x * V + e] = acc[e];
+    __syncthreads();
+    for (int h = TY >> 1; h > 0; h >>= 1) {
+        if (ty < h) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                acc[e] = red_apply<T>(a.redop, acc[e], xbuf[(threadIdx.x + h * TX) * V + e]);
+                xbuf[threadIdx.x * V + e] = acc[e];
+            }
+        }
+        __syncthreads();
+    }
+    if (live && ty == 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (a.nsplit == 1) {
+                epilogue<T, MIXED>(a, ooff[0] + e * a.strides[0][0], acc[e]);
+            } else {
+                const i64 o = i0 + e + krest * a.dims[0];
+                ((T*)a.partials)[o * a.nsplit + sp] = acc[e];
+            }
+        }
+    }
+}
+
+// second pass of a split partial reduction: LPO = 2^lpolog consecutive lanes fold the nsplit partials
+// of one output (strided walk + wave butterfly); LPO = 1 when there are many outputs and few partials
+template <class T, bool MIXED>
+__global__ void __launch_bounds__(256) k_reduce_part_final(RedArgs a) {
+    const int lpolog = a.trlog;  // reused: log2 lanes per output of THIS pass (<= 6)
+    const int lpo = 1 << lpolog;
+    const i64 o = ((i64)blockIdx.x * 256 + threadIdx.x) >> lpolog;
+    const int l = threadIdx.x & (lpo - 1);
+    const bool live = o < a.nout;
     T acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = neutral<T>(a.redop);
-    for (int i = 0; i < a.nsplit; i += 4) {
+    if (live) {
+        const T* p = (const T*)a.partials + o * a.nsplit;
+        for (int i = l; i < a.nsplit; i += 4 * lpo) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i + j < a.nsplit) acc[j] = red_apply<T>(a.redop, acc[j], p[i + j]);
+            for (int j = 0; j < 4; ++j)
+                if (i + j * lpo < a.nsplit) acc[j] = red_apply<T>(a.redop, acc[j], p[i + j * lpo]);
+        }
     }
-    epilogue<T, MIXED>(a, ooff[0],
-                       red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3])));
+    T v = red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3]));
+    v = wave_reduce(v, a.redop, lpo);
+    if (live && l == 0) {
+        i64 ooff[MAXM];
+#pragma unroll
+        for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
+        decompose(a, o, 0, a.NK, ooff);
+        epilogue<T, MIXED>(a, ooff[0], v);
+    }
 }
 
 #ifndef SMR_JIT
@@ -294,6 +582,14 @@ __global__ void __launch_bounds__(256) k_reduce_all(RedArgs a, F f) {
 template <class T, class F, bool MIXED>
 __global__ void __launch_bounds__(256) k_reduce_part(RedArgs a, F f) {
     reduce_part_body<T, F, MIXED>(a, f);
+}
+template <class T, class F, bool MIXED, int V>
+__global__ void __launch_bounds__(256) k_reduce_row(RedArgs a, F f) {
+    reduce_row_body<T, F, MIXED, V>(a, f);
+}
+template <class T, class F, bool MIXED, int V>
+__global__ void __launch_bounds__(256) k_reduce_col(RedArgs a, F f) {
+    reduce_col_body<T, F, MIXED, V>(a, f);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------
@@ -374,42 +670,119 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     return rc;
 }
 
+// launches one of the three partial-reduction bodies (KIND 0 general, 1 ROW, 2 COL)
+template <class T, class F, bool MIXED, int KIND, int V>
+static int launch_part(const Canon& c, const RedArgs& a, i64 blocks, hipStream_t s, F f) {
+    if constexpr (is_jit<F>::value) {
+        static const char* body[] = {"reduce_part_body", "reduce_row_body", "reduce_col_body"};
+        JitLaunch l;
+        l.family = "reduce";
+        l.tname = tname<T>();
+        l.argtype = "smr::RedArgs";
+        l.entry = std::string("smr::") + body[KIND] + "<" + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") +
+                  (KIND ? ", " + std::to_string(V) : std::string()) + ">(a, smr::FJit{});";
+        l.grid = (unsigned)blocks;
+        l.block = 256;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(c, l, s);
+    } else {
+        if (jit_dry_run()) return SMR_OK;
+        clear_sticky_error();
+        if constexpr (KIND == 0) hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        if constexpr (KIND == 1) hipLaunchKernelGGL((k_reduce_row<T, F, MIXED, V>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        if constexpr (KIND == 2) hipLaunchKernelGGL((k_reduce_col<T, F, MIXED, V>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        return check_launch("k_reduce_part");
+    }
+}
+
 template <class T, class F, bool MIXED>
 static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     const Canon& c = plan.c;
     RedArgs a;
     fill_args(plan, bases, a);
-    a.tr = plan.part_tr;
-    a.trlog = 0;
-    while ((1 << a.trlog) < a.tr) ++a.trlog;
-    const int ob = 256 / a.tr;
-    const i64 groups = (c.nout + ob - 1) / ob;
-    int nsplit = (plan.part_split > 1 && plan.scratch) ? plan.part_split : 1;
+    const bool have_scratch = plan.scratch != nullptr;
+    int nsplit = (plan.part_split > 1 && have_scratch) ? plan.part_split : 1;
     a.nsplit = nsplit;
-    a.ngroups = (int32_t)groups;
-    a.chunk = ((a.nred + nsplit - 1) / nsplit + a.tr - 1) / a.tr * a.tr;
-    const i64 blocks = groups * nsplit;
-    if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
+    a.xsplit = a.qsplit = 1;
+    i64 blocks = 0;
     int rc;
-    if constexpr (is_jit<F>::value) {
-        JitLaunch l;
-        l.family = "reduce";
-        l.tname = tname<T>();
-        l.argtype = "smr::RedArgs";
-        l.entry = std::string("smr::reduce_part_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ">(a, smr::FJit{});";
-        l.grid = (unsigned)blocks;
-        l.block = 256;
-        l.args = &a;
-        l.argsize = sizeof a;
-        rc = jit_launch(c, l, s);
+    constexpr int VMAX = (MIXED || sizeof(T) >= 16) ? 1 : (int)(16 / sizeof(T));
+    if (plan.part_kind == 0) {
+        a.tr = plan.part_tr;
+        a.trlog = 0;
+        while ((1 << a.trlog) < a.tr) ++a.trlog;
+        const int ob = 256 / a.tr;
+        const i64 groups = (c.nout + ob - 1) / ob;
+        a.ngroups = (int32_t)groups;
+        a.chunk = ((a.nred + nsplit - 1) / nsplit + a.tr - 1) / a.tr * a.tr;
+        blocks = groups * nsplit;
+        if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
+        rc = launch_part<T, F, MIXED, 0, 1>(c, a, blocks, s, f);
     } else {
-        if (jit_dry_run()) return SMR_OK;
-        clear_sticky_error();
-        hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
-        rc = check_launch("k_reduce_part");
+        a.g0log = plan.part_g0log;
+        a.g1log = plan.part_g1log;
+        a.txlog = plan.part_txlog;
+        a.L0 = c.dims[c.NK];
+        a.Q = a.nred / a.L0;
+        if (nsplit > 1) {
+            a.xsplit = plan.part_xsplit;
+            a.qsplit = plan.part_qsplit;
+        }
+        a.qchunk = (a.Q + a.qsplit - 1) / a.qsplit;
+        // vector width: the vector axis must divide, every vector-loaded operand must be aligned
+        const int vax = plan.part_kind == 1 ? c.NK : 0;  // axis the vectors run along
+        bool vec = VMAX > 1 && (c.dims[vax] % VMAX == 0);
+        for (int k = 1; k < c.M && vec; ++k) {
+            if (c.strides[k][vax] != 1) continue;
+            if (((uintptr_t)a.ops.base[k]) % 16) vec = false;
+            for (int d = 0; d < c.N; ++d)
+                if (d != vax && (c.strides[k][d] % VMAX)) vec = false;
+        }
+        const int V = vec ? VMAX : 1;
+        if (plan.part_kind == 1) {
+            const i64 unit = ((i64)V) << a.g0log;
+            a.xchunk = ((a.L0 + a.xsplit - 1) / a.xsplit + unit - 1) / unit * unit;
+            const i64 groups = (c.nout + (256 >> (a.g0log + a.g1log)) - 1) / (256 >> (a.g0log + a.g1log));
+            a.ngroups = (int32_t)groups;
+            blocks = groups * nsplit;
+            if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
+            rc = SMR_OK;
+            bool done = false;
+            if constexpr (VMAX > 1) {
+                if (vec) {
+                    rc = launch_part<T, F, MIXED, 1, VMAX>(c, a, blocks, s, f);
+                    done = true;
+                }
+            }
+            if (!done) rc = launch_part<T, F, MIXED, 1, 1>(c, a, blocks, s, f);
+        } else {
+            a.xchunk = (a.L0 + a.xsplit - 1) / a.xsplit;
+            const i64 per = ((i64)V) << a.txlog;
+            a.nkb0 = (c.dims[0] + per - 1) / per;
+            const i64 groups = a.nkb0 * (c.nout / c.dims[0]);
+            a.ngroups = (int32_t)groups;
+            blocks = groups * nsplit;
+            if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
+            rc = SMR_OK;
+            bool done = false;
+            if constexpr (VMAX > 1) {
+                if (vec) {
+                    rc = launch_part<T, F, MIXED, 2, VMAX>(c, a, blocks, s, f);
+                    done = true;
+                }
+            }
+            if (!done) rc = launch_part<T, F, MIXED, 2, 1>(c, a, blocks, s, f);
+        }
     }
     if (rc || nsplit == 1 || jit_dry_run()) return rc;
-    hipLaunchKernelGGL((k_reduce_part_final<T, MIXED>), dim3((unsigned)((c.nout + 255) / 256)), dim3(256), 0, s, a);
+    // lanes per output of the folding pass: as many as there are partials (up to a wave), fewer
+    // when there are plenty of outputs anyway
+    int lpolog = 0;
+    while (lpolog < 6 && (4 << lpolog) < nsplit && (c.nout << lpolog) < 256 * 1024) ++lpolog;
+    a.trlog = lpolog;
+    const i64 fthreads = c.nout << lpolog;
+    hipLaunchKernelGGL((k_reduce_part_final<T, MIXED>), dim3((unsigned)((fthreads + 255) / 256)), dim3(256), 0, s, a);
     return check_launch("k_reduce_part_final");
 }
 

@@ -671,32 +671,98 @@ int make_plan(const smr_problem* p, Plan& plan) {
             plan.red_blocks = (int)nb;
             plan.scratch_bytes = (size_t)nb * es;
         } else {
-            // lanes cooperating per output: more when few outputs / long reductions
-            i64 red = c.total / std::max<i64>(1, c.nout);
-            int tr = 1;
-            // the inputs' fastest-varying dim is a reduced one -> lanes along it coalesce
-            bool red_fast = false;
-            for (int k = 1; k < c.M; ++k)
-                for (int i = c.NK; i < c.N; ++i)
-                    if (std::llabs(c.strides[k][i]) == 1) red_fast = true;
-            if (red_fast || c.nout < 256 * 256) {
-                while (tr < 256 && tr * 2 <= red && (tr < 64 || c.nout * tr < 256 * 1024)) tr <<= 1;
+            const i64 red = c.total / std::max<i64>(1, c.nout);
+            const i64 L0 = c.dims[c.NK];  // inner reduced dim
+            const i64 Q = red / L0;        // outer reduced index (dims NK+1..)
+            // which vectorisable form applies?
+            bool row = true, col = c.strides[0][0] == 1, any_row = false, any_col = false;
+            for (int k = 1; k < c.M; ++k) {
+                const i64 sr = c.strides[k][c.NK], sc = c.strides[k][0];
+                if (sr == 1) any_row = true;
+                else if (sr != 0) row = false;
+                if (sc == 1) any_col = true;
+                else if (sc != 0) col = false;
             }
-            if (red_fast && tr < 16 && red >= 16) tr = 16;
-            plan.part_tr = tr;
-            // few destination elements, long reductions: cut the reduced range so that ~2048
-            // workgroups are in flight, partials folded by a second launch (also keeps the
-            // serial per-lane accumulation short, which is what bounds the rounding error)
-            const i64 groups = (c.nout + (256 / tr) - 1) / (256 / tr);
-            i64 split = 1;
-            if (groups < 1024 && red >= (i64)tr * 256) {
-                split = std::min<i64>(2048 / std::max<i64>(1, groups), red / ((i64)tr * 64));
-                split = std::max<i64>(1, std::min<i64>(split, 4096));
+            row = row && any_row;
+            col = col && any_col;
+            const int vmax = std::max(1, 16 / es);
+            auto p2ceil = [](i64 v) {
+                int l = 0;
+                while (((i64)1 << l) < v) ++l;
+                return l;
+            };
+            if (o.reduce_part_kind >= 0) {  // tuning / testing override
+                row = row && o.reduce_part_kind == 1;
+                col = col && o.reduce_part_kind == 2;
             }
-            plan.part_split = (int)split;
-            if (split > 1) {
-                plan.scratch_bytes = (size_t)c.nout * (size_t)split * es;
-                plan.red_blocks = (int)split;  // > 1: the API allocates the partials buffer
+            if (col) {
+                // COL: a workgroup = TX lanes along kept dim 0 (vmax elements each) x TY rows of the
+                // reduced space; LDS tree over the rows
+                plan.part_kind = 2;
+                const i64 K0 = c.dims[0];
+                int txlog = std::min(8, p2ceil((K0 + vmax - 1) / vmax));
+                txlog = std::min<int>(txlog, (int)o.reduce_col_txlog);
+                plan.part_txlog = txlog;
+                const int tylog = 8 - txlog;
+                plan.part_g0log = std::min(tylog, p2ceil(L0));
+                plan.part_g1log = tylog - plan.part_g0log;
+                const i64 kb = ((K0 + (((i64)vmax) << txlog) - 1) / (((i64)vmax) << txlog)) * (c.nout / K0);
+                i64 split = 1;
+                const i64 rows_per_wg = (i64)1 << tylog;
+                if (kb < 2048 && red >= rows_per_wg * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / kb, red / (rows_per_wg * 8)));
+                split = std::min<i64>(split, 4096);
+                if (Q >= 2 * split * ((i64)1 << plan.part_g1log)) {
+                    plan.part_qsplit = (int)split;
+                } else {
+                    plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split, L0 / ((i64)4 << plan.part_g0log)));
+                }
+                plan.part_split = plan.part_xsplit * plan.part_qsplit;
+                plan.part_tr = 1 << tylog;
+            } else if (row) {
+                // ROW: G consecutive lanes per output, vector loads along the inner reduced dim
+                plan.part_kind = 1;
+                int glog = 8;
+                while (glog > 4 && red < ((i64)vmax << glog) * 4) --glog;
+                plan.part_g0log = std::min(glog, p2ceil((L0 + vmax - 1) / vmax));
+                plan.part_g1log = glog - plan.part_g0log;
+                const i64 groups = (c.nout + (256 >> glog) - 1) / (256 >> glog);
+                i64 split = 1;
+                if (groups < 2048 && red >= ((i64)vmax << glog) * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / groups, red / (((i64)vmax << glog) * 8)));
+                split = std::min<i64>(split, 4096);
+                if (Q >= 2 * split * ((i64)1 << plan.part_g1log)) {
+                    plan.part_qsplit = (int)split;
+                } else {
+                    plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split, L0 / (((i64)vmax * 4) << plan.part_g0log)));
+                }
+                plan.part_split = plan.part_xsplit * plan.part_qsplit;
+                plan.part_tr = 1 << glog;
+            } else {
+                // general form: lanes cooperating per output: more when few outputs / long reductions
+                int tr = 1;
+                // the inputs' fastest-varying dim is a reduced one -> lanes along it coalesce
+                bool red_fast = false;
+                for (int k = 1; k < c.M; ++k)
+                    for (int i = c.NK; i < c.N; ++i)
+                        if (std::llabs(c.strides[k][i]) == 1) red_fast = true;
+                if (red_fast || c.nout < 256 * 256) {
+                    while (tr < 256 && tr * 2 <= red && (tr < 64 || c.nout * tr < 256 * 1024)) tr <<= 1;
+                }
+                if (red_fast && tr < 16 && red >= 16) tr = 16;
+                plan.part_tr = tr;
+                // few destination elements, long reductions: cut the reduced range so that ~2048
+                // workgroups are in flight, partials folded by a second launch (also keeps the
+                // serial per-lane accumulation short, which is what bounds the rounding error)
+                const i64 groups = (c.nout + (256 / tr) - 1) / (256 / tr);
+                i64 split = 1;
+                if (groups < 1024 && red >= (i64)tr * 256) {
+                    split = std::min<i64>(2048 / std::max<i64>(1, groups), red / ((i64)tr * 64));
+                    split = std::max<i64>(1, std::min<i64>(split, 4096));
+                }
+                plan.part_split = (int)split;
+            }
+            if (plan.part_split > 1) {
+                plan.scratch_bytes = (size_t)c.nout * (size_t)plan.part_split * es;
+                plan.red_blocks = plan.part_split;  // > 1: the API allocates the partials buffer
             }
         }
     }
@@ -725,8 +791,9 @@ void describe(Plan& plan) {
     } else if (plan.family == FAM_REDUCE_ALL) {
         n += std::snprintf(buf + n, sizeof buf - n, " blocks=%d", plan.red_blocks);
     } else if (plan.family == FAM_REDUCE_PART) {
-        n += std::snprintf(buf + n, sizeof buf - n, " nout=%lld lanes_per_out=%d split=%d", (long long)c.nout, plan.part_tr,
-                           plan.part_split);
+        static const char* kinds[] = {"general", "row", "col"};
+        n += std::snprintf(buf + n, sizeof buf - n, " nout=%lld form=%s lanes_per_out=%d split=%d", (long long)c.nout, kinds[plan.part_kind],
+                           plan.part_tr, plan.part_split);
     }
     std::snprintf(buf + n, sizeof buf - n, " algbytes=%lld", (long long)c.algbytes);
     plan.desc = buf;

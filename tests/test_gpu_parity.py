@@ -214,6 +214,41 @@ def test_runtime_compiled_functors_equal_the_interpreter_bit_for_bit(T):
     assert np.array_equal(jit[0], a * 2 + b / 3 - 1) or cplx
 
 
+@pytest.mark.parametrize("T", [np.float32, np.float64, np.complex64])
+@pytest.mark.parametrize("shape,dims", [((300, 200), (0,)), ((300, 200), (1,)), ((64, 33, 20, 9), (0, 2)), ((64, 33, 20, 9), (1, 3)),
+                                        ((12, 70000), (1,)), ((70000, 12), (0,)), ((40, 40, 40), (0, 1)), ((37, 5, 41), (1,)),
+                                        ((16, 8, 6, 4, 10), (1, 2, 4))])
+def test_partial_reductions_vectorised_forms_match_the_general_kernel_and_numpy(shape, dims, T):
+    """sum/mapreduce over some dims: the ROW form (inputs contiguous along a reduced dim), the COL
+    form (contiguous along a kept dim), their split two-pass variants (few outputs, long
+    reductions) and ragged extents, against the general kernel and NumPy in float64."""
+    import torch
+    fn = S.fn
+    rng = np.random.default_rng(17)
+    a = cases._rand(rng, shape, T)
+    b = cases._rand(rng, shape, T)
+    truth = (np.sin(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)) * b).sum(axis=dims, keepdims=True)
+    tol = rtol(T)
+    res = {}
+    for kind in (-1, 0):
+        S.set_option("reduce_part_kind", kind)
+        try:
+            A, B = dview(a), dview(b)
+            out = A.similar(size=tuple(1 if d in dims else n for d, n in enumerate(shape)))
+            S.copyto_(out, 1.5)
+            # out = out*2 + sum(sin(a)*b): exercises initop-once on top of the reduction
+            S._mapreducedim_(lambda x, y: fn.sin(x) * y, "+", ("scale", 2.0), shape, (out, A, B))
+            plan = S.make_plan(lambda x, y: fn.sin(x) * y, "+", ("scale", 2.0), shape, S.promoteshape(shape, out, A, B))
+            torch.cuda.synchronize()
+            res[kind] = (out.toarray(), plan.describe())
+        finally:
+            S.set_option("reduce_part_kind", -1)
+    assert "form=general" in res[0][1]
+    assert "form=row" in res[-1][1] or "form=col" in res[-1][1], res[-1][1]
+    for kind, (got, d) in res.items():
+        assert _isapprox(got, truth + 3.0, tol), f"{shape} dims={dims} {np.dtype(T).name}: {d}"
+
+
 def test_every_kernel_family_is_exercised():
     """Plans for representative problems pick the intended family (guards against a silent
     fallback to the generic kernel)."""
