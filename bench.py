@@ -242,7 +242,7 @@ def main():
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": roofline,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(S)
         if extra:
             out["extra"] = extra
