@@ -234,6 +234,23 @@ int smr_plan_jit_source(const smr_plan* plan, char* buf, size_t buflen);
 int smr_shard(const smr_problem* problem, int nshards, int shard, smr_problem* out,
               int* needs_allreduce);
 
+/* ---- multi-GPU from plain C: one process per GPU, RCCL over xGMI --------------------------
+ * The C twin of what strided.jl_amd/distributed.py does through torch.distributed, for hosts
+ * without it (the Julia shim).  Rank 0 calls smr_comm_unique_id and ships the 128 bytes to
+ * the other ranks out of band (MPI, a socket, a file); every rank -- with its device already
+ * selected (smr_init) -- calls smr_comm_init.  smr_mapreduce_sharded then executes ONE logical
+ * problem cooperatively: every rank passes the same problem over its own device copies of
+ * the operands; smr_shard picks this rank's sub-box; a split reduced dim is completed by one
+ * ncclAllReduce of the destination elements (initop / old destination content enter once,
+ * on rank 0: the distributed form of src/mapreduce.jl:153-170).  Map: on return each rank's
+ * destination holds its own slab.  Reduce: every rank's destination holds the full result.
+ * With nranks == 1 everything degenerates to smr_mapreduce and RCCL is never loaded.       */
+int smr_comm_unique_id(void* out, size_t len);
+int smr_comm_init(int nranks, int rank, const void* unique_id, size_t len);
+int smr_comm_rank(int* rank, int* nranks);
+int smr_comm_destroy(void);
+int smr_mapreduce_sharded(const smr_problem* problem);
+
 /* Tuning knobs (name = "tile_log2", "block_threads", "force_family", ...); returns
  * SMR_EINVAL for unknown names.  Analogue of the reference's compile-time constants
  * MINTHREADLENGTH / BLOCKMEMORYSIZE (src/mapreduce.jl:141,462).                          */

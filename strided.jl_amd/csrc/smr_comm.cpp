@@ -1,0 +1,260 @@
+// smr_comm.cpp -- multi-GPU execution of the funnel from plain C (one process per GPU, RCCL over
+// xGMI).  The C twin of strided.jl_amd/distributed.py for hosts that do not go through
+// torch.distributed (the Julia shim of INTEGRATION.md).
+//
+// Decomposition = the reference's task bisection (_mapreduce_threaded!, src/mapreduce.jl:195-227)
+// applied across ranks by smr_shard: maps split the slowest destination dim (disjoint slabs, no
+// collective); reductions split a kept dim when one is long enough (no collective), otherwise a
+// reduced dim, and the per-rank partial destinations are combined by ONE ncclAllReduce -- the
+// distributed form of the reference's per-task partial slots + fold (:153-170).  `initop` and the
+// existing destination content enter exactly once (rank 0); the other ranks start from the
+// neutral element.
+//
+// RCCL is loaded lazily with dlopen (no link-time dependency; a single-GPU user never needs it).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "smr_internal.h"
+
+namespace smr {
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    bool tried = false;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+struct CommState {
+    std::mutex mu;
+    Rccl r;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    void* staging = nullptr;  // dense buffer for strided destinations (grow-only)
+    size_t staging_bytes = 0;
+};
+CommState& st() {
+    static CommState s;
+    return s;
+}
+
+int load_rccl() {
+    Rccl& r = st().r;
+    if (r.tried) return r.lib ? SMR_OK : set_error(SMR_EUNSUPPORTED, "librccl.so is not available");
+    r.tried = true;
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return set_error(SMR_EUNSUPPORTED, "librccl.so is not available");
+    r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.lib, "ncclGetUniqueId");
+    r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(r.lib, "ncclCommInitRank");
+    r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.lib, "ncclCommDestroy");
+    r.all_reduce = (decltype(r.all_reduce))dlsym(r.lib, "ncclAllReduce");
+    r.error_string = (decltype(r.error_string))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce) {
+        dlclose(r.lib);
+        r.lib = nullptr;
+        return set_error(SMR_EUNSUPPORTED, "librccl.so lacks a required symbol");
+    }
+    return SMR_OK;
+}
+
+int nccl_error(ncclResult_t e, const char* what) {
+    Rccl& r = st().r;
+    return set_error(SMR_EHIP, std::string(what) + ": " + (r.error_string ? r.error_string(e) : "RCCL error"));
+}
+
+// element type / count as RCCL sees a destination of `n` elements of `dtype`
+bool nccl_type(int dtype, int redop, ncclDataType_t* t, size_t* mult) {
+    *mult = 1;
+    switch (dtype) {
+        case SMR_F32: *t = ncclFloat32; return true;
+        case SMR_F64: *t = ncclFloat64; return true;
+        case SMR_C32: *t = ncclFloat32; *mult = 2; return redop == SMR_RED_ADD;  // sums are component-wise
+        case SMR_C64: *t = ncclFloat64; *mult = 2; return redop == SMR_RED_ADD;
+        case SMR_I8: *t = ncclInt8; return true;
+        case SMR_U8: *t = ncclUint8; return true;
+        case SMR_I32: *t = ncclInt32; return true;
+        case SMR_U32: *t = ncclUint32; return true;
+        case SMR_I64: *t = ncclInt64; return true;
+        case SMR_U64: *t = ncclUint64; return true;
+    }
+    return false;
+}
+
+// the distinct destination elements of a reduction as an operand of a map: stride-0 dims -> extent 1
+void kept_box(const smr_problem* p, int64_t* dims, int64_t* count) {
+    *count = 1;
+    for (int i = 0; i < p->N; ++i) {
+        dims[i] = p->ops[0].strides[i] == 0 ? 1 : p->dims[i];
+        *count *= dims[i];
+    }
+}
+
+int fill_neutral(const smr_problem* p) {
+    smr_problem f;
+    std::memset(&f, 0, sizeof f);
+    int64_t cnt;
+    f.N = p->N;
+    f.M = 1;
+    kept_box(p, f.dims, &cnt);
+    f.ops[0] = p->ops[0];
+    static const uint8_t code[2] = {SMR_OP_CONST, 0};
+    double c[2] = {0, 0};
+    if (p->redop == SMR_RED_MUL) c[0] = 1;
+    if (p->redop == SMR_RED_MIN) c[0] = __builtin_huge_val();
+    if (p->redop == SMR_RED_MAX) c[0] = -__builtin_huge_val();
+    f.fprog = code;
+    f.fprog_len = 1;
+    f.fconsts = c;
+    f.nconsts = 1;
+    f.redop = SMR_RED_NONE;
+    f.stream = p->stream;
+    // dims of extent 1 keep the destination's (zero) stride harmlessly; a pure map needs non-zero ones
+    for (int i = 0; i < f.N; ++i)
+        if (f.ops[0].strides[i] == 0) f.ops[0].strides[i] = 1;
+    return smr_mapreduce(&f);
+}
+
+// dense <-> strided copy of the kept destination elements (dir 0: gather into staging, 1: scatter back)
+int copy_kept(const smr_problem* p, void* dense, int dir) {
+    smr_problem c;
+    std::memset(&c, 0, sizeof c);
+    int64_t cnt;
+    c.N = p->N;
+    c.M = 2;
+    kept_box(p, c.dims, &cnt);
+    smr_operand view = p->ops[0];
+    view.conj = 0;  // raw element moves: the stored representation is what gets reduced ...
+    smr_operand flat;
+    std::memset(&flat, 0, sizeof flat);
+    flat.base = dense;
+    flat.dtype = p->ops[0].dtype;
+    int64_t s = 1;
+    for (int i = 0; i < c.N; ++i) {
+        flat.strides[i] = s;
+        s *= c.dims[i];
+        if (view.strides[i] == 0) view.strides[i] = 1;  // extent-1 dims
+    }
+    c.ops[0] = dir == 0 ? flat : view;
+    c.ops[1] = dir == 0 ? view : flat;
+    c.redop = SMR_RED_NONE;
+    c.stream = p->stream;
+    return smr_mapreduce(&c);
+}
+
+}  // namespace
+}  // namespace smr
+
+using namespace smr;
+
+int smr_comm_unique_id(void* out, size_t len) {
+    if (!out || len < NCCL_UNIQUE_ID_BYTES) return set_error(SMR_EINVAL, "unique id buffer must hold 128 bytes");
+    std::lock_guard<std::mutex> g(st().mu);
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t e = st().r.get_unique_id(&id);
+    if (e != ncclSuccess) return nccl_error(e, "ncclGetUniqueId");
+    std::memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return SMR_OK;
+}
+
+int smr_comm_init(int nranks, int rank, const void* unique_id, size_t len) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(SMR_EINVAL, "bad rank / nranks");
+    std::lock_guard<std::mutex> g(st().mu);
+    CommState& s = st();
+    if (s.comm) return set_error(SMR_EINVAL, "communicator already initialised (smr_comm_destroy first)");
+    s.nranks = nranks;
+    s.rank = rank;
+    if (nranks == 1 && !unique_id) return SMR_OK;  // single rank: nothing to set up
+    if (!unique_id || len < NCCL_UNIQUE_ID_BYTES) return set_error(SMR_EINVAL, "unique id (128 bytes, from rank 0's smr_comm_unique_id) required");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    std::memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+    ncclResult_t e = s.r.comm_init_rank(&s.comm, nranks, id, rank);
+    if (e != ncclSuccess) {
+        s.comm = nullptr;
+        s.nranks = 1;
+        s.rank = 0;
+        return nccl_error(e, "ncclCommInitRank");
+    }
+    return SMR_OK;
+}
+
+int smr_comm_rank(int* rank, int* nranks) {
+    std::lock_guard<std::mutex> g(st().mu);
+    if (rank) *rank = st().rank;
+    if (nranks) *nranks = st().nranks;
+    return SMR_OK;
+}
+
+int smr_comm_destroy(void) {
+    std::lock_guard<std::mutex> g(st().mu);
+    CommState& s = st();
+    if (s.comm && s.r.comm_destroy) (void)s.r.comm_destroy(s.comm);
+    s.comm = nullptr;
+    s.nranks = 1;
+    s.rank = 0;
+    if (s.staging) (void)hipFree(s.staging);
+    s.staging = nullptr;
+    s.staging_bytes = 0;
+    return SMR_OK;
+}
+
+int smr_mapreduce_sharded(const smr_problem* p) {
+    if (!p) return set_error(SMR_EINVAL, "null problem");
+    CommState& s = st();
+    int nranks, rank;
+    {
+        std::lock_guard<std::mutex> g(s.mu);
+        nranks = s.nranks;
+        rank = s.rank;
+    }
+    if (nranks == 1) return smr_mapreduce(p);
+    smr_problem sub;
+    int need = 0;
+    int rc = smr_shard(p, nranks, rank, &sub, &need);
+    if (rc) return rc;
+    if (!need) return smr_mapreduce(&sub);
+    ncclDataType_t t;
+    size_t mult;
+    if (!nccl_type(p->ops[0].dtype, p->redop, &t, &mult))
+        return set_error(SMR_EUNSUPPORTED, "this destination type / reduction has no RCCL all-reduce");
+    if (rank != 0) {
+        rc = fill_neutral(p);
+        if (rc) return rc;
+    }
+    rc = smr_mapreduce(&sub);
+    if (rc) return rc;
+    int64_t kd[SMR_MAXN], count;
+    kept_box(p, kd, &count);
+    const size_t bytes = (size_t)count * (size_t)dtype_size(p->ops[0].dtype);
+    std::lock_guard<std::mutex> g(s.mu);
+    if (!s.comm) return set_error(SMR_EINVAL, "smr_comm_init has not been called");
+    if (bytes > s.staging_bytes) {
+        if (s.staging) {
+            (void)hipStreamSynchronize((hipStream_t)p->stream);
+            (void)hipFree(s.staging);
+            s.staging = nullptr;
+        }
+        hipError_t e = hipMalloc(&s.staging, bytes);
+        if (e != hipSuccess) return hip_error(e, "hipMalloc(all-reduce staging)");
+        s.staging_bytes = bytes;
+    }
+    rc = copy_kept(p, s.staging, 0);
+    if (rc) return rc;
+    static const ncclRedOp_t ops[] = {ncclSum, ncclSum, ncclProd, ncclMin, ncclMax};
+    ncclResult_t e = s.r.all_reduce(s.staging, s.staging, (size_t)count * mult, t, ops[p->redop], s.comm, (hipStream_t)p->stream);
+    if (e != ncclSuccess) return nccl_error(e, "ncclAllReduce");
+    return copy_kept(p, s.staging, 1);
+}

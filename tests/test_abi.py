@@ -188,3 +188,17 @@ def test_shard_follows_the_reference_offset_arithmetic():
     o, a = _views((64, 50), [(1, 0), (1, 64)])
     sdims, _, need, _ = D.shard(lambda v: v, "+", None, (64, 50), (o, a), 4, 1)
     assert not need and sdims == (16, 50)
+
+
+def test_comm_entry_points_without_a_communicator():
+    """The C-level multi-GPU entry points (csrc/smr_comm.cpp): argument checking and the
+    single-rank degenerate case need neither RCCL nor a device."""
+    lib = L.load()
+    rank, n = C.c_int(-1), C.c_int(-1)
+    assert lib.smr_comm_rank(C.byref(rank), C.byref(n)) == L.SMR_OK and (rank.value, n.value) == (0, 1)
+    assert lib.smr_comm_init(0, 0, None, 0) == L.SMR_EINVAL
+    assert lib.smr_comm_init(2, 2, None, 0) == L.SMR_EINVAL
+    assert lib.smr_comm_init(2, 0, None, 0) == L.SMR_EINVAL          # more than one rank needs the unique id
+    assert lib.smr_comm_init(1, 0, None, 0) == L.SMR_OK              # one rank: nothing to set up
+    assert lib.smr_comm_destroy() == L.SMR_OK
+    assert lib.smr_comm_unique_id(None, 0) == L.SMR_EINVAL

@@ -249,6 +249,33 @@ def test_partial_reductions_vectorised_forms_match_the_general_kernel_and_numpy(
         assert _isapprox(got, truth + 3.0, tol), f"{shape} dims={dims} {np.dtype(T).name}: {d}"
 
 
+def test_c_level_comm_single_rank_roundtrip():
+    """smr_comm_*: a real one-rank RCCL communicator on the GPU box; smr_mapreduce_sharded then
+    equals smr_mapreduce (the multi-rank decomposition itself is covered by the 2-rank gloo test
+    of the Python twin, tests/test_distributed_cpu.py)."""
+    import ctypes as C
+    from strided_jl_amd import _lib as L
+    lib = L.load()
+    uid = C.create_string_buffer(128)
+    L.check(lib.smr_comm_unique_id(uid, 128))
+    assert any(uid.raw), "ncclGetUniqueId returned zeros"
+    L.check(lib.smr_comm_init(1, 0, uid, 128))
+    try:
+        rank, n = C.c_int(-1), C.c_int(-1)
+        lib.smr_comm_rank(C.byref(rank), C.byref(n))
+        assert (rank.value, n.value) == (0, 1)
+        rng = np.random.default_rng(9)
+        a = cases._rand(rng, (33, 20, 17), np.float64)
+        A = dview(a)
+        out = A.similar(size=(33, 1, 1))
+        S.copyto_(out, 2.0)
+        p, keep = S.build_problem(S.fn.abs2, "+", "identity", A.size, S.promoteshape(A.size, out, A), stream=0)
+        L.check(lib.smr_mapreduce_sharded(C.byref(p)))
+        assert _isapprox(out.toarray(), (a * a).sum(axis=(1, 2), keepdims=True) + 2.0, 1e-12)
+    finally:
+        L.check(lib.smr_comm_destroy())
+
+
 def test_every_kernel_family_is_exercised():
     """Plans for representative problems pick the intended family (guards against a silent
     fallback to the generic kernel)."""
