@@ -68,7 +68,7 @@ struct OpDesc {
 template <bool WIDE>
 struct TiledArgs {
     // header + tile decode first: they arrive with the first batch of scalar loads
-    int32_t M, ng, tilelog, nstaged, base32, nt, ordmode, pad1;
+    int32_t M, ng, tilelog, nstaged, base32, nt, ordmode, nwork;  // nwork: entries of the work list (persistent form)
     int32_t staged[MAXM];  // [1 + i]: LDS slot of input i or -1 ([0] unused)
     uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
     const LaneRow<WIDE>* lanetab;  // [(operand k) * T + tid], k = 0 destination
@@ -319,10 +319,199 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE>& a, F f) {
     }
 }
 
+
+// ---- persistent, software-pipelined form ---------------------------------------------------------------
+// For grids larger than the machine holds at once.  The classic form runs one tile per workgroup
+// and its phases (table rows -> global loads -> LDS exchange -> stores) strictly one after the
+// other; with one 1024-lane workgroup per CU nothing overlaps, and every workgroup re-reads its
+// 40 KiB of lane-table rows (measured at 128^4: 24 % of all L2 read requests, 7.4 us per tile,
+// 3 TB/s of HBM traffic).  Here a workgroup stays resident, reads its table rows ONCE and walks the
+// work list with stride gridDim.x; the global loads of tile i+1 are issued right after tile i's
+// staged values have gone to LDS, so they are in flight during tile i's LDS reads, f and stores.
+// Only instantiated without bounds checks (no ragged tiled dim).
+template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
+SMR_DEV void tiled_map_pipe_body(const TiledArgs<WIDE>& a, F f) {
+    typedef typename off_t_of<WIDE>::type O;
+    typedef TVec<T, V> VT;
+    constexpr int NREP = EPL / V;
+    constexpr int NT = 1 << THRLOG;
+    constexpr int NIN_STATIC = F::NIN;
+    constexpr int NINMAX = (NIN_STATIC >= 0) ? NIN_STATIC : MAXIN;
+    constexpr int NX = NINMAX > 0 ? NINMAX : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int nin = (NIN_STATIC >= 0) ? NIN_STATIC : a.M - 1;
+    const uint32_t tid = threadIdx.x;
+
+    LaneRow<WIDE> row[NINMAX + 1];
+#pragma unroll
+    for (int k = 0; k <= NINMAX; ++k) {
+        row[k].g = 0;
+        row[k].l = 0;
+        if (k <= nin) row[k] = a.lanetab[k * NT + tid];
+    }
+
+    // work-list entry -> tile id (0xffffffff: none, and none after it for this workgroup)
+    auto tile_of = [&](uint32_t e) -> uint32_t {
+        if (e >= (uint32_t)a.nwork) return 0xffffffffu;
+        return a.ordmode == 2 ? a.ordtab[e] : e;
+    };
+    // tile id -> per-operand tile origins
+    auto origins = [&](uint32_t b, char* (&bp)[NINMAX + 1]) {
+        uint32_t tc[MAXN];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t q = fastdiv(b, a.div_m[g], a.div_s[g]);
+            tc[g] = b - q * a.ntiles[g];
+            b = q;
+        }
+#pragma unroll
+        for (int g = NG; g < MAXN; ++g) tc[g] = 0;
+        if (a.ng > NG) {
+#pragma unroll
+            for (int g = NG; g < MAXN; ++g) {
+                const uint32_t q = fastdiv(b, a.div_m[g], a.div_s[g]);
+                tc[g] = b - q * a.ntiles[g];
+                b = q;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k <= NINMAX; ++k) {
+            bp[k] = nullptr;
+            if (k <= nin) {
+                if (a.base32) {
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) o += tc[g] * a.op[k].tstep32[g];
+                    bp[k] = (char*)a.op[k].base + o;
+                } else {
+                    i64 o = 0;
+#pragma unroll
+                    for (int g = 0; g < MAXN; ++g)
+                        if (g < NG || a.ng > NG) o += (i64)tc[g] * a.tstep[k][g];
+                    bp[k] = (char*)a.op[k].base + o;
+                }
+            }
+        }
+    };
+    auto issue_loads = [&](char* const (&bp)[NINMAX + 1], VT (&x)[NX][NREP]) {
+#pragma unroll
+        for (int i = 0; i < NINMAX; ++i) {
+            if (i < nin) {
+                const OpDesc<WIDE>& d = a.op[i + 1];
+#pragma unroll
+                for (int r = 0; r < NREP; ++r) {
+                    const char* p = bp[i + 1] + (O)(row[i + 1].g + d.Gr[r]);
+                    if constexpr (V == 1) {
+                        x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
+                    } else {
+                        x[i][r] = *reinterpret_cast<const VT*>(p);
+                        if constexpr (tr<T>::cx) {
+                            if (d.conj) {
+#pragma unroll
+                                for (int h = 0; h < V; ++h) x[i][r].v[h] = cj(x[i][r].v[h]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    uint32_t e = blockIdx.x;
+    uint32_t tile = tile_of(e);
+    if (tile == 0xffffffffu) return;
+    char* bp[NINMAX + 1];
+    VT x[NX][NREP], xn[NX][NREP];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int r = 0; r < NREP; ++r)
+#pragma unroll
+            for (int h = 0; h < V; ++h) {
+                x[i][r].v[h] = T{};
+                xn[i][r].v[h] = T{};
+            }
+    origins(tile, bp);
+    issue_loads(bp, x);
+    while (true) {
+        char* const bp0 = bp[0];
+        // staged inputs of the current tile -> LDS (destination order, swizzled)
+#pragma unroll
+        for (int i = 0; i < NINMAX; ++i) {
+            if (i < nin && a.staged[i + 1] >= 0) {
+                const OpDesc<WIDE>& d = a.op[i + 1];
+                T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
+#pragma unroll
+                for (int r = 0; r < NREP; ++r)
+#pragma unroll
+                    for (int h = 0; h < V; ++h) L[row[i + 1].l ^ d.Lr[r] ^ d.Lh[h]] = x[i][r].v[h];
+            }
+        }
+        __syncthreads();
+        // next tile: its loads fly while this one is finished
+        e += gridDim.x;
+        const uint32_t next = tile_of(e);
+        const bool more = next != 0xffffffffu;
+        if (more) {
+            origins(next, bp);
+            issue_loads(bp, xn);
+        }
+        // current tile: LDS -> registers (destination order), f, store
+#pragma unroll
+        for (int i = 0; i < NINMAX; ++i) {
+            if (i < nin && a.staged[i + 1] >= 0) {
+                const T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
+#pragma unroll
+                for (int r = 0; r < NREP; ++r)
+#pragma unroll
+                    for (int h = 0; h < V; ++h) x[i][r].v[h] = L[row[0].l ^ a.Lrd[r] ^ a.Lhd[h]];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            VT out;
+#pragma unroll
+            for (int h = 0; h < V; ++h) {
+                T arg[MAXIN];
+#pragma unroll
+                for (int i = 0; i < MAXIN; ++i) {
+                    arg[i] = T{};
+                    if (i < NINMAX) arg[i] = x[i < NINMAX ? i : 0][r].v[h];
+                }
+                out.v[h] = f(arg);
+            }
+            char* p = bp0 + (O)(row[0].g + a.op[0].Gr[r]);
+            if constexpr (V == 1) {
+                store_at<T, MIXED>(p, a.op[0].dtype, a.op[0].conj, out.v[0]);
+            } else {
+                if constexpr (tr<T>::cx) {
+                    if (a.op[0].conj) {
+#pragma unroll
+                        for (int h = 0; h < V; ++h) out.v[h] = cj(out.v[h]);
+                    }
+                }
+                *reinterpret_cast<VT*>(p) = out;
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // every lane has read its LDS values before the next tile overwrites them
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) x[i][r] = xn[i][r];
+    }
+}
+
 #ifndef SMR_JIT
 template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
 __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE> a, F f) {
     tiled_map_body<T, F, MIXED, WIDE, V, EDGE, THRLOG>(a, f);
+}
+
+template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
+__global__ void __launch_bounds__(1 << THRLOG) k_tiled_map_pipe(const TiledArgs<WIDE> a, F f) {
+    tiled_map_pipe_body<T, F, MIXED, WIDE, V, THRLOG>(a, f);
 }
 
 // ---- LDS swizzle ------------------------------------------------------------------------------------
@@ -417,16 +606,38 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     constexpr int variant = (WIDE ? 2 : 0) + (V > 1 ? 1 : 0);
     const size_t lds = (size_t)t.nstaged * ((size_t)1 << t.tilelog) * sizeof(T);
     const unsigned grid_ = t.ord.empty() ? (unsigned)t.grid : (unsigned)t.ord.size();
+    // persistent, software-pipelined form when the work list is longer than the machine holds at once
+    unsigned pgrid = 0;
+    if constexpr (!EDGE) {
+        const Options& o = options();
+        if (o.tiled_persist) {
+            static const int ncu = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                (void)hipGetLastError();
+                return n;
+            }();
+            i64 wpc = std::min<i64>(2048 >> THRLOG, lds ? (i64)(160 * 1024 / lds) : 8);
+            wpc = std::max<i64>(1, std::min<i64>(wpc, 4));  // measured: 4 workgroups per CU beat 8 and 2
+            if (o.tiled_persist_wpc > 0) wpc = o.tiled_persist_wpc;
+            const i64 cap = (i64)ncu * wpc / 8 * 8;
+            if ((i64)grid_ >= cap * o.tiled_persist_min && cap >= 8) pgrid = (unsigned)cap;
+        }
+    }
     auto launch = [&](const TiledArgs<WIDE>& ka) -> int {
+        auto b2s = [](bool b) { return b ? "true" : "false"; };
         if constexpr (is_jit<F>::value) {
-            auto b2s = [](bool b) { return b ? "true" : "false"; };
             JitLaunch l;
             l.family = "tiled";
             l.tname = tname<T>();
             l.argtype = WIDE ? "smr::TiledArgs<true>" : "smr::TiledArgs<false>";
-            l.entry = std::string("smr::tiled_map_body<") + tname<T>() + ", smr::FJit, " + b2s(MIXED) + ", " + b2s(WIDE) + ", " +
-                      std::to_string(V) + ", " + b2s(EDGE) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
-            l.grid = grid_;
+            if (pgrid)
+                l.entry = std::string("smr::tiled_map_pipe_body<") + tname<T>() + ", smr::FJit, " + b2s(MIXED) + ", " + b2s(WIDE) + ", " +
+                          std::to_string(V) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
+            else
+                l.entry = std::string("smr::tiled_map_body<") + tname<T>() + ", smr::FJit, " + b2s(MIXED) + ", " + b2s(WIDE) + ", " +
+                          std::to_string(V) + ", " + b2s(EDGE) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
+            l.grid = pgrid ? pgrid : grid_;
             l.block = 1u << THRLOG;
             l.lds = lds;
             l.args = &ka;
@@ -434,8 +645,19 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             return jit_launch(c, l, s);
         } else {
             if (jit_dry_run()) return SMR_OK;
-            auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
             clear_sticky_error();
+            if constexpr (!EDGE) {
+                if (pgrid) {
+                    auto kern = k_tiled_map_pipe<T, F, MIXED, WIDE, V, THRLOG>;
+                    if (lds > 64 * 1024) {
+                        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+                    }
+                    hipLaunchKernelGGL(kern, dim3(pgrid), dim3(1u << THRLOG), lds, s, ka, f);
+                    return check_launch("k_tiled_map_pipe");
+                }
+            }
+            auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
@@ -453,6 +675,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         return launch(a);
     }
     std::memset(&a, 0, sizeof a);
+    a.nwork = (int32_t)grid_;
     if (!t.ord.empty() && t.ord.size() <= (size_t)NORD16 && t.grid < 0xffff) {
         a.ordmode = 1;
         for (size_t i = 0; i < t.ord.size(); ++i) {

@@ -2,11 +2,11 @@
 # PMC passes (one counter group per run, no tracing domains besides the kernel trace) for the
 # headline kernels.  Usage on the GPU box: bash tools/pmc_passes.sh <outdir> [which]
 set -u
-OUT=${1:-gpurun_out/prof}; WHICH=${2:-both}
+OUT=${1:-gpurun_out/prof}; WHICH=${2:-both}; NN=${3:-32}; ITERS=${4:-20}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/$OUT
-run() { name=$1; shift; timeout 90 rocprofv3 --pmc "$@" -d $R/$OUT/$name -o $name -- python $R/tools/prof_headline.py --which $WHICH --iters 20 > $R/$OUT/$name.log 2>&1; }
+run() { name=$1; shift; timeout 90 rocprofv3 --pmc "$@" -d $R/$OUT/$name -o $name -- python $R/tools/prof_headline.py --which $WHICH --iters $ITERS --n $NN > $R/$OUT/$name.log 2>&1; }
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 run tcc1 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 run tcc2 TCC_EA0_WRREQ_sum TCC_WRITE_sum TCC_READ_sum TCC_TAG_STALL_sum
