@@ -251,9 +251,15 @@ int smr_comm_rank(int* rank, int* nranks);
 int smr_comm_destroy(void);
 int smr_mapreduce_sharded(const smr_problem* problem);
 
-/* Tuning knobs (name = "tile_log2", "block_threads", "force_family", ...); returns
- * SMR_EINVAL for unknown names.  Analogue of the reference's compile-time constants
- * MINTHREADLENGTH / BLOCKMEMORYSIZE (src/mapreduce.jl:141,462).                          */
+/* Tuning knobs; smr_set_option returns SMR_EINVAL for unknown names.  Analogue of the
+ * reference's compile-time constants MINTHREADLENGTH / BLOCKMEMORYSIZE
+ * (src/mapreduce.jl:141,462).  Names: "force_family" (0 auto, 1 generic, 3 tiled),
+ * "tile_log2" (0 auto, 10, 12), "tile_lg0".."tile_lg7" (per-dim log2 tile extent, -1 auto),
+ * "tiled_vec", "max_lds_bytes", "tile_order" (orbit-major tile order on/off),
+ * "tiled_persist" / "tiled_persist_wpc" / "tiled_persist_min" (persistent pipelined form),
+ * "reduce_blocks", "reduce_part_kind" (-1 auto, 0 general, 1 row, 2 col), "reduce_col_txlog",
+ * "reduce_part_wgs", "jit" (runtime compilation of f on/off).  Read-only counters through
+ * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms".             */
 int smr_set_option(const char* name, int64_t value);
 int64_t smr_get_option(const char* name);
 

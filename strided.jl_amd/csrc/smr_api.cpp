@@ -388,8 +388,6 @@ int smr_set_option(const char* name, int64_t value) {
     bool ok = true;
     if (n == "force_family") o.force_family = value;
     else if (n == "tile_log2") o.tile_log2 = value;
-    else if (n == "block_threads") o.block_threads = value;
-    else if (n == "stream_unroll") o.stream_unroll = value;
     else if (n == "tile_order") o.tile_order = value;
     else if (n == "reduce_blocks") o.reduce_blocks = value;
     else if (n == "jit") o.jit = value;
@@ -417,8 +415,6 @@ int64_t smr_get_option(const char* name) {
     std::string n(name);
     if (n == "force_family") return o.force_family;
     if (n == "tile_log2") return o.tile_log2;
-    if (n == "block_threads") return o.block_threads;
-    if (n == "stream_unroll") return o.stream_unroll;
     if (n == "tile_order") return o.tile_order;
     if (n == "reduce_blocks") return o.reduce_blocks;
     if (n == "jit") return o.jit;

@@ -155,9 +155,6 @@ struct Plan {
 struct Options {
     i64 force_family = 0;
     i64 tile_log2 = 0;       // 0 = planner default
-    i64 block_threads = 256;
-    i64 stream_unroll = 4;
-    i64 tiled_minrun_bytes = 64;
     i64 tile_order = 1;      // orbit-major tile order for inputs that are permuted views of one buffer
     i64 jit = 1;             // compile unrecognised f-programs with hiprtc (0 = always interpret)
     i64 reduce_col_txlog = 5;   // COL form: log2 of the lanes along kept dim 0 (cap)
