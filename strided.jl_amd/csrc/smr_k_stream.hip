@@ -65,7 +65,7 @@ SMR_DEV void stream_map_body(const StreamArgs& a, F f) {
 #pragma unroll
                         for (int e = 0; e < V; ++e) in[u][k].v[e] = s;
                     } else if constexpr (MIXED || V == 1) {
-                        in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, roff[k + 1] + col[u]);
+                        in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, roff[k + 1] + col[u] * a.strides[k + 1][0]);
                     } else {
                         in[u][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + roff[k + 1] + col[u] * V);
                         if constexpr (tr<T>::cx) {
@@ -94,7 +94,7 @@ SMR_DEV void stream_map_body(const StreamArgs& a, F f) {
                 out.v[e] = f(x);
             }
             if constexpr (MIXED || V == 1) {
-                store_op<T, MIXED>(a.ops, roff[0] + col[u], out.v[0]);
+                store_op<T, MIXED>(a.ops, roff[0] + col[u] * a.strides[0][0], out.v[0]);
             } else {
                 if constexpr (tr<T>::cx) {
                     if (a.ops.conj[0]) {
@@ -156,7 +156,16 @@ template <class T, class F>
 static int go_vec(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     constexpr int VMAX = (sizeof(T) >= 16) ? 1 : (int)(16 / sizeof(T));
     if constexpr (VMAX > 1) {
-        if (plan.vec == VMAX) return go<T, F, false, VMAX>(plan, bases, s, f);
+        if (plan.vec == VMAX) {
+            // the plan chose vectors for the pointers it was created with; re-check rebound ones
+            bool aligned = true;
+            if (bases) {
+                const OpTab tab = make_optab(plan.c, bases);
+                for (int k = 0; k < plan.c.M; ++k)
+                    if (plan.c.strides[k][0] != 0 && ((uintptr_t)tab.base[k]) % 16) aligned = false;
+            }
+            if (aligned) return go<T, F, false, VMAX>(plan, bases, s, f);
+        }
     }
     return go<T, F, false, 1>(plan, bases, s, f);
 }

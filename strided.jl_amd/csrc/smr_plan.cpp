@@ -637,6 +637,11 @@ int make_plan(const smr_problem* p, Plan& plan) {
             fam = FAM_STREAM;
         } else if (plan_tiles(c, plan.tile)) {
             fam = FAM_TILED;
+        } else if (c.dims[0] >= 64) {
+            // strided along dim 0 (A[1:2:end, :], a destination that is itself a strided view):
+            // still one row segment per workgroup with the outer dims decoded once per
+            // workgroup; element-wise (non-vector) accesses with the operand's own stride
+            fam = FAM_STREAM;
         }
     } else {
         fam = (c.NK == 0) ? FAM_REDUCE_ALL : FAM_REDUCE_PART;
@@ -649,6 +654,8 @@ int make_plan(const smr_problem* p, Plan& plan) {
         // vector width: 16 B per lane when every unit-stride operand stays 16-B aligned
         const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
         int v = (c.mixed || es >= 16) ? 1 : 16 / es;
+        for (int k = 0; k < c.M; ++k)
+            if (c.strides[k][0] != 1 && c.strides[k][0] != 0) v = 1;  // strided form
         while (v > 1) {
             bool ok = c.dims[0] % v == 0;
             for (int k = 0; k < c.M && ok; ++k) {

@@ -276,6 +276,44 @@ def test_c_level_comm_single_rank_roundtrip():
         L.check(lib.smr_comm_destroy())
 
 
+@pytest.mark.parametrize("T", [np.float32, np.complex128, np.int16])
+def test_strided_rows_take_the_stream_family(T):
+    """Views with a step along the fastest dim (A[1:2:end, :], reversed ranges, a destination that
+    is itself a strided view) run in the STREAM family's element-wise form, not in the
+    one-thread-per-element fallback; results equal NumPy exactly."""
+    import torch
+    rng = np.random.default_rng(23)
+    a = cases._rand(rng, (400, 37, 5), T) if T != np.int16 else rng.integers(-1000, 1000, (400, 37, 5)).astype(T)
+    b = cases._rand(rng, (200, 37, 5), T) if T != np.int16 else rng.integers(-1000, 1000, (200, 37, 5)).astype(T)
+    A, B = dview(a), dview(b)
+    D = dview(np.zeros((200, 37, 5), dtype=T))
+    src = A.sview(slice(1, 400, 2), slice(None), slice(None))
+    rev = B.sview(slice(199, None, -1), slice(None), slice(None))
+    if T == np.int16:
+        S.copy_(D, src)
+        d = S.make_plan(lambda x: x, None, None, D.size, (D, src)).describe()
+        assert "family=stream" in d and "vec=1" in d
+        torch.cuda.synchronize()
+        assert np.array_equal(D.toarray(), a[1::2])
+        S.copy_(D, rev)
+        torch.cuda.synchronize()
+        assert np.array_equal(D.toarray(), b[::-1])
+        return
+    D.assign(src * 2 + rev)
+    d = S.make_plan(lambda x, y: x * 2 + y, None, None, D.size, (D, src, rev)).describe()
+    assert "family=stream" in d and "vec=1" in d, d
+    torch.cuda.synchronize()
+    assert np.array_equal(D.toarray(), a[1::2] * 2 + b[::-1])
+    # strided destination: every third row of a bigger array
+    big = dview(np.zeros((600, 37, 5), dtype=T))
+    dst = big.sview(slice(0, 600, 3), slice(None), slice(None))
+    dst.assign(B - src)
+    torch.cuda.synchronize()
+    want = np.zeros((600, 37, 5), dtype=T)
+    want[0::3] = b - a[1::2]
+    assert np.array_equal(big.toarray(), want)
+
+
 def test_every_kernel_family_is_exercised():
     """Plans for representative problems pick the intended family (guards against a silent
     fallback to the generic kernel)."""
