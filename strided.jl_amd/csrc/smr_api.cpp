@@ -44,7 +44,10 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
     switch (plan.family) {
         case FAM_GENERIC: return launch_generic_map(plan, bases, s);
         case FAM_STREAM: return launch_stream_map(plan, bases, s);
-        case FAM_TILED: return launch_tiled_map(plan, bases, s);
+        case FAM_TILED: {
+            std::lock_guard<std::mutex> g(*plan.build_mu);
+            return launch_tiled_map(plan, bases, s);
+        }
         case FAM_REDUCE_ALL: return launch_reduce_all(plan, bases, s);
         case FAM_REDUCE_PART: return launch_reduce_part(plan, bases, s);
     }
@@ -97,6 +100,7 @@ static int plan_build(const smr_problem* p, smr_plan** out) {
 
 // reduction partials are allocated on first execution (planning itself needs no device)
 static int ensure_scratch(smr_plan* h) {
+    std::lock_guard<std::mutex> g(*h->plan.build_mu);
     if (h->plan.scratch || h->plan.scratch_bytes == 0 || h->plan.red_blocks <= 1) return SMR_OK;
     hipError_t e = hipMalloc(&h->plan.scratch, h->plan.scratch_bytes);
     if (e != hipSuccess) return hip_error(e, "hipMalloc(reduction partials)");

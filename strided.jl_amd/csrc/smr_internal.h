@@ -7,6 +7,8 @@
 #ifndef SMR_JIT
 #include <hip/hip_runtime.h>
 
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -146,6 +148,9 @@ struct Plan {
     int part_xsplit = 1, part_qsplit = 1;  // split of the inner / outer reduced range over workgroups
     // TILED: per-lane index tables in device memory, one per kernel variant (built on first use)
     mutable void* lanetab[4] = {nullptr, nullptr, nullptr, nullptr};
+    // first execution builds the tables below; concurrent executions of one (cached) plan from
+    // several host threads serialise on this
+    mutable std::shared_ptr<std::mutex> build_mu = std::make_shared<std::mutex>();
     mutable void* ordtab = nullptr;  // TILED: tile-order table in device memory (large grids)
     mutable std::vector<unsigned char> tiled_args[4];  // fully built kernel arguments per variant
     std::string desc;
