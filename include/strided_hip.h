@@ -90,7 +90,9 @@ typedef enum {
     SMR_RED_ADD = 1, /* +, Base.add_sum */
     SMR_RED_MUL = 2, /* *, Base.mul_prod */
     SMR_RED_MIN = 3,
-    SMR_RED_MAX = 4
+    SMR_RED_MAX = 4,
+    SMR_RED_AND = 5, /* &: both operands non-zero -> 1, else 0 (neutral element true, :188)  */
+    SMR_RED_OR = 6   /* |  (neutral element false, :189)                                     */
 } smr_redop;
 
 /* `initop`, applied once to each destination element before accumulation.  These are

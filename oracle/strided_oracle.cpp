@@ -489,6 +489,8 @@ struct RedOp {
             case SMR_RED_MUL: return ops<T>::bin(SMR_OP_MUL, a, b);
             case SMR_RED_MIN: return ops<T>::bin(SMR_OP_MIN, a, b);
             case SMR_RED_MAX: return ops<T>::bin(SMR_OP_MAX, a, b);
+            case SMR_RED_AND: return make<T>((ops<T>::truthy(a) && ops<T>::truthy(b)) ? 1 : 0, 0);
+            case SMR_RED_OR: return make<T>((ops<T>::truthy(a) || ops<T>::truthy(b)) ? 1 : 0, 0);
         }
         return b;
     }
@@ -827,6 +829,8 @@ int run_typed(const smr_problem* p, const Lowered& L, const Prog& prog, int nthr
         switch (p->redop) {
             case SMR_RED_ADD: neutral = make<T>(R(0), R(0)); break;
             case SMR_RED_MUL: neutral = make<T>(R(1), R(0)); break;
+            case SMR_RED_AND: neutral = make<T>(R(1), R(0)); break;  // true, :188
+            case SMR_RED_OR: neutral = make<T>(R(0), R(0)); break;   // false, :189
             default: neutral = a; break;  // min / max: fill with a
         }
         for (auto& v : threadedout) v = neutral;

@@ -23,7 +23,7 @@ SMR_OK, SMR_EINVAL, SMR_EUNSUPPORTED, SMR_EHIP, SMR_ENOMEM, SMR_ENODEVICE = 0, -
  SMR_U8, SMR_U16, SMR_U32, SMR_U64) = range(12)
 
 # smr_redop / smr_initop
-SMR_RED_NONE, SMR_RED_ADD, SMR_RED_MUL, SMR_RED_MIN, SMR_RED_MAX = range(5)
+SMR_RED_NONE, SMR_RED_ADD, SMR_RED_MUL, SMR_RED_MIN, SMR_RED_MAX, SMR_RED_AND, SMR_RED_OR = range(7)
 (SMR_INIT_NONE, SMR_INIT_IDENTITY, SMR_INIT_ZERO, SMR_INIT_SCALE, SMR_INIT_CONST,
  SMR_INIT_CONJ) = range(6)
 

@@ -109,7 +109,7 @@ int fill_neutral(const smr_problem* p) {
     f.ops[0] = p->ops[0];
     static const uint8_t code[2] = {SMR_OP_CONST, 0};
     double c[2] = {0, 0};
-    if (p->redop == SMR_RED_MUL) c[0] = 1;
+    if (p->redop == SMR_RED_MUL || p->redop == SMR_RED_AND) c[0] = 1;
     if (p->redop == SMR_RED_MIN) c[0] = __builtin_huge_val();
     if (p->redop == SMR_RED_MAX) c[0] = -__builtin_huge_val();
     f.fprog = code;
@@ -173,9 +173,11 @@ int smr_comm_init(int nranks, int rank, const void* unique_id, size_t len) {
     std::lock_guard<std::mutex> g(st().mu);
     CommState& s = st();
     if (s.comm) return set_error(SMR_EINVAL, "communicator already initialised (smr_comm_destroy first)");
-    s.nranks = nranks;
-    s.rank = rank;
-    if (nranks == 1 && !unique_id) return SMR_OK;  // single rank: nothing to set up
+    if (nranks == 1 && !unique_id) {  // single rank: nothing to set up
+        s.nranks = 1;
+        s.rank = 0;
+        return SMR_OK;
+    }
     if (!unique_id || len < NCCL_UNIQUE_ID_BYTES) return set_error(SMR_EINVAL, "unique id (128 bytes, from rank 0's smr_comm_unique_id) required");
     int rc = load_rccl();
     if (rc) return rc;
@@ -184,10 +186,10 @@ int smr_comm_init(int nranks, int rank, const void* unique_id, size_t len) {
     ncclResult_t e = s.r.comm_init_rank(&s.comm, nranks, id, rank);
     if (e != ncclSuccess) {
         s.comm = nullptr;
-        s.nranks = 1;
-        s.rank = 0;
         return nccl_error(e, "ncclCommInitRank");
     }
+    s.nranks = nranks;
+    s.rank = rank;
     return SMR_OK;
 }
 
@@ -253,7 +255,7 @@ int smr_mapreduce_sharded(const smr_problem* p) {
     }
     rc = copy_kept(p, s.staging, 0);
     if (rc) return rc;
-    static const ncclRedOp_t ops[] = {ncclSum, ncclSum, ncclProd, ncclMin, ncclMax};
+    static const ncclRedOp_t ops[] = {ncclSum, ncclSum, ncclProd, ncclMin, ncclMax, ncclMin /* & on 0/1 */, ncclMax /* | on 0/1 */};
     ncclResult_t e = s.r.all_reduce(s.staging, s.staging, (size_t)count * mult, t, ops[p->redop], s.comm, (hipStream_t)p->stream);
     if (e != ncclSuccess) return nccl_error(e, "ncclAllReduce");
     return copy_kept(p, s.staging, 1);

@@ -362,6 +362,8 @@ SMR_DEV T red_apply(int op, T a, T b) {
             case SMR_RED_MUL: return a * b;
             case SMR_RED_MIN: return mathx<T>::bin(SMR_OP_MIN, a, b);
             case SMR_RED_MAX: return mathx<T>::bin(SMR_OP_MAX, a, b);
+            case SMR_RED_AND: return mk<T>((mathx<T>::truthy(a) && mathx<T>::truthy(b)) ? typename tr<T>::real(1) : typename tr<T>::real(0), typename tr<T>::real(0));
+            case SMR_RED_OR: return mk<T>((mathx<T>::truthy(a) || mathx<T>::truthy(b)) ? typename tr<T>::real(1) : typename tr<T>::real(0), typename tr<T>::real(0));
         }
     }
     return b;

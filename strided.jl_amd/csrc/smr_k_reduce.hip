@@ -41,6 +41,7 @@ SMR_DEV T neutral(int op) {
     typedef typename tr<T>::real R;
     switch (op) {
         case SMR_RED_MUL: return mk<T>(R(1), R(0));
+        case SMR_RED_AND: return mk<T>(R(1), R(0));
         case SMR_RED_MIN: return mk<T>(R(__builtin_huge_val()), R(0));
         case SMR_RED_MAX: return mk<T>(R(-__builtin_huge_val()), R(0));
     }

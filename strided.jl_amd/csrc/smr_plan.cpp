@@ -122,7 +122,7 @@ int canonicalise(const smr_problem* p, Canon& c) {
         if (!p->ops[k].base) return set_error(SMR_EINVAL, "null operand base pointer");
         if (dtype_size(p->ops[k].dtype) == 0) return set_error(SMR_EINVAL, "bad operand dtype");
     }
-    if (p->redop < SMR_RED_NONE || p->redop > SMR_RED_MAX) return set_error(SMR_EINVAL, "bad redop");
+    if (p->redop < SMR_RED_NONE || p->redop > SMR_RED_OR) return set_error(SMR_EINVAL, "bad redop");
     if (p->initop < SMR_INIT_NONE || p->initop > SMR_INIT_CONJ) return set_error(SMR_EINVAL, "bad initop");
     if (p->redop == SMR_RED_NONE && p->initop != SMR_INIT_NONE)
         return set_error(SMR_EINVAL, "initop requires a reduction op (src/mapreduce.jl:310-316)");

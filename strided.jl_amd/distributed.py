@@ -46,7 +46,8 @@ def shard(f, op, initop, dims, arrays, nshards: int, index: int):
 def _torch_reduce_op(op):
     import torch.distributed as dist
     return {L.SMR_RED_ADD: dist.ReduceOp.SUM, L.SMR_RED_MUL: dist.ReduceOp.PRODUCT,
-            L.SMR_RED_MIN: dist.ReduceOp.MIN, L.SMR_RED_MAX: dist.ReduceOp.MAX}[_redop_code(op)]
+            L.SMR_RED_MIN: dist.ReduceOp.MIN, L.SMR_RED_MAX: dist.ReduceOp.MAX,
+            L.SMR_RED_AND: dist.ReduceOp.MIN, L.SMR_RED_OR: dist.ReduceOp.MAX}[_redop_code(op)]
 
 
 def _as_tensor(view: StridedView):

@@ -22,6 +22,8 @@ _REDOPS = {
     "+": L.SMR_RED_ADD, "add": L.SMR_RED_ADD, "add_sum": L.SMR_RED_ADD, operator.add: L.SMR_RED_ADD,
     "*": L.SMR_RED_MUL, "mul": L.SMR_RED_MUL, "mul_prod": L.SMR_RED_MUL, operator.mul: L.SMR_RED_MUL,
     "min": L.SMR_RED_MIN, min: L.SMR_RED_MIN, "max": L.SMR_RED_MAX, max: L.SMR_RED_MAX,
+    "&": L.SMR_RED_AND, "and": L.SMR_RED_AND, operator.and_: L.SMR_RED_AND,
+    "|": L.SMR_RED_OR, "or": L.SMR_RED_OR, operator.or_: L.SMR_RED_OR,
 }
 
 
@@ -208,8 +210,10 @@ def _neutral(op, dtype):
     code = _redop_code(op)
     if code == L.SMR_RED_ADD:
         return 0
-    if code == L.SMR_RED_MUL:
-        return 1
+    if code in (L.SMR_RED_MUL, L.SMR_RED_AND):
+        return 1  # one / true (src/mapreduce.jl:185,188)
+    if code == L.SMR_RED_OR:
+        return 0  # false (:189)
     if np.issubdtype(dtype, np.integer):
         info = np.iinfo(dtype)
         return info.max if code == L.SMR_RED_MIN else info.min
@@ -228,6 +232,8 @@ def _reduced_dtype(e, op, A):
         # Base.mapreduce_first)
         if _redop_code(op) in (L.SMR_RED_ADD, L.SMR_RED_MUL):
             T = np.dtype(np.int64)
+    if _redop_code(op) in (L.SMR_RED_AND, L.SMR_RED_OR):
+        T = np.dtype(np.bool_)
     return T
 
 
