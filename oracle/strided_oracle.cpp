@@ -378,12 +378,18 @@ void computeblocks(const i64* dims, const i64* costs, const i64 (*bytestrides)[M
         for (int i = first; i < N; ++i) w[i - first] = (b[i] - 1) * costs[i];
         return first + lastargmax(w, N - first);
     };
+    // Termination guard (not in the reference): `costs` come from the SIGNED minimum stride (:137),
+    // so with reversed ranges (negative strides) every candidate weight can be <= 0 and the
+    // arg-max lands on a dim whose block is already 1 -- the reference's loops would then spin
+    // forever (:491-498).  Blocking only affects the traversal order, so the oracle stops there.
     while (totalmemoryregion(b, N, bytestrides, M, first) >= 2 * BLOCKMEMORYSIZE) {  // :491-494
         int i = pick();
+        if (b[i] <= 1) break;
         b[i] = (b[i] + 1) >> 1;
     }
     while (totalmemoryregion(b, N, bytestrides, M, first) > BLOCKMEMORYSIZE) {  // :495-498
         int i = pick();
+        if (b[i] <= 1) break;
         b[i] = b[i] - 1;
     }
     for (int i = first; i < N; ++i) blocks[i] = b[i];
