@@ -20,7 +20,7 @@ struct GenArgs {
 };
 
 template <class T, class F, bool MIXED>
-SMR_DEV void generic_map_body(const GenArgs& a, F f) {
+SMR_DEV void generic_map_body(const GenArgs a, F f) {
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     const i64 step = (i64)gridDim.x * 256;
     const bool small = a.total <= 0x7fffffffLL;

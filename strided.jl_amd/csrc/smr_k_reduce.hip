@@ -91,7 +91,7 @@ struct alignas(sizeof(T) * V) RVec {
 };
 
 template <class T, class F, bool MIXED, int V>
-SMR_DEV void reduce_all_body(const RedArgs& a, F f) {
+SMR_DEV void reduce_all_body(const RedArgs a, F f) {
     __shared__ T wsum[4];
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     constexpr int ACC = 4;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_reduce_final(RedArgs a) {
 // are consecutive threads, so when the inputs' unit-stride axis is a reduced dim the loads
 // coalesce; with TR == 1 consecutive threads own consecutive destination elements instead.
 template <class T, class F, bool MIXED>
-SMR_DEV void reduce_part_body(const RedArgs& a, F f) {
+SMR_DEV void reduce_part_body(const RedArgs a, F f) {
     __shared__ T xbuf[256];
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     const int tr_ = a.tr;
@@ -279,7 +279,7 @@ SMR_DEV void reduce_part_body(const RedArgs& a, F f) {
 // lanes cooperate on one destination element: G0 lanes walk the inner dim with V-element vector
 // loads, G1 lanes take different q.  sum(A; dims=1) of a column-major matrix is the model case.
 template <class T, class F, bool MIXED, int V>
-SMR_DEV void reduce_row_body(const RedArgs& a, F f) {
+SMR_DEV void reduce_row_body(const RedArgs a, F f) {
     __shared__ T xbuf[256];
     typedef RVec<T, V> VT;
     constexpr int U = 4;  // vectors in flight per lane
@@ -409,7 +409,7 @@ SMR_DEV void reduce_row_body(const RedArgs& a, F f) {
 // the inner reduced dim x Y1 along q); the rows are folded through LDS.  sum(A; dims=2) of a
 // column-major matrix is the model case.
 template <class T, class F, bool MIXED, int V>
-SMR_DEV void reduce_col_body(const RedArgs& a, F f) {
+SMR_DEV void reduce_col_body(const RedArgs a, F f) {
     __shared__ T xbuf[256 * V];
     typedef RVec<T, V> VT;
     constexpr int U = 4;

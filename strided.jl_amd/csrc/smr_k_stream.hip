@@ -26,7 +26,7 @@ struct alignas(sizeof(T) * V) Vec {
 };
 
 template <class T, class F, bool MIXED, int V, int U>
-SMR_DEV void stream_map_body(const StreamArgs& a, F f) {
+SMR_DEV void stream_map_body(const StreamArgs a, F f) {
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     i64 row = 0, cb = blockIdx.x;
     if (a.rows > 1) {

@@ -116,7 +116,7 @@ SMR_DEV void store_at(char* p, int dtype, int conj, T v) {
 
 // V > 1 implies !MIXED && !WIDE and every direct operand unit-stride along dim 0 (launcher).
 template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
-SMR_DEV void tiled_map_body(const TiledArgs<WIDE>& a, F f) {
+SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     typedef typename off_t_of<WIDE>::type O;
     typedef TVec<T, V> VT;
     constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : 2);
@@ -330,7 +330,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE>& a, F f) {
 // staged values have gone to LDS, so they are in flight during tile i's LDS reads, f and stores.
 // Only instantiated without bounds checks (no ragged tiled dim).
 template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
-SMR_DEV void tiled_map_pipe_body(const TiledArgs<WIDE>& a, F f) {
+SMR_DEV void tiled_map_pipe_body(const TiledArgs<WIDE> a, F f) {
     typedef typename off_t_of<WIDE>::type O;
     typedef TVec<T, V> VT;
     constexpr int NREP = EPL / V;

@@ -21,7 +21,7 @@ def tm(fn, n=5):
     return min(event_time_ms(torch, fn, n) for _ in range(3)) * 1e3
 
 
-TXLOGS = [int(x) for x in os.environ.get('TXLOGS', '6').split(',')]
+TXLOGS = [int(x) for x in os.environ.get('TXLOGS', '5').split(',')]
 WGS = [int(x) for x in os.environ.get('WGS', '4096').split(',')]
 
 
