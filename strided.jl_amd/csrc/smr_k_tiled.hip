@@ -115,8 +115,12 @@ SMR_DEV void store_at(char* p, int dtype, int conj, T v) {
 }
 
 // V > 1 implies !MIXED && !WIDE and every direct operand unit-stride along dim 0 (launcher).
-template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
+// MODE bit 0: bounds checks for ragged tiles, bit 1: tile-order lookup.  The plain variant (0) carries
+// neither: code size and every extra scalar wait are part of the latency of a ~3.5 us launch.
+template <class T, class F, bool MIXED, bool WIDE, int V, int MODE, int THRLOG>
 SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
+    constexpr bool EDGE = (MODE & 1) != 0;
+    constexpr bool ORD = (MODE & 2) != 0;
     typedef typename off_t_of<WIDE>::type O;
     typedef TVec<T, V> VT;
     constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : 2);
@@ -140,7 +144,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
 
     // ---- which tile ---------------------------------------------------------------------------------
     uint32_t b = blockIdx.x;
-    {
+    if constexpr (ORD) {
         // locality-aware tile order (smr_plan.cpp: plan_tile_order).  The in-kernarg lookup is
         // issued unconditionally so that it travels with the first batch of scalar loads.
         const uint32_t pair = a.ord16[(b & (NORD16 - 1)) >> 1];
@@ -504,9 +508,9 @@ SMR_DEV void tiled_map_pipe_body(const TiledArgs<WIDE> a, F f) {
 }
 
 #ifndef SMR_JIT
-template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
+template <class T, class F, bool MIXED, bool WIDE, int V, int MODE, int THRLOG>
 __global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE> a, F f) {
-    tiled_map_body<T, F, MIXED, WIDE, V, EDGE, THRLOG>(a, f);
+    tiled_map_body<T, F, MIXED, WIDE, V, MODE, THRLOG>(a, f);
 }
 
 template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
@@ -594,8 +598,9 @@ static Swizzle choose_swizzle(int tilelog, int w, const std::vector<LanePattern>
     return sw;
 }
 
-template <class T, class F, bool MIXED, bool WIDE, int V, bool EDGE, int THRLOG>
+template <class T, class F, bool MIXED, bool WIDE, int V, int MODE, int THRLOG>
 static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+    constexpr bool EDGE = (MODE & 1) != 0;
     typedef typename off_t_of<WIDE>::type O;
     constexpr int NREP = EPL / V;
     constexpr int NT = 1 << THRLOG;
@@ -636,7 +641,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                           std::to_string(V) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
             else
                 l.entry = std::string("smr::tiled_map_body<") + tname<T>() + ", smr::FJit, " + b2s(MIXED) + ", " + b2s(WIDE) + ", " +
-                          std::to_string(V) + ", " + b2s(EDGE) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
+                          std::to_string(V) + ", " + std::to_string(MODE) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
             l.grid = pgrid ? pgrid : grid_;
             l.block = 1u << THRLOG;
             l.lds = lds;
@@ -657,7 +662,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                     return check_launch("k_tiled_map_pipe");
                 }
             }
-            auto kern = k_tiled_map<T, F, MIXED, WIDE, V, EDGE, THRLOG>;
+            auto kern = k_tiled_map<T, F, MIXED, WIDE, V, MODE, THRLOG>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
@@ -889,8 +894,9 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     bool ragged = false;
     for (int j = 0; j < t.nt; ++j)
         if (c.dims[t.tdim[j]] & (((i64)1 << t.tlog[j]) - 1)) ragged = true;
-    if (ragged) return go3e<T, F, MIXED, WIDE, V, true, THRLOG>(plan, s, f, tab);
-    return go3e<T, F, MIXED, WIDE, V, false, THRLOG>(plan, s, f, tab);
+    if (ragged) return go3e<T, F, MIXED, WIDE, V, 3, THRLOG>(plan, s, f, tab);
+    if (!t.ord.empty()) return go3e<T, F, MIXED, WIDE, V, 2, THRLOG>(plan, s, f, tab);
+    return go3e<T, F, MIXED, WIDE, V, 0, THRLOG>(plan, s, f, tab);
 }
 
 // Can every operand be accessed V elements at a time (V * sizeof(T) <= 16 bytes)?
