@@ -115,12 +115,16 @@ SMR_DEV void store_at(char* p, int dtype, int conj, T v) {
 }
 
 // V > 1 implies !MIXED && !WIDE and every direct operand unit-stride along dim 0 (launcher).
-// MODE bit 0: bounds checks for ragged tiles, bit 1: tile-order lookup.  The plain variant (0) carries
-// neither: code size and every extra scalar wait are part of the latency of a ~3.5 us launch.
+// MODE bit 0: bounds checks for ragged tiles, bit 1: tile-order lookup, bit 2: general tile origins
+// (more than 4 grid dims, or origins beyond 4 GiB / negative steps).  The plain variant (0) carries
+// none of it: code size and every extra scalar wait are part of the latency of a ~3.5 us launch
+// (measured: permutedims! 3.48 -> 3.43 us, 4-way sum 6.84 -> 6.59 us for dropping bit 2 alone).
+// Instantiated: 0 (plain), 2 (orbit order), 7 (everything).
 template <class T, class F, bool MIXED, bool WIDE, int V, int MODE, int THRLOG>
 SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     constexpr bool EDGE = (MODE & 1) != 0;
     constexpr bool ORD = (MODE & 2) != 0;
+    constexpr bool GENORG = (MODE & 4) != 0;
     typedef typename off_t_of<WIDE>::type O;
     typedef TVec<T, V> VT;
     constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : 2);
@@ -165,7 +169,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     }
 #pragma unroll
     for (int g = NG; g < MAXN; ++g) tc[g] = 0;
-    if (a.ng > NG) {
+    if (GENORG && a.ng > NG) {
 #pragma unroll
         for (int g = NG; g < MAXN; ++g) {
             const uint32_t q = fastdiv(b, a.div_m[g], a.div_s[g]);
@@ -183,7 +187,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
         uint32_t emin = 0xffffffffu;  // 0 iff some grid coordinate sits on a ragged last tile
 #pragma unroll
         for (int g = 0; g < MAXN; ++g)
-            if (g < NG || a.ng > NG) emin = min(emin, tc[g] ^ a.last_ragged[g]);
+            if (g < NG || (GENORG && a.ng > NG)) emin = min(emin, tc[g] ^ a.last_ragged[g]);
         edge = emin == 0;
         if (edge) {
 #pragma unroll
@@ -206,7 +210,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
         return ok;
     };
     auto tile_base = [&](int k) -> char* {
-        if (a.base32) {  // every tile origin of every operand is below 4 GiB, steps non-negative
+        if (!GENORG || a.base32) {  // every tile origin of every operand is below 4 GiB, steps non-negative
             uint32_t o = 0;
 #pragma unroll
             for (int g = 0; g < NG; ++g) o += tc[g] * a.op[k].tstep32[g];
@@ -676,6 +680,9 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     std::vector<unsigned char>& cached = plan.tiled_args[variant];
     if (cached.size() == sizeof a) {
         std::memcpy(&a, cached.data(), sizeof a);
+        if constexpr ((MODE & 4) == 0) {
+            if (!a.base32 || a.ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
+        }
         for (int k = 0; k < c.M; ++k) a.op[k].base = tab.base[k];
         return launch(a);
     }
@@ -798,6 +805,10 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         if (span >= 4294967296.0L) base32 = false;
     }
     a.base32 = base32 ? 1 : 0;
+    if constexpr ((MODE & 4) == 0) {
+        // the lean variants assume 32-bit tile origins over at most 4 grid dims
+        if (!base32 || ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
+    }
 
     // per-lane table: built once per (plan, kernel variant), kept in device memory
     const bool build_tab = plan.lanetab[variant] == nullptr && !jit_dry_run();
@@ -894,7 +905,7 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     bool ragged = false;
     for (int j = 0; j < t.nt; ++j)
         if (c.dims[t.tdim[j]] & (((i64)1 << t.tlog[j]) - 1)) ragged = true;
-    if (ragged) return go3e<T, F, MIXED, WIDE, V, 3, THRLOG>(plan, s, f, tab);
+    if (ragged) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
     if (!t.ord.empty()) return go3e<T, F, MIXED, WIDE, V, 2, THRLOG>(plan, s, f, tab);
     return go3e<T, F, MIXED, WIDE, V, 0, THRLOG>(plan, s, f, tab);
 }
