@@ -123,3 +123,29 @@ def test_c4_abs2_sum_slab_f32_accuracy_and_shard_additivity():
     per_plane = S.mapreduce(fn.abs2, "+", V, dims=(0, 1)).toarray().ravel()
     assert np.allclose(per_plane, planes, rtol=1e-6)
     assert S.maximum(V, f=fn.abs) == float(tA.abs().max().item())
+
+
+def test_transposes_beyond_4_gib_use_64_bit_tile_arithmetic():
+    """Maximum sizes: a 5 GiB byte matrix (65536 x 81920) transposed -- tile origins and in-tile
+    offsets exceed 32 bits (the WIDE kernel variant and the general-origin mode) -- and a 5 GiB Int16
+    one; checked against torch's own transpose of the same buffer."""
+    import torch
+    for dt, rows, cols in ((torch.uint8, 65536, 81920), (torch.int16, 49152, 57344)):
+        t = torch.randint(0, 200, (rows * cols,), dtype=dt, device="cuda")
+        out = torch.empty_like(t)
+        A = cm(t, (rows, cols))                      # column-major rows x cols
+        B = cm(out, (cols, rows))
+        plan = S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims((1, 0))))
+        d = plan.describe()
+        assert "family=tiled" in d, d
+        S.permutedims_(B, A, (1, 0))
+        torch.cuda.synchronize()
+        # column-major (rows, cols) == row-major (cols, rows): B = A^T is the row-major transpose
+        want = t.view(cols, rows).t().contiguous().view(-1)
+        assert torch.equal(out, want), d
+        # and back: an involution
+        back = torch.empty_like(t)
+        S.permutedims_(cm(back, (rows, cols)), B, (1, 0))
+        torch.cuda.synchronize()
+        assert torch.equal(back, t)
+        del t, out, back, want
