@@ -65,7 +65,8 @@ class smr_problem(C.Structure):
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libstrided_hip.so")
+# $SMR_LIB: another build of the library (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("SMR_LIB") or os.path.join(_PKG_DIR, "libstrided_hip.so")
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
 # every symbol include/strided_hip.h declares
