@@ -9,10 +9,16 @@
 //     OWN stride order (consecutive lanes walk that input's unit-stride axis -> coalesced,
 //     16 bytes per lane), direct inputs in destination order;
 //   * phase B: transposed inputs are scattered into an LDS tile laid out in DESTINATION
-//     order, XOR-swizzled so that the strided LDS writes of a lane group fall on distinct
-//     banks;
+//     order, XOR-swizzled with masks searched on the host per plan (choose_swizzle: GF(2) rank
+//     test of every staged operand's write pattern and of the read pattern) so that neither the
+//     strided writes nor the linear reads of a lane group collide on a bank;
 //   * phase C: linear (conflict-free) LDS reads, f applied in registers, 16-byte coalesced
 //     stores.
+// Variants: the classic form runs one tile per workgroup (tiled_map_body; MODE selects at compile
+// time which rarely needed features it carries); long work lists use the persistent,
+// software-pipelined form (tiled_map_pipe_body).  Tiles are visited in the planner's order
+// (smr_plan.cpp: plan_tile_order -- orbit-major when several inputs are permuted views of one
+// buffer, so that they meet in one XCD's L2).
 //
 // Index arithmetic.  Tile extents are powers of two, so the position e of an element inside a
 // tile (in any operand's enumeration order) is a bit string, and both its global byte offset
@@ -22,11 +28,14 @@
 //                 the tid bits -- ONE 8-byte vector load per operand, issued first thing;
 //     Gr[r], Lr[r], Lh[h] (kernel arguments): contribution of repeat index r / sub-element h,
 // so the kernel contains no index arithmetic beyond one add (address) and one xor (LDS) per
-// access.  Tile coordinates come from multiply-shift division of the workgroup id.
+// access.  Tile coordinates come from multiply-shift division of the workgroup id.  The kernel
+// arguments are built once per plan and cached (only the operand addresses are patched per call).
 // Measured history (32^4 f64, permutedims! / 4-way sum, us per launch): generic per-dim decode
 // with dependent kernarg loads 11.5 / 28.5 (~2000 scalar instructions per wave: bound by the
 // CU's single scalar unit) -> per-bit tables 6.0 / 14.6 -> 16-B vectors + repeat tables
-// 4.4 / 9.9 -> all loads first, branch-free variants 4.1 / 8.9 -> lane tables: this version.
+// 4.4 / 9.9 -> all loads first, branch-free variants 4.1 / 8.9 -> lane tables 3.4 / 8.4 ->
+// 4096-element tiles on 1024 lanes, searched swizzle, orbit-major order 3.4 / 6.85 -> compile-time
+// modes 3.4 / 6.6 (a plain 16 MiB copy: 3.2; a 5-stream contiguous add: 5.4).
 #ifndef SMR_JIT
 #include <cstdio>
 #include <cstdlib>
