@@ -137,6 +137,7 @@ redcode(::Nothing) = 0
 redcode(::Union{typeof(+),typeof(Base.add_sum)}) = 1
 redcode(::Union{typeof(*),typeof(Base.mul_prod)}) = 2
 redcode(::typeof(min)) = 3; redcode(::typeof(max)) = 4
+redcode(::typeof(&)) = 5; redcode(::typeof(|)) = 6           # neutral elements true / false (src/mapreduce.jl:188-189)
 redcode(op) = throw(Unsupported("reduction $op"))
 initcode(::Nothing) = (0, 0.0 + 0im); initcode(::typeof(identity)) = (1, 0.0 + 0im)
 initcode(::typeof(zero)) = (2, 0.0 + 0im); initcode(::typeof(conj)) = (5, 0.0 + 0im)
@@ -158,7 +159,10 @@ function _mapreduce_fuse!(f, op, initop, dims::Dims, arrays::Tuple{HipView,Varar
             p = Ref(SmrProblem(N, M, pad(dims, 1), ops, pointer(prog.code), length(prog.code) ÷ 2,
                                length(prog.consts) ÷ 2, pointer(prog.consts), redcode(op), ic,
                                (real(β), imag(β)), C_NULL))
-            check(ccall((:smr_mapreduce, lib), Cint, (Ptr{SmrProblem},), p))
+            # one process per GPU: after `smr_comm_init` (see INTEGRATION.md) the same call shards the box over the
+            # ranks and all-reduces a split reduced dim; with a single rank it is plain smr_mapreduce.  An `f`
+            # without a precompiled functor is compiled for gfx950 on first use (library-side, cached).
+            check(ccall((:smr_mapreduce_sharded, lib), Cint, (Ptr{SmrProblem},), p))
             check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))   # the reference is synchronous
         end
         return arrays[1]
