@@ -650,6 +650,17 @@ int make_plan(const smr_problem* p, Plan& plan) {
         }
     } else {
         fam = (c.NK == 0) ? FAM_REDUCE_ALL : FAM_REDUCE_PART;
+        if (fam == FAM_REDUCE_ALL && c.N > 1) {
+            // a complete reduction whose dims do not fuse into one run (a sub-box, a permuted sub-box):
+            // the ROW form with a single destination element walks it without a per-element index
+            // decomposition (measured on a 1000x1000x256 box of a 1024x1024x256 array: 0.59 -> 5 TB/s)
+            bool row = true, any = false;
+            for (int k = 1; k < c.M; ++k) {
+                if (c.strides[k][0] == 1) any = true;
+                else if (c.strides[k][0] != 0) row = false;
+            }
+            if (row && any) fam = FAM_REDUCE_PART;
+        }
     }
     if (o.force_family == FAM_GENERIC && c.redop == SMR_RED_NONE) fam = FAM_GENERIC;
     if (o.force_family == FAM_TILED && c.redop == SMR_RED_NONE && fam != FAM_TILED && plan_tiles(c, plan.tile)) fam = FAM_TILED;
