@@ -16,6 +16,8 @@ struct StreamArgs {
     i64 n0v;   // vectors along dim 0
     i64 rows;  // product of the outer dims
     i64 bpr;   // workgroups per row
+    int32_t txlog, pad_;  // 8: a workgroup covers U x 256 vectors of ONE row; < 8 (short rows): 2^txlog lanes
+                          // along dim 0 x (256 >> txlog) x U entries of dim 1 -- then `rows` counts dims >= 2
     i64 dims[MAXN];
     i64 strides[MAXM][MAXN];
 };
@@ -25,7 +27,7 @@ struct alignas(sizeof(T) * V) Vec {
     T v[V];
 };
 
-template <class T, class F, bool MIXED, int V, int U>
+template <class T, class F, bool MIXED, int V, int U, bool FLAT>
 SMR_DEV void stream_map_body(const StreamArgs a, F f) {
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     i64 row = 0, cb = blockIdx.x;
@@ -33,6 +35,10 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
         row = cb / a.bpr;
         cb -= row * a.bpr;
     }
+    const int txlog = FLAT ? 8 : a.txlog;
+    constexpr bool flat = FLAT;            // one row segment per workgroup (compile-time: the classic form stays lean)
+    const int dfirst = flat ? 1 : 2;       // first dim resolved per workgroup (scalar arithmetic)
+    const int tx = threadIdx.x & ((1 << txlog) - 1), ty = threadIdx.x >> txlog, TY = 256 >> txlog;
     i64 roff[MAXM];
 #pragma unroll
     for (int k = 0; k < MAXM; ++k) roff[k] = 0;
@@ -40,7 +46,7 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
         i64 rem = row;
 #pragma unroll
         for (int d = 1; d < MAXN; ++d) {
-            if (d < a.N) {
+            if (d >= dfirst && d < a.N) {
                 const i64 q = rem / a.dims[d];
                 const i64 c = rem - q * a.dims[d];
                 rem = q;
@@ -53,21 +59,33 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
     typedef Vec<T, V> VT;
     VT in[U][MAXIN];
     i64 col[U];
+    i64 joff[U][MAXM];  // offset of this lane's dim-1 entry (short-row form), 0 otherwise
+    bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        col[u] = (cb * U + u) * 256 + threadIdx.x;
-        if (col[u] < a.n0v) {
+        i64 j = 0;
+        if (flat) {
+            col[u] = (cb * U + u) * 256 + threadIdx.x;
+            live[u] = col[u] < a.n0v;
+        } else {
+            col[u] = tx;
+            j = (cb * U + u) * TY + ty;
+            live[u] = tx < a.n0v && j < a.dims[1];
+        }
+#pragma unroll
+        for (int k = 0; k < MAXM; ++k) joff[u][k] = (k < a.M) ? (flat ? roff[k] : roff[k] + j * a.strides[k][1]) : 0;
+        if (live[u]) {
 #pragma unroll
             for (int k = 0; k < MAXIN; ++k) {
                 if (k < nin) {
                     if (a.strides[k + 1][0] == 0) {
-                        const T s = load_op<T, MIXED>(a.ops, k + 1, roff[k + 1]);
+                        const T s = load_op<T, MIXED>(a.ops, k + 1, joff[u][k + 1]);
 #pragma unroll
                         for (int e = 0; e < V; ++e) in[u][k].v[e] = s;
                     } else if constexpr (MIXED || V == 1) {
-                        in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, roff[k + 1] + col[u] * a.strides[k + 1][0]);
+                        in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, joff[u][k + 1] + col[u] * a.strides[k + 1][0]);
                     } else {
-                        in[u][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + roff[k + 1] + col[u] * V);
+                        in[u][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + joff[u][k + 1] + col[u] * V);
                         if constexpr (tr<T>::cx) {
                             if (a.ops.conj[k + 1]) {
 #pragma unroll
@@ -81,7 +99,7 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (col[u] < a.n0v) {
+        if (live[u]) {
             VT out;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -94,7 +112,7 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
                 out.v[e] = f(x);
             }
             if constexpr (MIXED || V == 1) {
-                store_op<T, MIXED>(a.ops, roff[0] + col[u] * a.strides[0][0], out.v[0]);
+                store_op<T, MIXED>(a.ops, joff[u][0] + col[u] * a.strides[0][0], out.v[0]);
             } else {
                 if constexpr (tr<T>::cx) {
                     if (a.ops.conj[0]) {
@@ -102,16 +120,16 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
                         for (int e = 0; e < V; ++e) out.v[e] = cj(out.v[e]);
                     }
                 }
-                *reinterpret_cast<VT*>((T*)a.ops.base[0] + roff[0] + col[u] * V) = out;
+                *reinterpret_cast<VT*>((T*)a.ops.base[0] + joff[u][0] + col[u] * V) = out;
             }
         }
     }
 }
 
 #ifndef SMR_JIT
-template <class T, class F, bool MIXED, int V, int U>
+template <class T, class F, bool MIXED, int V, int U, bool FLAT>
 __global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f) {
-    stream_map_body<T, F, MIXED, V, U>(a, f);
+    stream_map_body<T, F, MIXED, V, U, FLAT>(a, f);
 }
 
 template <class T, class F, bool MIXED, int V>
@@ -124,9 +142,16 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.N = c.N;
     a.M = c.M;
     a.n0v = c.dims[0] / V;
+    // short rows (sub-boxes): pack (256 >> txlog) entries of dim 1 into a workgroup instead of leaving
+    // most of its lanes idle (measured on 100-element rows: 0.93 -> TB/s below)
+    a.txlog = 8;
+    if (c.N >= 2 && a.n0v <= 128) {
+        a.txlog = 0;
+        while ((1 << a.txlog) < a.n0v) ++a.txlog;
+    }
     a.rows = 1;
-    for (int i = 1; i < c.N; ++i) a.rows *= c.dims[i];
-    a.bpr = (a.n0v + 256 * U - 1) / (256 * U);
+    for (int i = (a.txlog == 8 ? 1 : 2); i < c.N; ++i) a.rows *= c.dims[i];
+    a.bpr = (a.txlog == 8) ? (a.n0v + 256 * U - 1) / (256 * U) : (c.dims[1] + (256 >> a.txlog) * U - 1) / ((256 >> a.txlog) * U);
     for (int i = 0; i < MAXN; ++i) a.dims[i] = (i < c.N) ? c.dims[i] : 1;
     for (int k = 0; k < MAXM; ++k)
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
@@ -138,7 +163,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         l.tname = tname<T>();
         l.argtype = "smr::StreamArgs";
         l.entry = std::string("smr::stream_map_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ", " +
-                  std::to_string(V) + ", " + std::to_string(U) + ">(a, smr::FJit{});";
+                  std::to_string(V) + ", " + std::to_string(U) + ", " + (a.txlog == 8 ? "true" : "false") + ">(a, smr::FJit{});";
         l.grid = (unsigned)grid;
         l.block = 256;
         l.args = &a;
@@ -147,7 +172,10 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     } else {
         if (jit_dry_run()) return SMR_OK;
         clear_sticky_error();
-        hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
+        if (a.txlog == 8)
+            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, true>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
+        else
+            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, false>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
         return check_launch("k_stream_map");
     }
 }
