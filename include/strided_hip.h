@@ -205,6 +205,10 @@ int smr_plan_create(const smr_problem* problem, smr_plan** out);
  * plan was created with.  `stream` overrides problem->stream.                            */
 int smr_plan_execute(smr_plan* plan, void* const* bases, void* stream);
 int smr_plan_destroy(smr_plan* plan);
+/* Builds everything the first execution would build -- index tables uploaded, the kernel for a
+ * runtime-compiled f compiled and loaded, reduction scratch allocated -- without launching.
+ * Call it before capturing smr_plan_execute into a hipGraph (uploads are synchronous copies).  */
+int smr_plan_prepare(smr_plan* plan);
 /* Writes a one-line description ("family=tiled tile=32x32 grid=1024 ...") into buf.      */
 int smr_plan_describe(const smr_plan* plan, char* buf, size_t buflen);
 /* Algorithmic bytes of one execution: every distinct operand footprint counted once

@@ -74,7 +74,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_shard", "smr_set_option",
     "smr_get_option",
 ]
@@ -180,6 +180,11 @@ class Plan:
         if bases is not None:
             arr = (C.c_void_p * len(bases))(*bases)
         check(self._lib.smr_plan_execute(self._h, arr, C.c_void_p(stream or 0)))
+
+    def prepare(self):
+        """Upload tables / compile + load the kernel / allocate scratch without launching (call before
+        capturing execute() into a hipGraph)."""
+        check(self._lib.smr_plan_prepare(self._h))
 
     def describe(self) -> str:
         buf = C.create_string_buffer(1024)

@@ -234,6 +234,18 @@ int smr_plan_execute(smr_plan* plan, void* const* bases, void* stream) {
     return execute(plan->plan, bases, s);
 }
 
+int smr_plan_prepare(smr_plan* plan) {
+    if (!plan) return set_error(SMR_EINVAL, "null plan");
+    int rc = ensure_device();
+    if (rc) return rc;
+    rc = ensure_scratch(plan);
+    if (rc) return rc;
+    jit_set_prepare(true);
+    rc = execute(plan->plan, nullptr, (hipStream_t)plan->stream);
+    jit_set_prepare(false);
+    return rc;
+}
+
 int smr_plan_destroy(smr_plan* plan) {
     plan_free(plan);
     return SMR_OK;

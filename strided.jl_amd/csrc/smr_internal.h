@@ -202,6 +202,10 @@ int jit_compile_only(const Canon& c, const JitLaunch& l, size_t* code_size);
 std::string jit_functor_source(const Canon& c, const char* tname);
 // dry run (thread-local): jit_launch() compiles only; launchers skip device allocations
 bool jit_dry_run();
+// prepare mode (thread-local): everything a first execution would build is built (tables uploaded, kernel
+// compiled and loaded, scratch allocated) but nothing is launched; jit_no_launch() = dry run or prepare
+void jit_set_prepare(bool on);
+bool jit_no_launch();
 void jit_set_dry_run(bool on);
 size_t jit_dry_code_size();
 struct JitStats {

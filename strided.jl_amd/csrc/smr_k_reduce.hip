@@ -609,7 +609,7 @@ static int launch_all(const Canon& c, const RedArgs& a, int blocks, hipStream_t 
         l.argsize = sizeof a;
         return jit_launch(c, l, s);
     } else {
-        if (jit_dry_run()) return SMR_OK;
+        if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
         hipLaunchKernelGGL((k_reduce_all<T, F, MIXED, V>), dim3(blocks), dim3(256), 0, s, a, f);
         return check_launch("k_reduce_all");
@@ -663,7 +663,7 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     }
     if (!done) rc = launch_all<T, F, MIXED, 1>(c, a, blocks, s, f);
     if (rc) return rc;
-    if (blocks > 1 && !jit_dry_run()) {
+    if (blocks > 1 && !jit_no_launch()) {
         clear_sticky_error();
     hipLaunchKernelGGL((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
         rc = check_launch("k_reduce_final");
@@ -688,7 +688,7 @@ static int launch_part(const Canon& c, const RedArgs& a, i64 blocks, hipStream_t
         l.argsize = sizeof a;
         return jit_launch(c, l, s);
     } else {
-        if (jit_dry_run()) return SMR_OK;
+        if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
         if constexpr (KIND == 0) hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
         if constexpr (KIND == 1) hipLaunchKernelGGL((k_reduce_row<T, F, MIXED, V>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
@@ -776,7 +776,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             if (!done) rc = launch_part<T, F, MIXED, 2, 1>(c, a, blocks, s, f);
         }
     }
-    if (rc || nsplit == 1 || jit_dry_run()) return rc;
+    if (rc || nsplit == 1 || jit_no_launch()) return rc;
     // lanes per output of the folding pass: as many as there are partials (up to a wave), fewer
     // when there are plenty of outputs anyway
     int lpolog = 0;

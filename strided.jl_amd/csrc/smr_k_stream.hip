@@ -170,7 +170,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         l.argsize = sizeof a;
         return jit_launch(c, l, s);
     } else {
-        if (jit_dry_run()) return SMR_OK;
+        if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
         if (a.txlog == 8)
             hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, true>), dim3((unsigned)grid), dim3(256), 0, s, a, f);

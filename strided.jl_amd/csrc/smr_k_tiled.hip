@@ -662,7 +662,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             l.argsize = sizeof ka;
             return jit_launch(c, l, s);
         } else {
-            if (jit_dry_run()) return SMR_OK;
+            if (jit_no_launch()) return SMR_OK;
             clear_sticky_error();
             if constexpr (!EDGE) {
                 if (pgrid) {

@@ -314,6 +314,31 @@ def test_strided_rows_take_the_stream_family(T):
     assert np.array_equal(big.toarray(), want)
 
 
+def test_prepare_then_capture_into_a_hip_graph_without_a_warm_up_execution():
+    """smr_plan_prepare builds the tables / compiles the kernel / allocates scratch; a plan prepared that
+    way can be captured into a hipGraph straight away (no synchronous upload inside the capture)."""
+    import torch
+    rng = np.random.default_rng(41)
+    a = cases._rand(rng, (96, 80), np.float64)
+    A = dview(a)
+    B = dview(np.zeros((80, 96)))
+    out = dview(np.zeros((96, 1)))
+    plans = [S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims((1, 0)))),                 # tiled, native functor
+             S.make_plan(lambda x: x * x - x / 3, None, None, B.size, (B, A.permutedims((1, 0)))),     # tiled, runtime-compiled
+             S.make_plan(lambda x: x, "+", "zero", A.size, S.promoteshape(A.size, out, A))]            # partial reduction
+    wants = [a.T, a.T * a.T - a.T / 3, a.sum(axis=1, keepdims=True)]
+    for plan, want, dst in zip(plans, wants, (B, B, out)):
+        plan.prepare()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                plan.execute(int(torch.cuda.current_stream().cuda_stream))
+        g.replay()
+        torch.cuda.synchronize()
+        assert _isapprox(dst.toarray(), want, 1e-13), plan.describe()
+
+
 def test_every_kernel_family_is_exercised():
     """Plans for representative problems pick the intended family (guards against a silent
     fallback to the generic kernel)."""
