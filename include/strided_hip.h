@@ -127,6 +127,9 @@ typedef enum {
     SMR_OP_COS = 18,
     SMR_OP_TANH = 19,
     SMR_OP_INV = 20,
+    SMR_OP_ROUND32 = 21, /* round to Float32 (each part of a complex value): the host inserts it after
+                            every operation Julia would have carried out in Float32 / ComplexF32 while
+                            the call as a whole computes in Float64 (per-operation typing)         */
     /* binary: pop b, pop a, push a (op) b */
     SMR_OP_ADD = 32,
     SMR_OP_SUB = 33,

@@ -122,6 +122,7 @@ struct real_ops {
             case SMR_OP_COS: return std::cos(a);
             case SMR_OP_TANH: return std::tanh(a);
             case SMR_OP_INV: return R(1) / a;
+            case SMR_OP_ROUND32: return (R)(float)a;
         }
         return a;
     }
@@ -169,6 +170,7 @@ struct cx_ops {
             case SMR_OP_COS: return from(std::cos(to(a)));
             case SMR_OP_TANH: return from(std::tanh(to(a)));
             case SMR_OP_INV: return T{R(1), R(0)} / a;
+            case SMR_OP_ROUND32: return T{(R)(float)a.re, (R)(float)a.im};
         }
         return a;
     }
@@ -231,7 +233,7 @@ int check_prog(const Prog& p, int M) {
         } else if (op == SMR_OP_CONST) {
             if (imm >= p.nconst) return -1;
             ++sp;
-        } else if (op >= 8 && op <= SMR_OP_INV) {
+        } else if (op >= 8 && op <= SMR_OP_ROUND32) {
             if (sp < 1) return -1;
         } else if (op >= 32 && op <= SMR_OP_NE) {
             if (sp < 2) return -1;

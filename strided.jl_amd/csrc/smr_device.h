@@ -96,6 +96,7 @@ struct mathx_real {
             case SMR_OP_COS: return cos(a);
             case SMR_OP_TANH: return tanh(a);
             case SMR_OP_INV: return R(1) / a;
+            case SMR_OP_ROUND32: return (R)(float)a;
         }
         return a;
     }
@@ -156,6 +157,7 @@ struct mathx_cx {
                 return T{sinh(x2) / den, sin(y2) / den};
             }
             case SMR_OP_INV: return T{R(1), R(0)} / a;
+            case SMR_OP_ROUND32: return T{(R)(float)a.re, (R)(float)a.im};
         }
         return a;
     }

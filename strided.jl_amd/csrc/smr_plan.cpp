@@ -50,7 +50,7 @@ static int check_prog(const ProgD& p, int M, int& maxdepth) {
         } else if (op == SMR_OP_CONST) {
             if (imm >= p.nconst) return -1;
             ++sp;
-        } else if (op >= SMR_OP_NEG && op <= SMR_OP_INV) {
+        } else if (op >= SMR_OP_NEG && op <= SMR_OP_ROUND32) {
             if (sp < 1) return -1;
         } else if (op >= SMR_OP_ADD && op <= SMR_OP_NE) {
             if (sp < 2) return -1;

@@ -129,10 +129,50 @@ def trace(f, nargs: int) -> Expr:
 
 
 # ---- serialisation ---------------------------------------------------------------------------------
-def serialize(e: Expr):
+def node_dtype(n, arg_dtypes):
+    """Element type Julia would give this sub-expression (None = weakly typed constant)."""
+    if isinstance(n, Arg):
+        return np.dtype(arg_dtypes[n.index - 1])
+    if isinstance(n, Const):
+        return n.dtype
+    ts = [node_dtype(a, arg_dtypes) for a in n.args]
+    strong = [t for t in ts if t is not None]
+    if n.op in ("lt", "le", "gt", "ge", "eq", "ne"):
+        return np.dtype(np.bool_)
+    if n.op in ("abs", "abs2", "real", "imag"):
+        return _real_of(strong[0]) if strong else None
+    if n.op in ("sqrt", "exp", "log", "sin", "cos", "tanh", "inv"):
+        return _float_of(strong[0]) if strong else np.dtype(np.float64)
+    if n.op == "select":
+        strong = [t for t in ts[1:] if t is not None]
+    if not strong:
+        return None
+    r = np.result_type(*strong)
+    if n.op == "div" and not np.issubdtype(r, np.inexact):
+        r = np.dtype(np.float64)
+    if r == np.bool_ and n.op in ("add", "sub", "mul"):
+        r = np.dtype(np.int64)
+    return np.dtype(r)
+
+
+def serialize(e: Expr, arg_dtypes=None, wide: bool = False):
     """Expr -> (code bytes, constants as (re, im) list).  Post-order; leaves are visited left to
-    right, which is the order `consume` pops array values in (src/broadcast.jl:86-98)."""
+    right, which is the order `consume` pops array values in (src/broadcast.jl:86-98).
+
+    Per-operation typing: Julia types every operation of the fused expression separately
+    (`Float32 .* Float32` is a Float32 product even when the result is later widened), the device
+    computes a whole call in one class.  When the call computes in Float64 (`wide`) although an
+    operation's Julia type is Float32 / ComplexF32, a ROUND32 follows it: for + - * / sqrt the
+    double-rounded result equals the Float32 operation exactly (53 >= 2*24 + 2 bits)."""
     code, consts = [], []
+    narrow = (np.dtype(np.float32), np.dtype(np.complex64))
+
+    def rounds(node) -> bool:
+        if not wide or arg_dtypes is None or not isinstance(node, Call):
+            return False
+        if node.op == "select":
+            return False  # picks one of two already rounded values
+        return node_dtype(node, arg_dtypes) in narrow
 
     def const_index(v: complex) -> int:
         for i, c in enumerate(consts):
@@ -152,6 +192,8 @@ def serialize(e: Expr):
             if node.op in _UNARY:
                 emit(node.args[0])
                 code.extend((OPCODES[_UNARY[node.op]], 0))
+                if rounds(node):
+                    code.extend((OPCODES["ROUND32"], 0))
             elif node.op == "select":
                 for a in node.args:
                     emit(a)
@@ -163,6 +205,8 @@ def serialize(e: Expr):
                 for a in node.args[1:]:
                     emit(a)
                     code.extend((OPCODES[_BINARY[node.op]], 0))
+                    if rounds(node):  # every step of a left fold has the fold's type
+                        code.extend((OPCODES["ROUND32"], 0))
         else:
             raise TypeError(type(node))
 
@@ -201,29 +245,5 @@ def result_dtype(e: Expr, arg_dtypes):
     """Element type Julia would infer for f(args...): weak (Int/Bool/Rational) constants do not
     widen, a Python float is a Float64, comparisons give Bool."""
 
-    def go(n):
-        if isinstance(n, Arg):
-            return np.dtype(arg_dtypes[n.index - 1])
-        if isinstance(n, Const):
-            return n.dtype  # None = weak
-        ts = [go(a) for a in n.args]
-        strong = [t for t in ts if t is not None]
-        if n.op in ("lt", "le", "gt", "ge", "eq", "ne"):
-            return np.dtype(np.bool_)
-        if n.op in ("abs", "abs2", "real", "imag"):
-            return _real_of(strong[0]) if strong else None
-        if n.op in ("sqrt", "exp", "log", "sin", "cos", "tanh", "inv"):
-            return _float_of(strong[0]) if strong else np.dtype(np.float64)
-        if n.op == "select":
-            strong = [t for t in ts[1:] if t is not None]
-        if not strong:
-            return None
-        r = np.result_type(*strong)
-        if n.op == "div" and not np.issubdtype(r, np.inexact):
-            r = np.dtype(np.float64)
-        if r == np.bool_ and n.op in ("add", "sub", "mul"):
-            r = np.dtype(np.int64)
-        return np.dtype(r)
-
-    r = go(e)
+    r = node_dtype(e, arg_dtypes)
     return np.dtype(np.float64) if r is None else r

@@ -96,7 +96,11 @@ def build_problem(f, op, initop, dims, arrays, stream=None):
     e = E.trace(f, M - 1)
     if E.max_arg(e) > M - 1:
         raise ValueError("f uses more arguments than arrays were given")
-    code, consts = E.serialize(e)
+    # the library computes the call in the widest float class among ALL operands (csrc/smr_plan.cpp:
+    # canonicalise); operations Julia would carry out in Float32 get a ROUND32 when that class is wider
+    dts = [np.dtype(a.dtype) for a in arrays]
+    wide = any(d in (np.dtype(np.float64), np.dtype(np.complex128)) or np.issubdtype(d, np.integer) or d == np.bool_ for d in dts)
+    code, consts = E.serialize(e, [a.dtype for a in arrays[1:]], wide)
     p = L.smr_problem()
     p.N, p.M = N, M
     for i, d in enumerate(dims):
