@@ -202,3 +202,30 @@ def test_comm_entry_points_without_a_communicator():
     assert lib.smr_comm_init(1, 0, None, 0) == L.SMR_OK              # one rank: nothing to set up
     assert lib.smr_comm_destroy() == L.SMR_OK
     assert lib.smr_comm_unique_id(None, 0) == L.SMR_EINVAL
+
+
+def test_planner_picks_the_vectorised_reduction_and_stream_forms():
+    """Planning is host arithmetic: the forms added for views (ROW / COL partial reductions, complete
+    reductions over sub-boxes, strided and short rows in the STREAM family) are chosen when expected."""
+    a = S.StridedView(np.zeros((512, 384), dtype=np.float32, order="F"))
+
+    def red(view, dims):
+        out = view.similar(size=tuple(1 if d in dims else n for d, n in enumerate(view.size)))
+        return S.make_plan(lambda x: x, "+", None, view.size, S.promoteshape(view.size, out, view)).describe()
+
+    assert "family=reduce_part" in red(a, (0,)) and "form=row" in red(a, (0,))      # sum(A; dims=1): contiguous reduced dim
+    assert "form=col" in red(a, (1,))                                                # sum(A; dims=2): contiguous kept dim
+    assert "form=general" in red(a.sview(slice(0, 512, 2), slice(None)), (0,))       # stride 2 along the reduced dim
+    assert "family=reduce_all" in red(a, (0, 1)) and "N=1" in red(a, (0, 1))         # fuses into one run
+    box = a.sview(slice(0, 500), slice(0, 300))
+    d = red(box, (0, 1))                                                             # sub-box: does not fuse
+    assert "family=reduce_part" in d and "nout=1" in d and "form=row" in d
+    # few outputs, long reductions: split into many workgroups + folding pass
+    t = S.StridedView(np.zeros((16, 1 << 16), dtype=np.float32, order="F"))
+    assert "split=" in red(t, (1,)) and "split=1 " not in red(t, (1,)) + " "
+    # STREAM: stepped rows and short rows stay in the family
+    b = a.similar()
+    d = S.make_plan(lambda x: x * 2, None, None, (256, 384), (b.sview(slice(0, 256), slice(None)), a.sview(slice(0, 512, 2), slice(None)))).describe()
+    assert "family=stream" in d and "vec=1" in d
+    d = S.make_plan(lambda x: x * 2, None, None, (100, 384), (b.sview(slice(0, 100), slice(None)), a.sview(slice(0, 100), slice(None)))).describe()
+    assert "family=stream" in d and "vec=4" in d
