@@ -93,3 +93,16 @@ def test_disk_cache_is_opt_in_and_reused(tmp_path, monkeypatch):
     assert n1 > 0 and S.get_option("jit_compiles") == c0 + 1
     files = list(tmp_path.glob("smr_*.co"))
     assert len(files) == 1 and files[0].stat().st_size == n1
+
+
+def test_missing_compiler_helper_is_reported_not_fatal(monkeypatch):
+    """Without the helper the dry compile reports SMR_EUNSUPPORTED (on a GPU the launchers fall back to
+    the interpreter after a one-time warning); nothing crashes and native functors are unaffected."""
+    monkeypatch.setenv("SMR_JITC", "/nonexistent/smr_jitc")
+    A, B = _v((80, 80)), _v((80, 80))
+    f0 = S.get_option("jit_failures")
+    plan = S.make_plan(lambda a: a * a - a * 0.987654321, None, None, A.size, (B, A))   # a source no other test compiles
+    with pytest.raises(S.UnsupportedOnDevice):
+        plan.jit_compile()
+    assert S.get_option("jit_failures") == f0 + 1
+    assert S.make_plan(lambda a: a, None, None, A.size, (B, A.permutedims((1, 0)))).jit_compile() == 0
