@@ -408,6 +408,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_blocks") o.reduce_blocks = value;
     else if (n == "jit") o.jit = value;
     else if (n == "tiled_persist") o.tiled_persist = value;
+    else if (n == "stream_u") o.stream_u = value;
     else if (n == "tiled_persist_wpc") o.tiled_persist_wpc = value;
     else if (n == "tiled_persist_min") o.tiled_persist_min = value;
     else if (n == "reduce_part_kind") o.reduce_part_kind = value;
@@ -435,6 +436,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "reduce_blocks") return o.reduce_blocks;
     if (n == "jit") return o.jit;
     if (n == "tiled_persist") return o.tiled_persist;
+    if (n == "stream_u") return o.stream_u;
     if (n == "tiled_persist_wpc") return o.tiled_persist_wpc;
     if (n == "tiled_persist_min") return o.tiled_persist_min;
     if (n == "reduce_part_kind") return o.reduce_part_kind;

@@ -170,6 +170,7 @@ struct Options {
     i64 tiled_persist_wpc = 0;  // workgroups per CU of that form (0 = derived from threads / LDS)
     i64 tiled_persist_min = 32; // ... used when the work list holds at least this many rounds (measured: 64^4 / 4000^2
                                 // problems with ~16 rounds are 2-12 % faster in the classic form, 128^4 / 8192^2 ones 6-18 % slower)
+    i64 stream_u = 0;           // experiment: vectors per lane of the STREAM family (runtime-compiled functors only)
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 max_lds_bytes = 65536;
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override
