@@ -39,6 +39,7 @@ int launch_stream_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR
 int launch_tiled_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_tiled_map) }
 int launch_reduce_all(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_reduce_all) }
 int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_reduce_part) }
+int launch_orbit_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_orbit_map) }
 
 static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
     switch (plan.family) {
@@ -47,6 +48,10 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
         case FAM_TILED: {
             std::lock_guard<std::mutex> g(*plan.build_mu);
             return launch_tiled_map(plan, bases, s);
+        }
+        case FAM_ORBIT: {
+            std::lock_guard<std::mutex> g(*plan.build_mu);
+            return launch_orbit_map(plan, bases, s);
         }
         case FAM_REDUCE_ALL: return launch_reduce_all(plan, bases, s);
         case FAM_REDUCE_PART: return launch_reduce_part(plan, bases, s);
@@ -297,8 +302,8 @@ int smr_plan_jit_source(const smr_plan* plan, char* buf, size_t buflen) {
 }
 
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
-    if (!plan || plan->plan.family != FAM_TILED) return 0;
-    const std::vector<uint32_t>& ord = plan->plan.tile.ord;
+    if (!plan || (plan->plan.family != FAM_TILED && plan->plan.family != FAM_ORBIT)) return 0;
+    const std::vector<uint32_t>& ord = plan->plan.family == FAM_ORBIT ? plan->plan.orbit.list : plan->plan.tile.ord;
     if (out)
         for (size_t i = 0; i < ord.size() && i < cap; ++i) out[i] = ord[i];
     return (int64_t)ord.size();
@@ -415,6 +420,11 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_col_txlog") o.reduce_col_txlog = value;
     else if (n == "reduce_part_wgs") o.reduce_part_wgs = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
+    else if (n == "nt_store_max") o.nt_store_max = value;
+    else if (n == "nt_store") o.nt_store = value;
+    else if (n == "orbit_min") o.orbit_min = value;
+    else if (n == "orbit_lg") o.orbit_lg = value;
+    else if (n == "orbit") o.orbit = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
     else if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') o.tile_lg[n[7] - '0'] = value;
     else ok = false;
@@ -447,6 +457,11 @@ int64_t smr_get_option(const char* name) {
     if (n == "jit_failures") return jit_stats().failures;
     if (n == "jit_compile_ms") return (int64_t)jit_stats().compile_ms;
     if (n == "tiled_vec") return o.tiled_vec;
+    if (n == "nt_store_max") return o.nt_store_max;
+    if (n == "nt_store") return o.nt_store;
+    if (n == "orbit_min") return o.orbit_min;
+    if (n == "orbit_lg") return o.orbit_lg;
+    if (n == "orbit") return o.orbit;
     if (n == "max_lds_bytes") return o.max_lds_bytes;
     if (n.rfind("tile_lg", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '7') return o.tile_lg[n[7] - '0'];
     return -1;

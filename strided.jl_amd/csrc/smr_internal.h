@@ -78,7 +78,8 @@ enum Family : int {
     FAM_STREAM = 2,   // every operand unit-stride (or broadcast) along the fast dim
     FAM_TILED = 3,    // LDS-staged: operands with different unit-stride axes
     FAM_REDUCE_ALL = 4,
-    FAM_REDUCE_PART = 5
+    FAM_REDUCE_PART = 5,
+    FAM_ORBIT = 6     // LDS-staged: every input is a differently permuted view of ONE buffer
 };
 
 #ifndef SMR_JIT
@@ -127,10 +128,33 @@ struct TilePlan {
     int ord_groups = 0;
 };
 
+// Description for FAM_ORBIT (smr_k_orbit.hip).  Every input k is a view of one buffer whose strides are
+// the identity view's strides permuted by pi_k; G = <pi_k> (|G| <= MAXG).  A workgroup owns the G-orbit of
+// one tile (tile extents are equal along every cycle of G, so G permutes tiles): slot a holds the buffer
+// on tile g_a . t, the outputs of that tile read input k from slot (pi_k o g_a).
+constexpr int MAXG = 4;
+struct OrbitPlan {
+    int ng = 0;               // |G|
+    int k0 = 1;               // identity view: the input whose strides equal the destination's
+    int gdim[MAXG][MAXN];     // g_a as a permutation of canonical dims: (g_a . t)[gdim[a][d]] = t[d]
+    int pdim[MAXM][MAXN];     // pi_k (k = 1..M-1) the same way
+    int slot[MAXG][MAXM];     // slot[a][k] = index of pi_k o g_a
+    int lg[MAXN];             // log2 tile extent per canonical dim (invariant under G)
+    int tilelog = 0;
+    int vec = 1;              // elements per 16-byte access when alignment allows
+    i64 ntiles[MAXN];
+    i64 ntiles_total = 1;
+    int norbits = 0;
+    std::vector<uint32_t> list;  // root tile of the orbit executed by workgroup b (0xffffffff = idle);
+                                 // grouped by super-cells, one contiguous run per XCD
+    size_t lds_bytes = 0;
+};
+
 struct Plan {
     Canon c;
     int family = FAM_GENERIC;
     TilePlan tile;
+    OrbitPlan orbit;
     // STREAM
     int vec = 1;        // elements per vector access
     // reductions
@@ -172,6 +196,12 @@ struct Options {
                                 // problems with ~16 rounds are 2-12 % faster in the classic form, 128^4 / 8192^2 ones 6-18 % slower)
     i64 stream_u = 0;           // experiment: vectors per lane of the STREAM family (runtime-compiled functors only)
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
+    i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
+    i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
+    i64 orbit_min = 1024;    // pick the largest tile edge that still yields this many orbits
+    i64 nt_store = 0;        // non-temporal stores: -1 = when the destination is at most nt_store_max bytes, 0 never, 1 always
+                             // (measured on MI355X: no gain on the library's kernels at any size -> off)
+    i64 nt_store_max = (i64)32 << 20;
     i64 max_lds_bytes = 65536;
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override
 };
@@ -221,6 +251,7 @@ int launch_stream_map(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_tiled_map(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_reduce_all(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s);
+int launch_orbit_map(const Plan& plan, void* const* bases, hipStream_t s);
 
 #endif  // !SMR_JIT
 

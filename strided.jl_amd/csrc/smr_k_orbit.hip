@@ -1,0 +1,422 @@
+// smr_k_orbit.hip -- family ORBIT: fused N-ary map whose inputs are differently PERMUTED VIEWS OF ONE
+// BUFFER (B .= (A .+ A')./2, the 4-way permuted sum of the reference's README, any symmetrisation).
+//
+// The classic tiled kernel (smr_k_tiled.hip) treats the views as independent operands: the buffer passes
+// through L1 once per view, and with three or more distinct unit-stride axes most of those passes move
+// 32-/64-byte runs.  Here the permutation group G the views generate (|G| <= 4) acts on the TILES: tile
+// extents are equal along every cycle of G, so the image of a tile under g in G is again a tile.  A
+// workgroup owns one orbit {g.t : g in G}:
+//   * slot a of the LDS holds the buffer on tile g_a.t, loaded ONCE, in the buffer's natural order
+//     (16 B per lane along the buffer's unit-stride axis -- every slot has the same shape, so one set
+//     of per-lane offsets serves all of them);
+//   * an output element of tile g_a.t reads view k from slot (pi_k o g_a) at the local coordinate
+//     permuted by pi_k; the identity view comes straight from the lane's own registers;
+//   * outputs leave in the same natural order (the destination has the identity view's strides).
+// Every element of the buffer crosses L1 once instead of once per view, and an in-place update
+// (destination = the buffer) is safe: an orbit is read completely before it is written, and orbits are
+// disjoint.  Orbits are executed super-cell by super-cell in XCD-contiguous runs (smr_plan.cpp:
+// plan_orbit), so the partner halves of 64-B runs meet in one XCD's L2.
+// All index arithmetic is bit slicing of the lane id with kernel-argument shifts (no lane tables, no
+// dependent memory round trip before the first global load).
+// Measured on MI355X (4-way sum, Float64): 32^4 6.6 -> 4.7 us, 64^4 83 -> 46 us, 128^4 1.73 -> 1.41 ms
+// (tools/c3_proto.hip is the design experiment this kernel follows).
+#ifndef SMR_JIT
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
+
+#include "smr_dispatch.h"
+
+#ifndef SMR_CT
+#error "compile with -DSMR_CT=0..3"
+#endif
+
+namespace smr {
+
+constexpr int OMAXT = 4;  // tiled dims = dims of the unit class <= |G| <= 4
+
+struct OrbitArgs {
+    const char* src;  // the shared buffer, element offset applied
+    char* dst;
+    const uint32_t* list;  // per workgroup: the NG slot origins (element offsets; [0] = 0xffffffff: idle)
+    int32_t nin, tilelog, ntlog, conj0, nts, pad0;
+    uint32_t swz_s1, swz_s2, swz_mask, pad1;
+    // element enumeration inside a tile (natural order of the buffer); unused tiled dims have elen = 0
+    int32_t esh[OMAXT], elen[OMAXT];
+    uint32_t estride[OMAXT];       // byte stride of tiled dim j
+    int32_t lsh[MAXIN][OMAXT];     // LDS bit position of tiled dim j as seen through view k
+    int32_t slot[MAXG][MAXIN];     // LDS slot view k of slot a's outputs reads from
+    uint32_t conjbit[MAXIN];       // 0x80000000 when view k is conjugated (complex types)
+};
+
+template <class T, int V>
+struct alignas(sizeof(T) * V) OVec {
+    T v[V];
+};
+
+// conjugate iff bit == 0x80000000, without a branch (sign flip of the imaginary part)
+SMR_DEV float ocj(float x, uint32_t) { return x; }
+SMR_DEV double ocj(double x, uint32_t) { return x; }
+SMR_DEV c32 ocj(c32 x, uint32_t bit) { return c32{x.re, __uint_as_float(__float_as_uint(x.im) ^ bit)}; }
+SMR_DEV c64 ocj(c64 x, uint32_t bit) {
+    return c64{x.re, __longlong_as_double(__double_as_longlong(x.im) ^ ((long long)bit << 32))};
+}
+
+template <class VT>
+SMR_DEV void ostore(char* p, const VT& v, bool nts) {
+    if (nts) {
+        if constexpr (sizeof(VT) == 16) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(p));
+            return;
+        } else if constexpr (sizeof(VT) == 8) {
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(p));
+            return;
+        } else if constexpr (sizeof(VT) == 4) {
+            __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(p));
+            return;
+        }
+    }
+    *reinterpret_cast<VT*>(p) = v;
+}
+
+// NG = |G| (2 or 4; a group of order 3 is padded with a copy of slot 0), OWN0: view 0 is the identity view
+// (its value is the lane's own register).  Apart from the rare > 4 grid dims there is no branch on a
+// kernel argument before the stores: every scalar branch on a just-loaded argument is a serial
+// scalar-cache round trip, and at 32^4 the whole launch lasts 4-5 us.
+template <class T, class F, int V, int NREP, int NG, bool OWN0>
+SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
+    typedef OVec<T, V> VT;
+    constexpr int NIN_STATIC = F::NIN;
+    constexpr int NINMAX = (NIN_STATIC >= 0) ? NIN_STATIC : MAXIN;
+    constexpr int NK = NINMAX > 0 ? NINMAX : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int nin = (NIN_STATIC >= 0) ? NIN_STATIC : a.nin;
+    const uint32_t tid = threadIdx.x;
+    // ---- slot origins: one wide scalar load of this workgroup's table row -----------------------------
+    i64 org[NG];
+    {
+        typedef uint32_t rowv __attribute__((ext_vector_type(NG)));
+        const rowv row = reinterpret_cast<const rowv*>(a.list)[blockIdx.x];
+        uint32_t o32[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) o32[g] = row[g];
+        if (o32[0] == 0xffffffffu) return;  // padding workgroup (whole workgroup: no barrier is skipped)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) org[g] = (i64)o32[g] * (i64)sizeof(T);
+    }
+
+    // ---- per-lane offsets: bit slices of the element number ---------------------------------------
+    uint32_t goff[NREP];  // byte offset inside a tile (natural order)
+    uint32_t lr[NK][NREP];  // LDS index of the lane's first element seen through view k
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+        const uint32_t e = (((uint32_t)r << a.ntlog) | tid) * V;
+        uint32_t g = 0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) lr[k][r] = 0;
+#pragma unroll
+        for (int j = 0; j < OMAXT; ++j) {
+            const uint32_t cj = __builtin_amdgcn_ubfe(e, (uint32_t)a.esh[j], (uint32_t)a.elen[j]);
+            g += cj * a.estride[j];
+#pragma unroll
+            for (int k = (OWN0 ? 1 : 0); k < NK; ++k) lr[k][r] |= cj << a.lsh[k][j];
+        }
+        goff[r] = g;
+    }
+    auto swz = [&](uint32_t i) { return i ^ (((i >> a.swz_s1) ^ (i >> a.swz_s2)) & a.swz_mask); };
+
+    // ---- load every slot (natural order), park it in LDS ------------------------------------------
+    VT x[NG][NREP];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) x[g][r] = *reinterpret_cast<const VT*>(a.src + org[g] + goff[r]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        T* L = lds + ((size_t)g << a.tilelog);
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            const uint32_t e = (((uint32_t)r << a.ntlog) | tid) * V;
+#pragma unroll
+            for (int h = 0; h < V; ++h) L[swz(e + h)] = x[g][r].v[h];
+        }
+    }
+    __syncthreads();
+
+    // ---- outputs of every slot ---------------------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            VT out;
+#pragma unroll
+            for (int h = 0; h < V; ++h) {
+                T arg[MAXIN];
+#pragma unroll
+                for (int k = 0; k < MAXIN; ++k) {
+                    arg[k] = T{};
+                    if (k < NK) {
+                        T v;
+                        if (OWN0 && k == 0) {
+                            v = x[g][r].v[h];
+                        } else {
+                            // sub-element h moves along tiled dim 0 of the natural order
+                            const uint32_t idx = lr[k < NK ? k : 0][r] | ((uint32_t)h << a.lsh[k][0]);
+                            v = lds[((size_t)a.slot[g][k] << a.tilelog) + swz(idx)];
+                        }
+                        if constexpr (tr<T>::cx) v = ocj(v, a.conjbit[k]);
+                        arg[k] = v;
+                    }
+                }
+                (void)nin;
+                T o = f(arg);
+                if constexpr (tr<T>::cx) o = ocj(o, a.conj0 ? 0x80000000u : 0u);
+                out.v[h] = o;
+            }
+            x[g][r] = out;
+        }
+    }
+    const bool nts = a.nts != 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) ostore<VT>(a.dst + org[g] + goff[r], x[g][r], nts);
+}
+
+#ifndef SMR_JIT
+template <class T, class F, int V, int NREP, int NG, bool OWN0>
+__global__ void __launch_bounds__(1024) k_orbit_map(const OrbitArgs a, F f) {
+    orbit_map_body<T, F, V, NREP, NG, OWN0>(a, f);
+}
+
+// XOR-fold swizzle l ^ (((l >> s1) ^ (l >> s2)) & mask): parameters picked per plan by counting the
+// bank conflicts of the transposing LDS reads (a lane group of the hardware must hit distinct banks)
+struct OSwz {
+    uint32_t s1 = 31, s2 = 31, mask = 0;
+    uint32_t operator()(uint32_t i) const { return i ^ (((i >> s1) ^ (i >> s2)) & mask); }
+};
+
+static OSwz choose_orbit_swizzle(const OrbitArgs& a, int nin, bool own0, int esize, int V, int NREP) {
+    // lane group / bank-slot model: ds_read_b32/b64 are served in two halves of 32 lanes over 32 slots
+    // of the access width; ds_read_b128 in groups of 16 lanes over 16 slots
+    const int group = esize >= 16 ? 16 : 32;
+    const uint32_t slots = (uint32_t)group;
+    const uint32_t nt = 1u << a.ntlog;
+    auto cost = [&](const OSwz& s) {
+        long c = 0;
+        for (int k = own0 ? 1 : 0; k < nin; ++k)
+            for (int r = 0; r < NREP; ++r)
+                for (int h = 0; h < V; ++h)
+                    for (uint32_t w0 = 0; w0 < std::min(nt, 256u); w0 += group) {
+                        uint32_t first[32];
+                        int cnt[32];
+                        int worst = 0;
+                        for (uint32_t q = 0; q < slots; ++q) cnt[q] = 0;
+                        for (int lane = 0; lane < group; ++lane) {
+                            const uint32_t e = (((uint32_t)r << a.ntlog) | (w0 + lane)) * V + h;
+                            uint32_t idx = 0;
+                            for (int j = 0; j < OMAXT; ++j) idx |= ((e >> a.esh[j]) & ((1u << a.elen[j]) - 1u)) << a.lsh[k][j];
+                            const uint32_t l = s(idx), q = l % slots;
+                            if (cnt[q] == 0) {
+                                first[q] = l;
+                                cnt[q] = 1;
+                            } else if (first[q] != l) {
+                                ++cnt[q];
+                            }
+                        }
+                        for (uint32_t q = 0; q < slots; ++q) worst = std::max(worst, cnt[q]);
+                        c += worst - 1;
+                    }
+        return c;
+    };
+    OSwz best;
+    long bc = cost(best);
+    auto consider = [&](uint32_t s1, uint32_t s2) {
+        OSwz t;
+        t.s1 = s1;
+        t.s2 = s2;
+        t.mask = slots - 1;
+        const long cc = cost(t);
+        if (cc < bc) {
+            bc = cc;
+            best = t;
+        }
+    };
+    for (uint32_t s1 = 2; s1 <= 6 && bc > 0; ++s1) {
+        consider(s1, 31);  // one-term fold
+        for (uint32_t s2 = s1 + 1; s2 <= 13 && bc > 0; ++s2) consider(s1, s2);
+    }
+    if (std::getenv("SMR_DEBUG_SWIZZLE"))
+        std::fprintf(stderr, "[smr] orbit swizzle: s1=%u s2=%u mask=%u conflict cost %ld\n", best.s1, best.s2, best.mask, bc);
+    return best;
+}
+
+template <class T, class F, int V, int NREP, int NG, bool OWN0>
+static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+    const Canon& c = plan.c;
+    const OrbitPlan& o = plan.orbit;
+    OrbitArgs a;
+    std::vector<unsigned char>& cached = plan.tiled_args[V > 1 ? 1 : 0];
+    if (cached.size() == sizeof a) {
+        std::memcpy(&a, cached.data(), sizeof a);
+    } else {
+        std::memset(&a, 0, sizeof a);
+        const i64 es = (i64)sizeof(T);
+        a.nin = c.M - 1;
+        a.tilelog = o.tilelog;
+        int vlog = 0, nreplog = 0;
+        while ((1 << vlog) < V) ++vlog;
+        while ((1 << nreplog) < NREP) ++nreplog;
+        a.ntlog = o.tilelog - vlog - nreplog;
+        a.conj0 = tab.conj[0];
+        // tiled dims in canonical (= natural) order
+        int nt = 0, sh = 0, jof[MAXN];
+        for (int d = 0; d < c.N; ++d) {
+            jof[d] = -1;
+            if (o.lg[d] == 0) continue;
+            if (nt >= OMAXT) return set_error(SMR_EUNSUPPORTED, "orbit: too many tiled dims");
+            jof[d] = nt;
+            a.esh[nt] = sh;
+            a.elen[nt] = o.lg[d];
+            a.estride[nt] = (uint32_t)(c.strides[o.k0][d] * es);
+            sh += o.lg[d];
+            ++nt;
+        }
+        for (int k = 1; k < c.M; ++k) {
+            for (int d = 0; d < c.N; ++d)
+                if (jof[d] >= 0) a.lsh[k - 1][jof[d]] = a.esh[jof[o.pdim[k][d]]];
+            a.conjbit[k - 1] = tab.conj[k] ? 0x80000000u : 0u;
+            for (int g = 0; g < NG; ++g) a.slot[g][k - 1] = o.slot[g < o.ng ? g : 0][k];
+        }
+        const OSwz sw = choose_orbit_swizzle(a, c.M - 1, OWN0, (int)sizeof(T), V, NREP);
+        a.swz_s1 = sw.s1;
+        a.swz_s2 = sw.s2;
+        a.swz_mask = sw.mask;
+        if (!plan.ordtab && !jit_dry_run()) {
+            // origin table: slot g of the orbit rooted at tile t holds tile g.t, whose coordinate along dim
+            // gdim[g][d] is t[d]; a group of order 3 is padded with a copy of slot 0 (its outputs are
+            // written twice, with identical values)
+            std::vector<uint32_t> rows(o.list.size() * NG, 0xffffffffu);
+            for (size_t w = 0; w < o.list.size(); ++w) {
+                if (o.list[w] == 0xffffffffu) continue;
+                i64 id = o.list[w], tc[MAXN];
+                for (int d = 0; d < c.N; ++d) {
+                    tc[d] = id % o.ntiles[d];
+                    id /= o.ntiles[d];
+                }
+                for (int g = 0; g < NG; ++g) {
+                    const int gg = g < o.ng ? g : 0;
+                    i64 org = 0;
+                    for (int d = 0; d < c.N; ++d) org += tc[d] * (c.strides[o.k0][o.gdim[gg][d]] << o.lg[d]);
+                    rows[w * NG + g] = (uint32_t)org;
+                }
+            }
+            void* dptr = nullptr;
+            hipError_t e = hipMalloc(&dptr, rows.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return hip_error(e, "hipMalloc(orbit origins)");
+            e = hipMemcpy(dptr, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(dptr);
+                return hip_error(e, "hipMemcpy(orbit origins)");
+            }
+            plan.ordtab = dptr;
+        }
+        a.list = reinterpret_cast<const uint32_t*>(plan.ordtab);
+        if (!jit_dry_run()) {
+            cached.resize(sizeof a);
+            std::memcpy(cached.data(), &a, sizeof a);
+        }
+    }
+    a.src = (const char*)tab.base[o.k0];
+    a.dst = (char*)tab.base[0];
+    const Options& opt = options();
+    a.nts = (opt.nt_store > 0 || (opt.nt_store < 0 && c.nout * (i64)sizeof(T) <= opt.nt_store_max)) ? 1 : 0;
+    const unsigned grid = (unsigned)o.list.size();
+    const unsigned block = 1u << a.ntlog;
+    const size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "orbit";
+        l.tname = tname<T>();
+        l.argtype = "smr::OrbitArgs";
+        l.entry = std::string("smr::orbit_map_body<") + tname<T>() + ", smr::FJit, " + std::to_string(V) + ", " + std::to_string(NREP) + ", " +
+                  std::to_string(NG) + ", " + (OWN0 ? "true" : "false") + ">(a, smr::FJit{});";
+        l.grid = grid;
+        l.block = block;
+        l.lds = lds;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(c, l, s);
+    } else {
+        if (jit_no_launch()) return SMR_OK;
+        clear_sticky_error();
+        auto kern = k_orbit_map<T, F, V, NREP, NG, OWN0>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a, f);
+        return check_launch("k_orbit_map");
+    }
+}
+
+template <class T, class F, int V, int NREP>
+static int go2(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+    const OrbitPlan& o = plan.orbit;
+    bool own0 = true;  // is input 1 the identity view?
+    for (int d = 0; d < plan.c.N; ++d)
+        if (o.pdim[1][d] != d) own0 = false;
+    if (o.ng == 2) return own0 ? go3<T, F, V, NREP, 2, true>(plan, s, f, tab) : go3<T, F, V, NREP, 2, false>(plan, s, f, tab);
+    return own0 ? go3<T, F, V, NREP, 4, true>(plan, s, f, tab) : go3<T, F, V, NREP, 4, false>(plan, s, f, tab);
+}
+
+template <class T, class F>
+static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    const Canon& c = plan.c;
+    const OrbitPlan& o = plan.orbit;
+    const OpTab tab = make_optab(c, bases);
+    // every view must still be a view of ONE buffer after rebinding
+    for (int k = 1; k < c.M; ++k)
+        if (tab.base[k] != tab.base[o.k0]) return set_error(SMR_EINVAL, "orbit plan: the inputs must stay views of one buffer");
+    constexpr int VMAX = (16 / sizeof(T)) > 1 ? (int)(16 / sizeof(T)) : 1;
+    bool vec = o.vec == VMAX && VMAX > 1;
+    if (vec && ((((uintptr_t)tab.base[0]) | ((uintptr_t)tab.base[o.k0])) % 16)) vec = false;
+    const int tile = 1 << o.tilelog;
+    if constexpr (VMAX > 1) {
+        if (vec) {
+            const int nrep = std::max(1, tile / (VMAX * 1024));
+            if (nrep == 1) return go2<T, F, VMAX, 1>(plan, s, f, tab);
+            if (nrep == 2) return go2<T, F, VMAX, 2>(plan, s, f, tab);
+            return set_error(SMR_EINVAL, "orbit: unexpected tile size");
+        }
+        // element-wise accesses (operands not 16-byte aligned): only instantiated for tiles of up to 1024 elements
+        if (tile <= 1024) return go2<T, F, 1, 1>(plan, s, f, tab);
+        return set_error(SMR_EUNSUPPORTED, "orbit plan: operands must be 16-byte aligned (rebind aligned pointers or create a new plan)");
+    } else {
+        const int nrep = std::max(1, tile / 1024);
+        if (nrep == 1) return go2<T, F, 1, 1>(plan, s, f, tab);
+        if (nrep == 2) return go2<T, F, 1, 2>(plan, s, f, tab);
+        if (nrep == 4) return go2<T, F, 1, 4>(plan, s, f, tab);
+        return set_error(SMR_EINVAL, "orbit: unexpected tile size");
+    }
+}
+
+template <>
+int launch_orbit_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
+    typedef ct_type<SMR_CT>::type T;
+    const Canon& c = plan.c;
+    switch (c.fkind) {  // natively compiled functors of this family; everything else is compiled at run time
+        case FK_ADD2: return go<T, FAdd2<T>>(plan, bases, s, FAdd2<T>{});
+        case FK_ADD4: return go<T, FAdd4<T>>(plan, bases, s, FAdd4<T>{});
+        case FK_SYM: return go<T, FSym<T>>(plan, bases, s, FSym<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        default: break;
+    }
+    return with_prog<T>(c, [&](auto f) { return go<T, decltype(f)>(plan, bases, s, f); });
+}
+#endif  // !SMR_JIT
+
+}  // namespace smr

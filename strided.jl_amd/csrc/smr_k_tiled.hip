@@ -78,6 +78,7 @@ template <bool WIDE>
 struct TiledArgs {
     // header + tile decode first: they arrive with the first batch of scalar loads
     int32_t M, ng, tilelog, nstaged, base32, nt, ordmode, nwork;  // nwork: entries of the work list (persistent form)
+    int32_t nts, pad_[3];  // nts: non-temporal stores (small destinations: see Options::nt_store)
     int32_t staged[MAXM];  // [1 + i]: LDS slot of input i or -1 ([0] unused)
     uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
     const LaneRow<WIDE>* lanetab;  // [(operand k) * T + tid], k = 0 destination
@@ -99,6 +100,26 @@ template <class T, int V>
 struct alignas(sizeof(T) * V) TVec {
     T v[V];
 };
+
+// 16-/8-/4-byte vector store, optionally non-temporal (wave-uniform switch)
+template <class VT>
+SMR_DEV void store_vec(char* p, const VT& v, int nts) {
+    if (nts) {
+        if constexpr (sizeof(VT) == 16) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(p));
+            return;
+        } else if constexpr (sizeof(VT) == 8) {
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(p));
+            return;
+        } else if constexpr (sizeof(VT) == 4) {
+            __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(p));
+            return;
+        }
+    }
+    *reinterpret_cast<VT*>(p) = v;
+}
 
 template <class T, bool MIXED>
 SMR_DEV T load_at(const char* p, int dtype, int conj) {
@@ -330,7 +351,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
                         for (int h = 0; h < V; ++h) out.v[h] = cj(out.v[h]);
                     }
                 }
-                *reinterpret_cast<VT*>(p) = out;
+                store_vec<VT>(p, out, a.nts);
             }
         }
     }
@@ -508,7 +529,7 @@ SMR_DEV void tiled_map_pipe_body(const TiledArgs<WIDE> a, F f) {
                         for (int h = 0; h < V; ++h) out.v[h] = cj(out.v[h]);
                     }
                 }
-                *reinterpret_cast<VT*>(p) = out;
+                store_vec<VT>(p, out, a.nts);
             }
         }
         if (!more) break;
@@ -685,6 +706,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         }
     };
     TiledArgs<WIDE> a;
+    const int nts_now = (options().nt_store > 0 || (options().nt_store < 0 && c.nout * (i64)c.esize[0] <= options().nt_store_max)) ? 1 : 0;
     // the arguments depend on the plan only, except for the operand addresses: built once
     std::vector<unsigned char>& cached = plan.tiled_args[variant];
     if (cached.size() == sizeof a) {
@@ -693,6 +715,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             if (!a.base32 || a.ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
         }
         for (int k = 0; k < c.M; ++k) a.op[k].base = tab.base[k];
+        a.nts = nts_now;
         return launch(a);
     }
     std::memset(&a, 0, sizeof a);
@@ -904,6 +927,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         cached.resize(sizeof a);
         std::memcpy(cached.data(), &a, sizeof a);
     }
+    a.nts = nts_now;
     return launch(a);
 }
 

@@ -489,6 +489,196 @@ static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
     t.ord_groups = (int)orbits.size();
 }
 
+
+// ---- orbit planning (FAM_ORBIT) ----------------------------------------------------------------------
+// B .= (A .+ A')./2, the 4-way permuted sum, ... : every input is a permuted view of ONE buffer.  The
+// classic tiled kernel reads that buffer once per view (through L1: 4 x 8 MiB for the 4-way sum at 32^4);
+// here the workgroup that owns a tile also owns its images under the permutation group, loads the buffer
+// on those tiles once (natural order, full vectors) and serves every view from LDS.  Measured on MI355X
+// (tools/c3_proto.hip, 4-way sum f64): 32^4 6.6 -> 4.7 us, 64^4 83 -> 46 us, 128^4 1.73 -> 1.41 ms.
+static bool plan_orbit(const Canon& c, OrbitPlan& o) {
+    const Options& opt = options();
+    if (!opt.orbit) return false;
+    if (c.redop != SMR_RED_NONE || c.mixed || c.bitcopy) return false;
+    if (c.M < 3 || c.N < 2 || c.strides[0][0] != 1) return false;
+    const int es = dtype_size(c.ct);
+    // one buffer, one element type
+    for (int k = 2; k < c.M; ++k) {
+        if (c.dtype[k] != c.dtype[1]) return false;
+        if ((char*)c.base[k] + c.offsets[k] * c.esize[k] != (char*)c.base[1] + c.offsets[1] * c.esize[1]) return false;
+    }
+    if (c.dtype[0] != c.dtype[1]) return false;
+    // identity view: an input with exactly the destination's strides
+    o.k0 = -1;
+    for (int k = 1; k < c.M && o.k0 < 0; ++k) {
+        bool same = true;
+        for (int d = 0; d < c.N; ++d) same = same && c.strides[k][d] == c.strides[0][d];
+        if (same) o.k0 = k;
+    }
+    if (o.k0 < 0) return false;
+    const i64* s = c.strides[o.k0];
+    for (int d = 0; d < c.N; ++d) {
+        if (s[d] <= 0) return false;
+        for (int e = 0; e < d; ++e)
+            if (s[e] == s[d]) return false;
+    }
+    // pi_k: strides of input k = strides of the identity view permuted
+    for (int k = 1; k < c.M; ++k) {
+        bool used[MAXN] = {false};
+        for (int d = 0; d < c.N; ++d) {
+            int hit = -1;
+            for (int e = 0; e < c.N && hit < 0; ++e)
+                if (!used[e] && s[e] == c.strides[k][d] && c.dims[e] == c.dims[d]) hit = e;
+            if (hit < 0) return false;
+            used[hit] = true;
+            o.pdim[k][d] = hit;
+        }
+    }
+    // the group they generate (closure under composition), identity first
+    std::vector<std::array<int, MAXN>> G;
+    {
+        std::array<int, MAXN> id;
+        for (int d = 0; d < MAXN; ++d) id[d] = d;
+        G.push_back(id);
+        for (size_t head = 0; head < G.size(); ++head)
+            for (int k = 1; k < c.M; ++k) {
+                std::array<int, MAXN> h = id;
+                for (int d = 0; d < c.N; ++d) h[d] = o.pdim[k][G[head][d]];  // pi_k o g
+                if (std::find(G.begin(), G.end(), h) == G.end()) {
+                    if ((int)G.size() >= MAXG) return false;
+                    G.push_back(h);
+                }
+            }
+    }
+    o.ng = (int)G.size();
+    if (o.ng < 2) return false;
+    for (int a = 0; a < o.ng; ++a) {
+        for (int d = 0; d < MAXN; ++d) o.gdim[a][d] = G[a][d];
+        for (int k = 1; k < c.M; ++k) {
+            std::array<int, MAXN> h = G[0];
+            for (int d = 0; d < c.N; ++d) h[d] = o.pdim[k][G[a][d]];
+            o.slot[a][k] = (int)(std::find(G.begin(), G.end(), h) - G.begin());
+        }
+        o.slot[a][0] = a;
+    }
+    // the unit class: dims that are the unit-stride axis of some view
+    bool unit[MAXN] = {false};
+    int nu = 0;
+    for (int a = 0; a < o.ng; ++a)
+        if (!unit[G[a][0]]) {
+            unit[G[a][0]] = true;
+            ++nu;
+        }
+    // tile edge: the largest power of two that divides the unit dims, fits LDS and leaves enough orbits
+    const i64 n0 = c.dims[0];
+    i64 others = 1;
+    for (int d = 0; d < c.N; ++d)
+        if (!unit[d]) others *= c.dims[d];
+    const int vmax = std::max(1, 16 / es);
+    int vlog = 0;
+    while ((1 << vlog) < vmax) ++vlog;
+    // 16-byte accesses need aligned operands and vector-multiple strides; element-wise tiles stay <= 1024 elements
+    bool vec_ok = vmax > 1;
+    for (int d = 1; d < c.N; ++d)
+        if (s[d] % vmax) vec_ok = false;
+    if ((((uintptr_t)c.base[0] + (uintptr_t)(c.offsets[0] * c.esize[0])) | ((uintptr_t)c.base[o.k0] + (uintptr_t)(c.offsets[o.k0] * c.esize[o.k0]))) % 16) vec_ok = false;
+    const int maxbits = (vmax > 1 && !vec_ok) ? 10 : 12;
+    int best = -1;
+    for (int l = maxbits / nu; l >= 1; --l) {
+        if (n0 & (((i64)1 << l) - 1)) continue;
+        if ((size_t)o.ng * ((size_t)es << (l * nu)) > (size_t)128 * 1024) continue;
+        if (((i64)es << l) < 32 || l < vlog) continue;  // runs of at least 32 bytes
+        if (opt.orbit_lg >= 0) {
+            if (l == opt.orbit_lg) best = l;
+            continue;
+        }
+        i64 tiles = others;
+        for (int u = 0; u < nu; ++u) tiles *= n0 >> l;
+        best = l;  // the smallest admissible edge when no edge yields orbit_min orbits
+        if (tiles / o.ng >= opt.orbit_min) break;
+    }
+    if (best < 0) return false;
+    o.tilelog = best * nu;
+    if (o.tilelog < 8) return false;  // at least 256 elements per tile (128 lanes x 16 B); smaller: classic kernel
+    o.ntiles_total = 1;
+    for (int d = 0; d < c.N; ++d) {
+        o.lg[d] = unit[d] ? best : 0;
+        o.ntiles[d] = c.dims[d] >> o.lg[d];
+        o.ntiles_total *= o.ntiles[d];
+    }
+    for (int d = c.N; d < MAXN; ++d) {
+        o.lg[d] = 0;
+        o.ntiles[d] = 1;
+    }
+    if (o.ntiles_total > ((i64)1 << 22)) return false;
+    // 16-byte accesses: every non-unit stride a multiple of the vector (alignment is re-checked at launch)
+    o.vec = vec_ok ? vmax : 1;
+    o.lds_bytes = (size_t)o.ng * ((size_t)es << o.tilelog);
+    {  // 32-bit byte offsets inside a tile
+        long double span = 0;
+        for (int d = 0; d < c.N; ++d) span += (long double)(((i64)1 << o.lg[d]) - 1) * (long double)s[d] * es;
+        if (span >= 2147483648.0L) return false;
+        // slot origins travel as 32-bit element offsets
+        long double last = 0;
+        for (int d = 0; d < c.N; ++d) last += (long double)(c.dims[d] - 1) * (long double)s[d];
+        if (last >= 4294967295.0L) return false;
+    }
+
+    // orbits of tile coordinates; one root per orbit, listed super-cell by super-cell (2 tiles along every
+    // tiled dim: the partner halves of 64-B runs then meet in one XCD's L2), XCD-contiguous runs
+    i64 tmul[MAXN], acc = 1;
+    for (int d = 0; d < c.N; ++d) {
+        tmul[d] = acc;
+        acc *= o.ntiles[d];
+    }
+    std::vector<char> seen((size_t)o.ntiles_total, 0);
+    std::vector<uint32_t> list;
+    i64 ncell[MAXN], cells = 1;
+    int sub[MAXN];
+    for (int d = 0; d < c.N; ++d) {
+        sub[d] = (o.lg[d] > 0 && o.ntiles[d] > 1) ? 2 : 1;
+        ncell[d] = (o.ntiles[d] + sub[d] - 1) / sub[d];
+        cells *= ncell[d];
+    }
+    int nsub = 1;
+    for (int d = 0; d < c.N; ++d) nsub *= sub[d];
+    for (i64 cell = 0; cell < cells; ++cell) {
+        i64 cc[MAXN], r = cell;
+        for (int d = 0; d < c.N; ++d) {
+            cc[d] = r % ncell[d];
+            r /= ncell[d];
+        }
+        for (int q = 0; q < nsub; ++q) {
+            i64 t[MAXN];
+            int qq = q;
+            bool inside = true;
+            for (int d = 0; d < c.N; ++d) {
+                t[d] = cc[d] * sub[d] + qq % sub[d];
+                qq /= sub[d];
+                if (t[d] >= o.ntiles[d]) inside = false;
+            }
+            if (!inside) continue;
+            i64 root = -1;
+            for (int a = 0; a < o.ng; ++a) {
+                i64 id = 0;
+                for (int d = 0; d < c.N; ++d) id += t[d] * tmul[G[a][d]];
+                if (root < 0 || id < root) root = id;
+            }
+            if (seen[(size_t)root]) continue;
+            seen[(size_t)root] = 1;
+            list.push_back((uint32_t)root);
+        }
+    }
+    o.norbits = (int)list.size();
+    constexpr int NX = 8;
+    const size_t cs = (list.size() + NX - 1) / NX;
+    o.list.assign(cs * NX, 0xffffffffu);
+    for (size_t x = 0; x < (size_t)NX; ++x)
+        for (size_t sl = 0; sl < cs; ++sl)
+            if (x * cs + sl < list.size()) o.list[sl * NX + x] = list[x * cs + sl];
+    return true;
+}
+
 static bool plan_tiles(const Canon& c, TilePlan& t) {
     if (c.redop != SMR_RED_NONE) return false;
     if (c.N < 2 || c.strides[0][0] != 1) return false;
@@ -640,6 +830,8 @@ int make_plan(const smr_problem* p, Plan& plan) {
         }
         if (stream) {
             fam = FAM_STREAM;
+        } else if (o.force_family != FAM_TILED && o.force_family != FAM_GENERIC && plan_orbit(c, plan.orbit)) {
+            fam = FAM_ORBIT;
         } else if (plan_tiles(c, plan.tile)) {
             fam = FAM_TILED;
         } else if (c.dims[0] >= 64) {
@@ -795,7 +987,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
 
 void describe(Plan& plan) {
     const Canon& c = plan.c;
-    static const char* fam[] = {"auto", "generic", "stream", "tiled", "reduce_all", "reduce_part"};
+    static const char* fam[] = {"auto", "generic", "stream", "tiled", "reduce_all", "reduce_part", "orbit"};
     static const char* fk[] = {"prog", "ident", "add2", "add3", "add4", "scale", "sym", "axpy", "axpby", "abs2", "mul2", "expr5"};
     static const char* ct[] = {"f32", "f64", "c32", "c64"};
     char buf[1024];
@@ -809,6 +1001,16 @@ void describe(Plan& plan) {
         n += std::snprintf(buf + n, sizeof buf - n, " staged=%d lds=%zu grid=%lld threads=%d", plan.tile.nstaged,
                            plan.tile.lds_bytes, (long long)plan.tile.grid, plan.tile.threads);
         if (!plan.tile.ord.empty()) n += std::snprintf(buf + n, sizeof buf - n, " order=orbits:%d", plan.tile.ord_groups);
+    } else if (plan.family == FAM_ORBIT) {
+        const OrbitPlan& ob = plan.orbit;
+        n += std::snprintf(buf + n, sizeof buf - n, " tile=");
+        bool first = true;
+        for (int d = 0; d < c.N; ++d)
+            if (ob.lg[d] > 0) {
+                n += std::snprintf(buf + n, sizeof buf - n, "%sd%d:%d", first ? "" : ",", d, 1 << ob.lg[d]);
+                first = false;
+            }
+        n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.list.size());
     } else if (plan.family == FAM_STREAM) {
         n += std::snprintf(buf + n, sizeof buf - n, " vec=%d", plan.vec);
     } else if (plan.family == FAM_REDUCE_ALL) {

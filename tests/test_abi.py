@@ -52,7 +52,17 @@ def test_planning_needs_no_device_and_picks_the_expected_family():
     assert "family=tiled" in d and "f=ident" in d and "tile=d0:32,d3:32" in d and "algbytes=16777216" in d
     ps = [x.permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]
     d = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps)).describe()
-    assert "family=tiled" in d and "f=add4" in d and "staged=3" in d and "algbytes=16777216" in d
+    assert "family=orbit" in d and "f=add4" in d and "group=4" in d and "tile=d0:4,d1:4,d2:4,d3:4" in d and "algbytes=16777216" in d
+    S.set_option("orbit", 0)  # the classic tiled kernel stays available (distinct buffers, ragged sizes, tuning)
+    try:
+        d = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps)).describe()
+        assert "family=tiled" in d and "f=add4" in d and "staged=3" in d and "algbytes=16777216" in d
+    finally:
+        S.set_option("orbit", 1)
+    # four DISTINCT arrays with the same permuted strides: no shared buffer, classic kernel
+    zs = [x.similar().permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]
+    d = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *zs)).describe()
+    assert "family=tiled" in d and "staged=3" in d
     d = S.make_plan(lambda a: a * S.fn.exp(-2 * a) + S.fn.sin(a * a), None, None, x.size, (y, x)).describe()
     assert "family=stream" in d and "f=expr5" in d and "N=1" in d  # 4 dims fuse into one
     o = x.similar(size=(1,))
@@ -69,8 +79,15 @@ def _sym_plan(m, dtype=np.float64):
     return S.make_plan(lambda x, y: (x + y) / 2, None, None, a.size, (b, a, a.permutedims((1, 0))))
 
 
+@pytest.fixture
+def classic_tiled():
+    S.set_option("orbit", 0)
+    yield
+    S.set_option("orbit", 1)
+
+
 @pytest.mark.parametrize("m", [200, 1000, 4000])
-def test_tile_order_is_a_permutation_that_keeps_transposed_partners_on_one_xcd(m):
+def test_tile_order_is_a_permutation_that_keeps_transposed_partners_on_one_xcd(m, classic_tiled):
     """B .= (A .+ A')./2: tile (i, j) and tile (j, i) read the same two regions of A; the planner
     must run them back to back on one XCD (workgroup b -> XCD b mod 8) and every tile once."""
     plan = _sym_plan(m)
@@ -94,7 +111,58 @@ def test_tile_order_is_a_permutation_that_keeps_transposed_partners_on_one_xcd(m
     assert (~(same_xcd & adjacent)).sum() <= 2 * 7
 
 
-def test_tile_order_four_way_permuted_sum_and_opt_out():
+def _orbit_cover(roots, nt, perms):
+    """tiles covered by the orbits of `roots` (linear ids, dim 0 fastest) under the dim permutations"""
+    nd = len(nt)
+    mul = np.cumprod([1] + list(nt[:-1]))
+    covered = []
+    for r in roots:
+        t = [(r // mul[d]) % nt[d] for d in range(nd)]
+        orb = set()
+        for g in perms:
+            u = [0] * nd
+            for d in range(nd):
+                u[g[d]] = t[d]
+            orb.add(int(sum(u[d] * mul[d] for d in range(nd))))
+        covered.extend(sorted(orb))
+    return covered
+
+
+def test_orbit_list_covers_every_tile_once_and_groups_line_partners():
+    """FAM_ORBIT: one workgroup per orbit of tiles under the group the permuted views generate; the list
+    holds exactly one root per orbit (every tile is computed exactly once) and the orbits of one
+    super-cell (2 tiles along every tiled dim) run on one XCD."""
+    x = S.StridedView(np.zeros((32, 32, 32, 32), order="F"))
+    y = x.similar()
+    ps = [x.permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]
+    plan = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps))
+    assert "family=orbit" in plan.describe() and "orbits=1044" in plan.describe()  # necklaces of length 4 over 8 symbols
+    lst = np.array(plan.tile_order(), dtype=np.int64)
+    assert len(lst) % 8 == 0
+    roots = lst[lst != 0xFFFFFFFF]
+    assert len(roots) == 1044
+    rot = [[(d + k) % 4 for d in range(4)] for k in range(4)]
+    assert sorted(_orbit_cover(roots, (8, 8, 8, 8), rot)) == list(range(8 ** 4))
+    # super-cell (2^4 tiles) of a root; its orbits occupy consecutive slots of ONE XCD (runs may be cut 7 times)
+    where = {int(r): i for i, r in enumerate(lst) if r != 0xFFFFFFFF}
+    cells = {}
+    for r, i in where.items():
+        t = [(r // 8 ** d) % 8 for d in range(4)]
+        cells.setdefault(tuple(c // 2 for c in t), []).append(i)
+    split = sum(1 for v in cells.values() if len({i % 8 for i in v}) > 1)
+    assert split <= 7
+    # symmetrise: pairs of transposed 32x32 tiles, diagonal tiles alone
+    plan = _sym_plan(4000)
+    assert "family=orbit" in plan.describe() and "group=2" in plan.describe() and "tile=d0:32,d1:32" in plan.describe()
+    lst = np.array(plan.tile_order(), dtype=np.int64)
+    roots = lst[lst != 0xFFFFFFFF]
+    assert len(roots) == 125 * 126 // 2
+    assert sorted(_orbit_cover(roots, (125, 125), [[0, 1], [1, 0]])) == list(range(125 * 125))
+    # sizes without a power-of-two divisor fall back to the classic kernel with ragged tiles
+    assert "family=tiled" in _sym_plan(1000).describe()
+
+
+def test_tile_order_four_way_permuted_sum_and_opt_out(classic_tiled):
     x = S.StridedView(np.zeros((32, 32, 32, 32), order="F"))
     y = x.similar()
     ps = [x.permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]

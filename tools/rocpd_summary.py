@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd sqlite database: per-kernel dispatch count / avg / min / max
 duration (ns) and, when present, PMC counter values per kernel.  Writes a text table to stdout.
-Usage: python tools/rocpd_summary.py results.db [more.db ...]"""
+Usage: python tools/rocpd_summary.py [--hist] results.db [more.db ...]
+--hist adds, per kernel, the percentiles of the dispatch durations and a coarse histogram."""
 import sqlite3
 import sys
 
@@ -41,5 +42,39 @@ def summarise(path):
                 print("   ", t, [c[1] for c in cur.execute(f"pragma table_info('{t}')")])
 
 
-for p in sys.argv[1:]:
+def histogram(path):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    names = [r[0] for r in cur.execute(f"select distinct s.kernel_name from {kd} d join {ks} s on d.kernel_id = s.id")]
+    for name in names:
+        rows = list(cur.execute(f"select d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id where s.kernel_name = ? order by d.start", (name,)))
+        if len(rows) < 20:
+            continue
+        dur = sorted(e - s for s, e in rows)
+        gaps = sorted(rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1))
+        starts = sorted(rows[i + 1][0] - rows[i][0] for i in range(len(rows) - 1))
+        q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]  # noqa: E731
+        print(f"-- {name[:100]}")
+        print(f"   n={len(dur)}  duration ns: min {dur[0]} p5 {q(dur, .05)} p25 {q(dur, .25)} p50 {q(dur, .5)} p75 {q(dur, .75)} p95 {q(dur, .95)} max {dur[-1]}  mean {sum(dur) / len(dur):.0f}")
+        print(f"   start-to-start ns (back-to-back cadence): p5 {q(starts, .05)} p25 {q(starts, .25)} p50 {q(starts, .5)} p75 {q(starts, .75)} p95 {q(starts, .95)}")
+        print(f"   end-to-next-start gap ns: p5 {q(gaps, .05)} p50 {q(gaps, .5)} p95 {q(gaps, .95)}")
+        lo, hi = dur[0], q(dur, .99)
+        nb = 16
+        w = max(1, (hi - lo + nb) // nb)
+        cnt = [0] * (nb + 1)
+        for d in dur:
+            cnt[min(nb, (d - lo) // w)] += 1
+        for b, c in enumerate(cnt):
+            if c:
+                print(f"   {lo + b * w:7d}..{lo + (b + 1) * w:7d} ns {c:7d} {'#' * max(1, 60 * c // len(dur))}")
+
+
+args = sys.argv[1:]
+hist = "--hist" in args
+for p in [a for a in args if a != "--hist"]:
     summarise(p)
+    if hist:
+        histogram(p)
