@@ -242,6 +242,18 @@ int smr_plan_jit_source(const smr_plan* plan, char* buf, size_t buflen);
  * per-shard partial destinations with RCCL (ncclAllReduce, op = redop).                  */
 int smr_shard(const smr_problem* problem, int nshards, int shard, smr_problem* out,
               int* needs_allreduce);
+/* The same with block-partitioned operands: bit k of `local_ops` says that ops[k].base/offset
+ * already address THIS shard's slab (box index `start` of the split dim is the operand's index 0
+ * along it; strides unchanged), so that operand's offset is not shifted and nothing has to be
+ * replicated across devices.  *split_dim / *start / *stop (optional) report the slab
+ * [start, stop) of box dim split_dim this shard owns (-1 when nshards == 1).               */
+int smr_shard_ex(const smr_problem* problem, int nshards, int shard, uint32_t local_ops,
+                 smr_problem* out, int* needs_allreduce, int* split_dim, int64_t* start,
+                 int64_t* stop);
+/* Writes the neutral element of problem->redop (0, 1, +inf, -inf, true, false) into every
+ * distinct destination element: what _init_reduction! does for the per-task partial slots
+ * (src/mapreduce.jl:182-191,157-163).  Asynchronous on problem->stream.                    */
+int smr_init_reduction(const smr_problem* problem);
 
 /* ---- multi-GPU from plain C: one process per GPU, RCCL over xGMI --------------------------
  * The C twin of what strided.jl_amd/distributed.py does through torch.distributed, for hosts
@@ -259,6 +271,8 @@ int smr_comm_init(int nranks, int rank, const void* unique_id, size_t len);
 int smr_comm_rank(int* rank, int* nranks);
 int smr_comm_destroy(void);
 int smr_mapreduce_sharded(const smr_problem* problem);
+/* ... with block-partitioned operands (see smr_shard_ex).                                   */
+int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
 
 /* Tuning knobs; smr_set_option returns SMR_EINVAL for unknown names.  Analogue of the
  * reference's compile-time constants MINTHREADLENGTH / BLOCKMEMORYSIZE

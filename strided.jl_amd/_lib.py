@@ -75,7 +75,7 @@ EXPORTS = [
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
     "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
-    "smr_comm_destroy", "smr_mapreduce_sharded", "smr_shard", "smr_set_option",
+    "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option",
 ]
 
@@ -140,6 +140,14 @@ def load():
     lib.smr_plan_tile_order.restype = C.c_int64
     lib.smr_shard.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.POINTER(smr_problem),
                               C.POINTER(C.c_int)]
+    lib.smr_shard_ex.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.c_uint32, C.POINTER(smr_problem),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.smr_init_reduction.argtypes = [C.POINTER(smr_problem)]
+    lib.smr_mapreduce_sharded.argtypes = [C.POINTER(smr_problem)]
+    lib.smr_mapreduce_sharded_ex.argtypes = [C.POINTER(smr_problem), C.c_uint32]
+    lib.smr_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+    lib.smr_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.smr_comm_rank.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.smr_set_option.argtypes = [C.c_char_p, C.c_int64]
     lib.smr_get_option.argtypes = [C.c_char_p]
     lib.smr_get_option.restype = C.c_int64

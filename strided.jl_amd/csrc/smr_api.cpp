@@ -347,11 +347,19 @@ int smr_mapreduce(const smr_problem* problem) {
 }
 
 int smr_shard(const smr_problem* p, int nshards, int shard, smr_problem* out, int* needs_allreduce) {
+    return smr_shard_ex(p, nshards, shard, 0u, out, needs_allreduce, nullptr, nullptr, nullptr);
+}
+
+int smr_shard_ex(const smr_problem* p, int nshards, int shard, uint32_t local_ops, smr_problem* out, int* needs_allreduce, int* split_dim,
+                 int64_t* start_out, int64_t* stop_out) {
     if (!p || !out) return set_error(SMR_EINVAL, "null argument");
     if (nshards < 1 || shard < 0 || shard >= nshards) return set_error(SMR_EINVAL, "bad shard index");
     if (p->N < 1 || p->N > SMR_MAXN || p->M < 1 || p->M > SMR_MAXM) return set_error(SMR_EINVAL, "bad N/M");
     *out = *p;
     if (needs_allreduce) *needs_allreduce = 0;
+    if (split_dim) *split_dim = -1;
+    if (start_out) *start_out = 0;
+    if (stop_out) *stop_out = 0;
     if (nshards == 1) return SMR_OK;
     // Split dim: the slowest-varying destination dim that is long enough (destination slabs
     // are then disjoint and contiguous-ish); for reductions prefer a kept dim so that no
@@ -396,7 +404,14 @@ int smr_shard(const smr_problem* p, int nshards, int shard, smr_problem* out, in
     const int64_t d = p->dims[best];
     const int64_t start = d * shard / nshards, end = d * (shard + 1) / nshards;
     out->dims[best] = end - start;
-    for (int k = 0; k < p->M; ++k) out->ops[k].offset = p->ops[k].offset + start * p->ops[k].strides[best];
+    // an operand flagged in local_ops is already this shard's slab: its base/offset address box index
+    // `start` of the split dim (block-partitioned inputs: nothing is replicated); the others live in the whole
+    // parent and get the reference's offset shift (src/mapreduce.jl:217-219)
+    for (int k = 0; k < p->M; ++k)
+        if (!((local_ops >> k) & 1u)) out->ops[k].offset = p->ops[k].offset + start * p->ops[k].strides[best];
+    if (split_dim) *split_dim = best;
+    if (start_out) *start_out = start;
+    if (stop_out) *stop_out = end;
     if (allred && shard != 0) out->initop = SMR_INIT_NONE;  // initop is applied once, on shard 0
     if (needs_allreduce) *needs_allreduce = allred;
     return SMR_OK;
@@ -423,6 +438,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "nt_store_max") o.nt_store_max = value;
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "orbit_min") o.orbit_min = value;
+    else if (n == "orbit_few") o.orbit_few = value;
     else if (n == "orbit_lg") o.orbit_lg = value;
     else if (n == "orbit") o.orbit = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
@@ -460,6 +476,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "nt_store_max") return o.nt_store_max;
     if (n == "nt_store") return o.nt_store;
     if (n == "orbit_min") return o.orbit_min;
+    if (n == "orbit_few") return o.orbit_few;
     if (n == "orbit_lg") return o.orbit_lg;
     if (n == "orbit") return o.orbit;
     if (n == "max_lds_bytes") return o.max_lds_bytes;

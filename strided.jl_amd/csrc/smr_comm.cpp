@@ -100,6 +100,7 @@ void kept_box(const smr_problem* p, int64_t* dims, int64_t* count) {
 }
 
 int fill_neutral(const smr_problem* p) {
+    if (p->redop <= SMR_RED_NONE || p->redop > SMR_RED_OR) return set_error(SMR_EINVAL, "smr_init_reduction: the problem has no reduction op");
     smr_problem f;
     std::memset(&f, 0, sizeof f);
     int64_t cnt;
@@ -213,7 +214,14 @@ int smr_comm_destroy(void) {
     return SMR_OK;
 }
 
-int smr_mapreduce_sharded(const smr_problem* p) {
+int smr_init_reduction(const smr_problem* p) {
+    if (!p) return set_error(SMR_EINVAL, "null problem");
+    return fill_neutral(p);
+}
+
+int smr_mapreduce_sharded(const smr_problem* p) { return smr_mapreduce_sharded_ex(p, 0u); }
+
+int smr_mapreduce_sharded_ex(const smr_problem* p, uint32_t local_ops) {
     if (!p) return set_error(SMR_EINVAL, "null problem");
     CommState& s = st();
     int nranks, rank;
@@ -222,11 +230,23 @@ int smr_mapreduce_sharded(const smr_problem* p) {
         nranks = s.nranks;
         rank = s.rank;
     }
-    if (nranks == 1) return smr_mapreduce(p);
+    bool have_comm;
+    {
+        std::lock_guard<std::mutex> g(s.mu);
+        have_comm = s.comm != nullptr;
+    }
+    if (nranks == 1 && !have_comm) return smr_mapreduce(p);
     smr_problem sub;
     int need = 0;
-    int rc = smr_shard(p, nranks, rank, &sub, &need);
+    int rc = smr_shard_ex(p, nranks, rank, local_ops, &sub, &need, nullptr, nullptr, nullptr);
     if (rc) return rc;
+    // a one-rank communicator (created with a unique id) still runs the collective step of a complete
+    // reduction: the whole path -- gather, ncclAllReduce, scatter -- is exercised on a single GPU
+    if (nranks == 1 && p->redop != SMR_RED_NONE) {
+        need = 1;
+        for (int i = 0; i < p->N; ++i)
+            if (p->ops[0].strides[i] != 0 && p->dims[i] > 1) need = 0;
+    }
     if (!need) return smr_mapreduce(&sub);
     ncclDataType_t t;
     size_t mult;

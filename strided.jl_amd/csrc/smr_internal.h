@@ -198,7 +198,8 @@ struct Options {
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
-    i64 orbit_min = 1024;    // pick the largest tile edge that still yields this many orbits
+    i64 orbit_min = 150;     // pick the largest tile edge that still yields this many orbits (measured: tools/orbit_sweep.py)
+    i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
     i64 nt_store = 0;        // non-temporal stores: -1 = when the destination is at most nt_store_max bytes, 0 never, 1 always
                              // (measured on MI355X: no gain on the library's kernels at any size -> off)
     i64 nt_store_max = (i64)32 << 20;

@@ -98,43 +98,77 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     const uint32_t tid = threadIdx.x;
     // ---- slot origins: one wide scalar load of this workgroup's table row -----------------------------
     i64 org[NG];
+    bool live;
     {
         typedef uint32_t rowv __attribute__((ext_vector_type(NG)));
         const rowv row = reinterpret_cast<const rowv*>(a.list)[blockIdx.x];
         uint32_t o32[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) o32[g] = row[g];
-        if (o32[0] == 0xffffffffu) return;  // padding workgroup (whole workgroup: no barrier is skipped)
+        // a padding workgroup (first word 0xffffffff) runs on slot origins 0 and only skips its stores: an early
+        // exit here would keep every other kernel-argument load behind this row's round trip
+        live = o32[0] != 0xffffffffu;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) org[g] = (i64)o32[g] * (i64)sizeof(T);
+        for (int g = 0; g < NG; ++g) org[g] = live ? (i64)o32[g] * (i64)sizeof(T) : 0;
     }
 
-    // ---- per-lane offsets: bit slices of the element number ---------------------------------------
-    uint32_t goff[NREP];  // byte offset inside a tile (natural order)
-    uint32_t lr[NK][NREP];  // LDS index of the lane's first element seen through view k
+    // ---- per-lane byte offsets inside a tile: bit slices of the element number -----------------------
+    uint32_t goff[NREP], cj[NREP][OMAXT];
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
         const uint32_t e = (((uint32_t)r << a.ntlog) | tid) * V;
         uint32_t g = 0;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) lr[k][r] = 0;
-#pragma unroll
         for (int j = 0; j < OMAXT; ++j) {
-            const uint32_t cj = __builtin_amdgcn_ubfe(e, (uint32_t)a.esh[j], (uint32_t)a.elen[j]);
-            g += cj * a.estride[j];
-#pragma unroll
-            for (int k = (OWN0 ? 1 : 0); k < NK; ++k) lr[k][r] |= cj << a.lsh[k][j];
+            cj[r][j] = __builtin_amdgcn_ubfe(e, (uint32_t)a.esh[j], (uint32_t)a.elen[j]);
+            g += cj[r][j] * a.estride[j];
         }
         goff[r] = g;
     }
-    auto swz = [&](uint32_t i) { return i ^ (((i >> a.swz_s1) ^ (i >> a.swz_s2)) & a.swz_mask); };
 
-    // ---- load every slot (natural order), park it in LDS ------------------------------------------
+    // ---- load every slot (natural order) --------------------------------------------------------------
     VT x[NG][NREP];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int r = 0; r < NREP; ++r) x[g][r] = *reinterpret_cast<const VT*>(a.src + org[g] + goff[r]);
+
+    // ---- while the loads fly: everything the exchange needs from the kernel arguments ---------------
+    // (left to itself the compiler sinks these scalar loads below the barrier: one more serial scalar-memory
+    // round trip in a 5 us launch; the empty asm statements pin the values in registers here)
+    uint32_t lr[NK][NREP];  // LDS index of the lane's first element seen through view k
+#pragma unroll
+    for (int r = 0; r < NREP; ++r)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            uint32_t l = 0;
+            if (!(OWN0 && k == 0)) {
+#pragma unroll
+                for (int j = 0; j < OMAXT; ++j) l |= cj[r][j] << a.lsh[k][j];
+            }
+            lr[k][r] = l;
+        }
+    uint32_t swz_s1 = a.swz_s1, swz_s2 = a.swz_s2, swz_mask = a.swz_mask;
+    asm volatile("" : "+s"(swz_s1), "+s"(swz_s2), "+s"(swz_mask));
+    uint32_t sbase[NG][NK], hbit[NK], cbit[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        hbit[k] = (uint32_t)a.lsh[k][0];
+        cbit[k] = a.conjbit[k];
+        asm volatile("" : "+s"(hbit[k]), "+s"(cbit[k]));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            sbase[g][k] = (uint32_t)a.slot[g][k] << a.tilelog;
+            asm volatile("" : "+s"(sbase[g][k]));
+        }
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(lr[k][r]));
+    }
+    uint32_t conj0 = a.conj0 ? 0x80000000u : 0u, nts_flag = (uint32_t)a.nts;
+    asm volatile("" : "+s"(conj0), "+s"(nts_flag));
+    auto swz = [&](uint32_t i) { return i ^ (((i >> swz_s1) ^ (i >> swz_s2)) & swz_mask); };
+
+    // ---- park the slots in LDS ---------------------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         T* L = lds + ((size_t)g << a.tilelog);
@@ -147,11 +181,27 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     }
     __syncthreads();
 
-    // ---- outputs of every slot ---------------------------------------------------------------------
+    // ---- outputs of every slot: all LDS reads of a repeat are issued before the first use ----------------
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int r = 0; r < NREP; ++r) {
+        T val[NG][V][NK];
 #pragma unroll
-        for (int r = 0; r < NREP; ++r) {
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int h = 0; h < V; ++h)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    if (OWN0 && k == 0) {
+                        val[g][h][k] = x[g][r].v[h];
+                    } else {
+                        // sub-element h moves along tiled dim 0 of the natural order
+                        const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
+                        val[g][h][k] = lds[sbase[g][k] + swz(idx)];
+                    }
+                }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads together: one LDS latency per repeat, not one per output
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
             VT out;
 #pragma unroll
             for (int h = 0; h < V; ++h) {
@@ -160,27 +210,21 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
                 for (int k = 0; k < MAXIN; ++k) {
                     arg[k] = T{};
                     if (k < NK) {
-                        T v;
-                        if (OWN0 && k == 0) {
-                            v = x[g][r].v[h];
-                        } else {
-                            // sub-element h moves along tiled dim 0 of the natural order
-                            const uint32_t idx = lr[k < NK ? k : 0][r] | ((uint32_t)h << a.lsh[k][0]);
-                            v = lds[((size_t)a.slot[g][k] << a.tilelog) + swz(idx)];
-                        }
-                        if constexpr (tr<T>::cx) v = ocj(v, a.conjbit[k]);
+                        T v = val[g][h][k < NK ? k : 0];
+                        if constexpr (tr<T>::cx) v = ocj(v, cbit[k < NK ? k : 0]);
                         arg[k] = v;
                     }
                 }
                 (void)nin;
                 T o = f(arg);
-                if constexpr (tr<T>::cx) o = ocj(o, a.conj0 ? 0x80000000u : 0u);
+                if constexpr (tr<T>::cx) o = ocj(o, conj0);
                 out.v[h] = o;
             }
             x[g][r] = out;
         }
     }
-    const bool nts = a.nts != 0;
+    if (!live) return;
+    const bool nts = nts_flag != 0;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll

@@ -26,13 +26,23 @@ from .mapreduce import _neutral, _redop_code, build_problem, copy_
 from .stridedview import StridedView
 
 
-def shard(f, op, initop, dims, arrays, nshards: int, index: int):
+def _local_mask(local, M):
+    if not local:
+        return 0
+    assert len(local) == M, "`local` needs one flag per operand (destination first)"
+    return sum(1 << k for k, f in enumerate(local) if f)
+
+
+def shard(f, op, initop, dims, arrays, nshards: int, index: int, local=None):
     """Sub-problem `index` of `nshards`: (dims, arrays, needs_allreduce, initop) with the views
-    restricted to the shard's sub-box (same parents, shifted offsets)."""
+    restricted to the shard's sub-box (same parents, shifted offsets).  `local[k]` = operand k is
+    block-partitioned: its parent IS this shard's slab (index 0 along the split dim = the slab's first
+    box index), so its offset stays put and nothing needs to be replicated."""
     p, keep = build_problem(f, op, initop, dims, arrays, stream=0)
     out = L.smr_problem()
     need = C.c_int(0)
-    L.check(L.load().smr_shard(C.byref(p), int(nshards), int(index), C.byref(out), C.byref(need)))
+    L.check(L.load().smr_shard_ex(C.byref(p), int(nshards), int(index), _local_mask(local, len(arrays)), C.byref(out),
+                                  C.byref(need), None, None, None))
     N = p.N
     sub_dims = tuple(int(out.dims[i]) for i in range(N))
     sub = []
@@ -68,15 +78,15 @@ def all_reduce_(view: StridedView, op, group=None) -> StridedView:
                       tuple(view.strides[d] for d in kept) or (1,), view.offset, view.op)
     copy_(dense, src)
     t = _as_tensor(dense)
-    if t.is_cuda:
-        import torch
-        torch.cuda.current_stream().synchronize()
+    # no host synchronisation: the gather above runs on torch's current stream, which the collective is
+    # ordered after (ProcessGroupNCCL waits for the current stream); the scatter below follows it on the
+    # same stream
     dist.all_reduce(t, op=_torch_reduce_op(op), group=group)
     copy_(src, dense)
     return view
 
 
-def mapreduce_sharded_(f, op, initop, dims, arrays, group=None):
+def mapreduce_sharded_(f, op, initop, dims, arrays, group=None, local=None):
     """The funnel, executed cooperatively by all ranks of `group`.
 
     Every rank passes the SAME logical problem over its own device copies of the operands.
@@ -93,7 +103,7 @@ def mapreduce_sharded_(f, op, initop, dims, arrays, group=None):
     if world == 1:
         mr._mapreduce_fuse_(f, op, initop, dims, arrays)
         return arrays[0]
-    sdims, sarrays, need, sinit = shard(f, op, initop, dims, arrays, world, rank)
+    sdims, sarrays, need, sinit = shard(f, op, initop, dims, arrays, world, rank, local)
     if need and rank != 0:
         # partial destinations of the other ranks start from the neutral element
         dest = arrays[0]
@@ -118,3 +128,39 @@ def shard_slices(dims, dest_strides, nshards):
         best = int(np.argmax(dims))
     d = dims[best]
     return best, [(d * r // nshards, d * (r + 1) // nshards) for r in range(nshards)]
+
+
+# ---- the C-level path (csrc/smr_comm.cpp): RCCL driven by the library itself -------------------------
+def comm_unique_id() -> bytes:
+    """128 bytes from rank 0 (ncclGetUniqueId); ship them to the other ranks out of band."""
+    buf = C.create_string_buffer(128)
+    L.check(L.load().smr_comm_unique_id(buf, 128))
+    return bytes(buf.raw)
+
+
+def comm_init(nranks: int, rank: int, unique_id: bytes | None = None):
+    """Every rank, with its device already selected.  `unique_id` may be None only for nranks == 1."""
+    if unique_id is None:
+        L.check(L.load().smr_comm_init(int(nranks), int(rank), None, 0))
+    else:
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        L.check(L.load().smr_comm_init(int(nranks), int(rank), buf, 128))
+
+
+def comm_destroy():
+    L.check(L.load().smr_comm_destroy())
+
+
+def comm_mapreduce_sharded_(f, op, initop, dims, arrays, local=None, stream=None):
+    """smr_mapreduce_sharded_ex: shard -> neutral fill on ranks != 0 -> local kernel -> gather ->
+    ncclAllReduce -> scatter, all issued by the library on `stream` (default: torch's current)."""
+    p, keep = build_problem(f, op, initop, dims, arrays, stream=stream)
+    L.check(L.load().smr_mapreduce_sharded_ex(C.byref(p), _local_mask(local, len(arrays))))
+    return arrays[0]
+
+
+def init_reduction_(op, dest: StridedView, stream=None):
+    """Neutral element of `op` into every distinct element of `dest` (smr_init_reduction)."""
+    p, keep = build_problem(lambda x: x, op, None, dest.size, (dest, dest), stream=stream)
+    L.check(L.load().smr_init_reduction(C.byref(p)))
+    return dest

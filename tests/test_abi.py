@@ -297,3 +297,22 @@ def test_planner_picks_the_vectorised_reduction_and_stream_forms():
     assert "family=stream" in d and "vec=1" in d
     d = S.make_plan(lambda x: x * 2, None, None, (100, 384), (b.sview(slice(0, 100), slice(None)), a.sview(slice(0, 100), slice(None)))).describe()
     assert "family=stream" in d and "vec=4" in d
+
+
+def test_shard_ex_local_operands_and_reported_slab():
+    """smr_shard_ex: flagged operands keep their offset (block-partitioned inputs), the others get the
+    reference's shift (src/mapreduce.jl:217-219); the slab [start, stop) is reported."""
+    x, y = _views((6, 5, 16), [(0, 0, 0), (1, 6, 30)], np.float32)
+    p, keep = S.build_problem(S.fn.abs2, "+", None, (6, 5, 16), (x, y), stream=0)
+    lib = L.load()
+    for nsh in (2, 4, 8):
+        for r in range(nsh):
+            out = L.smr_problem()
+            need, dim, lo, hi = C.c_int(0), C.c_int(-2), C.c_int64(-1), C.c_int64(-1)
+            assert lib.smr_shard_ex(C.byref(p), nsh, r, 0b10, C.byref(out), C.byref(need), C.byref(dim), C.byref(lo), C.byref(hi)) == 0
+            assert need.value == 1 and dim.value == 2
+            assert (lo.value, hi.value) == (16 * r // nsh, 16 * (r + 1) // nsh)
+            assert out.dims[2] == hi.value - lo.value and out.ops[1].offset == 0 and out.ops[0].offset == 0
+            out2 = L.smr_problem()
+            assert lib.smr_shard(C.byref(p), nsh, r, C.byref(out2), C.byref(need)) == 0
+            assert out2.ops[1].offset == 30 * lo.value  # replicated operand: shifted inside the whole parent

@@ -454,6 +454,187 @@ static void run_tiled(Ctx& c) {
            1 << L1, 1 << L2, 1 << L3, 1 << NTLOG, SWZ, (int)NTS, grid, lds, us, 2.0 * c.N * 8 / us * 1e-3, 2.0 * c.N * 8 / us * 1e-3 / 80.0, ok ? "ok" : "WRONG");
 }
 
+// ---- the library's ORBIT kernel (smr_k_orbit.hip) restated stand-alone: every shift / stride / swizzle
+// parameter is a kernel argument.  VAR selects experiments on its prologue.
+struct RtArgs {
+    const char* src;
+    char* dst;
+    const uint32_t* list;  // 4 element origins per workgroup
+    int32_t nin, tilelog, ntlog, conj0, nts, pad0;
+    uint32_t swz_s1, swz_s2, swz_mask, pad1;
+    int32_t esh[4], elen[4];
+    uint32_t estride[4];
+    int32_t lsh[7][4];
+    int32_t slot[4][7];
+    uint32_t conjbit[7];
+};
+
+template <int VAR>
+__global__ void __launch_bounds__(1024) k_orbit_rt(const RtArgs a, long long* __restrict__ stamps) {
+    constexpr int NG = 4, NK = 4, V = 2;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const uint32_t tid = threadIdx.x;
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if (VAR & 8) t0 = __builtin_readcyclecounter();
+    typedef uint32_t rowv __attribute__((ext_vector_type(4)));
+    const rowv row = reinterpret_cast<const rowv*>(a.list)[blockIdx.x];
+    const bool live = row[0] != 0xffffffffu;
+    long long org[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) org[g] = live ? (long long)row[g] * 8 : 0;
+    const uint32_t e = tid * V;
+    uint32_t cj[4], goff = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cj[j] = __builtin_amdgcn_ubfe(e, (uint32_t)a.esh[j], (uint32_t)a.elen[j]);
+        goff += cj[j] * a.estride[j];
+    }
+    if (VAR & 8) t1 = __builtin_readcyclecounter();
+    d2 x[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const d2*>(a.src + org[g] + goff);
+    uint32_t lr[NK];
+#pragma unroll
+    for (int k = 1; k < NK; ++k) {
+        uint32_t l = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l |= cj[j] << a.lsh[k][j];
+        lr[k] = l;
+    }
+    lr[0] = 0;
+    uint32_t s1 = a.swz_s1, s2 = a.swz_s2, sm = a.swz_mask;
+    uint32_t sbase[NG][NK], hbit[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        hbit[k] = (uint32_t)a.lsh[k][0];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) sbase[g][k] = (uint32_t)a.slot[g][k] << a.tilelog;
+    }
+    if (VAR & 1) {
+        asm volatile("" : "+s"(s1), "+s"(s2), "+s"(sm));
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            asm volatile("" : "+s"(hbit[k]), "+v"(lr[k]));
+#pragma unroll
+            for (int g = 0; g < NG; ++g) asm volatile("" : "+s"(sbase[g][k]));
+        }
+    }
+    auto swzf = [&](uint32_t i) { return i ^ (((i >> s1) ^ (i >> s2)) & sm); };
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        double* L = lds + ((size_t)g << a.tilelog);
+        L[swzf(e)] = x[g].v[0];
+        L[swzf(e + 1)] = x[g].v[1];
+    }
+    if (VAR & 8) t2 = __builtin_readcyclecounter();
+    __syncthreads();
+    if (VAR & 8) t3 = __builtin_readcyclecounter();
+    double val[NG][V][NK];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int h = 0; h < V; ++h)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                if (k == 0) val[g][h][k] = x[g].v[h];
+                else val[g][h][k] = lds[sbase[g][k] + swzf(lr[k] | ((uint32_t)h << hbit[k]))];
+            }
+    if (VAR & 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int h = 0; h < V; ++h) x[g].v[h] = ((val[g][h][0] + val[g][h][1]) + val[g][h][2]) + val[g][h][3];
+    if (VAR & 8) t4 = __builtin_readcyclecounter();
+    if (!live) return;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) *reinterpret_cast<d2*>(a.dst + org[g] + goff) = x[g];
+    if ((VAR & 8) && tid == 0) {
+        long long* o = stamps + (size_t)blockIdx.x * 8;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = t2;
+        o[3] = t3;
+        o[4] = t4;
+        o[5] = __builtin_readcyclecounter();
+    }
+}
+
+template <int VAR>
+static void run_orbit_rt(Ctx& c, int lgc, int ntlog) {
+    const int ml = lgc;
+    if ((1 << ml) > c.n) return;
+    std::vector<uint32_t> boxes = grouped_boxes(c.n, ml, 1);
+    std::vector<uint32_t> rows(boxes.size() * 4, 0xffffffffu);
+    for (size_t w = 0; w < boxes.size(); ++w) {
+        if (boxes[w] == 0xffffffffu) continue;
+        uint32_t o[4];
+        for (int d = 0; d < 4; ++d) o[d] = ((boxes[w] >> (8 * d)) & 0xffu) << 2;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t off = 0;
+            for (int d = 0; d < 4; ++d) off += o[(d - k) & 3] << (c.nlog * d);
+            rows[w * 4 + k] = off;
+        }
+    }
+    uint32_t* db;
+    CK(hipMalloc(&db, rows.size() * 4));
+    CK(hipMemcpy(db, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    long long* stamps;
+    CK(hipMalloc(&stamps, boxes.size() * 64));
+    CK(hipMemset(stamps, 0, boxes.size() * 64));
+    RtArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = (const char*)c.dA;
+    a.dst = (char*)c.dB;
+    a.list = db;
+    a.nin = 4;
+    a.tilelog = 4 * lgc;
+    a.ntlog = ntlog;
+    for (int j = 0; j < 4; ++j) {
+        a.esh[j] = j * lgc;
+        a.elen[j] = lgc;
+        a.estride[j] = 8u << (c.nlog * j);
+    }
+    // view k reads the buffer at r^k(i): local coordinate j of the output sits at tiled dim (j + k) & 3
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 4; ++j) a.lsh[k][j] = ((j + k) & 3) * lgc;
+    for (int g = 0; g < 4; ++g)
+        for (int k = 0; k < 4; ++k) a.slot[g][k] = (g + k) & 3;
+    a.swz_s1 = 4;
+    a.swz_s2 = 8;
+    a.swz_mask = 31;
+    const size_t lds = (size_t)4 * 8 << a.tilelog;
+    const unsigned grid = (unsigned)boxes.size(), block = 1u << ntlog;
+    auto kern = k_orbit_rt<VAR>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemsetAsync(c.dB, 0xff, c.N * 8, c.st));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, c.st, a, stamps);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(c.st));
+    const bool ok = check(c, "orbit_rt");
+    const float us = time_graph(c.st, c.reps, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, c.st, a, stamps); });
+    printf("n=%3d orbit_rt var %2d cube %d lanes %4u wgs %6u lds %6zu : %9.2f us  %7.1f GB/s  (%.1f %% of 8 TB/s) %s\n", c.n, VAR, 1 << lgc, block, grid, lds, us,
+           2.0 * c.N * 8 / us * 1e-3, 2.0 * c.N * 8 / us * 1e-3 / 80.0, ok ? "ok" : "WRONG");
+    if (VAR & 8) {
+        std::vector<long long> h(boxes.size() * 8);
+        CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        long long tmin = -1;
+        for (size_t w = 0; w < boxes.size(); ++w)
+            if (h[w * 8] && (tmin < 0 || h[w * 8] < tmin)) tmin = h[w * 8];
+        double acc[6] = {0, 0, 0, 0, 0, 0}, last = 0;
+        size_t cnt = 0;
+        for (size_t w = 0; w < boxes.size(); ++w) {
+            if (!h[w * 8]) continue;
+            ++cnt;
+            for (int q = 0; q < 6; ++q) acc[q] += (double)(h[w * 8 + q] - (q ? h[w * 8 + q - 1] : tmin));
+            last = std::max(last, (double)(h[w * 8 + 5] - tmin));
+        }
+        printf("      cycles (mean over %zu workgroups): start-after-first %.0f | row+offsets %.0f | loads->LDS %.0f | barrier %.0f | LDS reads+adds %.0f | stores issued %.0f | last end %.0f\n",
+               cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, last);
+    }
+    CK(hipFree(db));
+    CK(hipFree(stamps));
+}
+
 int main(int argc, char** argv) {
     std::vector<int> sizes;
     for (int i = 1; i < argc; ++i) sizes.push_back(atoi(argv[i]));
@@ -511,35 +692,19 @@ int main(int argc, char** argv) {
             us = time_graph(c.st, c.reps, [&] { hipLaunchKernelGGL(k_add4, dim3(g), dim3(256), 0, c.st, c.dA, c.dA2, c.dA3, c.dA4, c.dB); });
             printf("n=%3d add4, 4 arrays       : %9.2f us  %7.1f GB/s (5N bytes: %.1f GB/s)\n", n, us, 2.0 * c.N * 8 / us * 1e-3, 5.0 * c.N * 8 / us * 1e-3);
         }
-        if (c.n <= 64) {
-        // 4^4 cubes
-        run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, true, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 7, 0, false, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 7, 1, false, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 7, 2, false, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 7, 4, false, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 6, 3, false, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 6, 3, true, 0, 1, false, 1>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 3>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 1, 2>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, true, 0, 1, false, 1, 2>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 1, 4>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, true, 0, 1, false, 1, 4>(c);
-        run_orbit<2, 2, 2, 2, 6, 3, false, 0, 1, false, 1, 4>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 2, 4>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 1, 8>(c);
-        run_orbit<2, 2, 2, 2, 7, 3, false, 1, 1, false, 1>(c);
+        if (c.n <= 32) {
+            run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 1>(c);
+            run_orbit_rt<0>(c, 2, 7);
+            run_orbit_rt<1>(c, 2, 7);
+            run_orbit_rt<2>(c, 2, 7);
+            run_orbit_rt<3>(c, 2, 7);
+            run_orbit_rt<8>(c, 2, 7);
+            run_orbit<2, 2, 2, 2, 7, 3, false, 0, 1, false, 1>(c);
+        } else {
+            run_orbit<3, 3, 3, 3, 10, 3, false, 0, 1, false, 1>(c);
+            run_orbit_rt<0>(c, 3, 10);
+            run_orbit_rt<3>(c, 3, 10);
         }
-        // 8^4 cubes
-        run_orbit<3, 3, 3, 3, 10, 3, false, 0, 1, false, 1>(c);
-        run_orbit<3, 3, 3, 3, 10, 0, false, 0, 1, false, 1>(c);
-        run_orbit<3, 3, 3, 3, 10, 1, false, 0, 1, false, 1>(c);
-        run_orbit<3, 3, 3, 3, 10, 2, false, 0, 1, false, 1>(c);
-        run_orbit<3, 3, 3, 3, 10, 4, false, 0, 1, false, 1>(c);
-        run_orbit<3, 3, 3, 3, 9, 3, false, 0, 1, false, 1>(c);
-        run_orbit<3, 3, 3, 3, 8, 3, false, 0, 1, false, 1>(c);
-        run_orbit<3, 3, 3, 3, 10, 3, false, 0, 1, false, 3>(c);
         CK(hipFree(c.dA));
         CK(hipFree(c.dB));
         if (distinct) {
