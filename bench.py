@@ -64,12 +64,37 @@ def graph_of(torch, fn, reps):
     return g
 
 
-def cpu_baseline(S, budget_s=20.0):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(S, budget_s=24.0):
     """The reference algorithm's CPU path (oracle: fuse/order/blocks/threaded bisection/kernel
-    restated in C++) on the same 32^4 f64 step, timed on this box's host cores."""
+    restated in C++) timed on this box's host cores: the headline 32^4 f64 step, and -- as bounded
+    samples -- the other BASELINE.json configs and the README / benchmarks/benchtests.jl extras."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
+    fn = S.fn
+    cores = os.cpu_count() or 1
+    threads = sorted({1, min(4, cores), cores})
+    t_end = time.perf_counter() + budget_s
+
+    def best_of(problem, nt, max_reps, t_stop):
+        best, reps = 1e30, 0
+        while reps < 2 or (time.perf_counter() < t_stop and reps < max_reps):
+            t0 = time.perf_counter()
+            oraclelib.mapreduce(problem, nt)
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+        return best, reps
+
     n = 32
     rng = np.random.default_rng(1234)
     A = S.StridedView(np.asfortranarray(rng.standard_normal((n,) * 4)))
@@ -79,26 +104,56 @@ def cpu_baseline(S, budget_s=20.0):
     p2, k2 = S.build_problem(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))), stream=0)
     p3, k3 = S.build_problem(lambda a, b, c, d: a + b + c + d, None, None, A.size,
                              (C,) + tuple(A.permutedims(p) for p in perms), stream=0)
-    cores = os.cpu_count() or 1
     out = {}
-    t_end = time.perf_counter() + budget_s
-    for nt in sorted({1, min(4, cores), cores}):
-        best2 = best3 = 1e30
-        reps = 0
-        t_stop = min(t_end, time.perf_counter() + budget_s / 3)
-        while reps < 5 or (time.perf_counter() < t_stop and reps < 200):
-            t0 = time.perf_counter(); oraclelib.mapreduce(p2, nt); t1 = time.perf_counter()
-            oraclelib.mapreduce(p3, nt); t2 = time.perf_counter()
-            best2, best3 = min(best2, t1 - t0), min(best3, t2 - t1)
-            reps += 1
-        out[nt] = dict(threads=nt, permutedims_ms=best2 * 1e3, broadcast4_ms=best3 * 1e3,
-                       gbs=2 * 16777216 / (best2 + best3) / 1e9, reps=reps)
+    for nt in threads:
+        t_stop = min(t_end, time.perf_counter() + budget_s / 8)
+        b2, r2 = best_of(p2, nt, 200, t_stop)
+        b3, r3 = best_of(p3, nt, 200, t_stop + budget_s / 16)
+        out[nt] = dict(threads=nt, permutedims_ms=b2 * 1e3, broadcast4_ms=b3 * 1e3,
+                       gbs=2 * 16777216 / (b2 + b3) / 1e9, reps=min(r2, r3))
     best = max(out.values(), key=lambda d: d["gbs"])
+
+    # the other configs (bounded samples; algorithmic bytes = distinct operand footprints)
+    configs = {}
+
+    def sample(name, what, problem, algbytes, keep):
+        rows = []
+        for nt in threads:
+            b, r = best_of(problem, nt, 20, min(t_end, time.perf_counter() + budget_s / 16))
+            rows.append({"threads": nt, "ms": round(b * 1e3, 3), "GB/s": round(algbytes / b / 1e9, 2), "reps": r})
+        configs[name] = {"sample": what, "algorithmic_bytes": algbytes, "best_GB/s": max(r["GB/s"] for r in rows), "by_threads": rows}
+        del keep
+
+    m = 4000  # configs[0]: the reference's own CPU-runnable case, full size
+    A1 = S.StridedView(np.asfortranarray(rng.standard_normal((m, m))))
+    B1 = A1.similar()
+    p, k = S.build_problem(lambda x, y: (x + y) / 2, None, None, (m, m), (B1, A1, A1.adjoint()), stream=0)
+    sample("c1_symmetrise_4000_f64", "B .= (A .+ A')./2, 4000x4000 Float64, full size (README.md:60-90)", p, 2 * 8 * m * m, k)
+    del A1, B1
+    m = 1000
+    A1 = S.StridedView(np.asfortranarray(rng.standard_normal((m, m))))
+    B1 = A1.similar()
+    p, k = S.build_problem(lambda x: 3 * x, None, None, (m, m), (B1, A1.adjoint()), stream=0)
+    sample("readme_3A'_1000_f64", "B .= 3 .* A', 1000x1000 Float64 (README.md:79-83)", p, 2 * 8 * m * m, k)
+    for q, name in (((1, 2, 3, 0), "perm_2341_32^4_f64"), ((2, 3, 0, 1), "perm_3412_32^4_f64")):
+        p, k = S.build_problem(lambda x: x, None, None, A.size, (B, A.permutedims(q)), stream=0)
+        sample(name, "permutedims!(B, A, %s), 32^4 Float64 (benchmarks/benchtests.jl:40-42)" % (tuple(i + 1 for i in q),), p, 2 * 8 * n ** 4, k)
+    X = S.StridedView(np.asfortranarray((rng.random((4096, 4096, 2)) * 2 - 1).astype(np.float32)))
+    o = S.StridedView(np.zeros(1, dtype=np.float32), X.size, (0, 0, 0), 0)
+    p, k = S.build_problem(fn.abs2, "+", None, X.size, (o, X), stream=0)
+    sample("c4_mapreduce_abs2_f32", "mapreduce(abs2,+) on a 4096x4096x2 Float32 slab (1/32 of configs[3])", p, 4 * 4096 * 4096 * 2 + 4, k)
+    del X
+    Y = S.StridedView(np.asfortranarray(rng.random((8192, 1024)).astype(np.float32)))
+    Z = Y.similar()
+    p, k = S.build_problem(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, Y.size, (Z, Y), stream=0)
+    sample("c5_expr_f32", "B .= A.*exp.(-2A) .+ sin.(A.*A) on 8192x1024 Float32 (1/8 of configs[4])", p, 2 * 4 * 8192 * 1024, k)
     return {
         "value": round(best["gbs"], 3), "unit": "GB/s", "cores": best["threads"], "kind": "port",
+        "cpu_model": _cpu_model(), "host_cores": cores,
         "sample": "min over %d repetitions of the same 32^4 f64 step (permutedims! + 4-way broadcast), "
-                  "oracle = C++ restatement of the reference algorithm; host has %d cores" % (best["reps"], cores),
+                  "oracle = C++ restatement of the reference algorithm; host has %d cores (%s)" % (best["reps"], cores, _cpu_model()),
         "by_threads": [out[k] for k in sorted(out)],
+        "configs": configs,
         "readme_4threads_gbs": {"permutedims": 14.07, "broadcast4": 6.00, "hardware": "unstated (README.md:143-153)"},
     }
 
@@ -320,38 +375,55 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
     A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
     p = S.make_plan(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, (m, m), (B, A))
     rec("c5_expr_8192_f32", p, timed(p, 20))
-    # C4 mapreduce(abs2,+) 4096x4096x64 f32 sharded over the ranks on dim 3 + RCCL all-reduce
+    # C4 mapreduce(abs2,+) 4096x4096x64 f32, block-partitioned over the ranks on dim 3 (every rank holds ONLY its
+    # slab), executed through the library's own multi-GPU entry point: smr_shard_ex -> local kernel ->
+    # gather -> ONE ncclAllReduce (RCCL over xGMI, csrc/smr_comm.cpp) -> scatter
+    from strided_jl_amd import distributed as D
     slab = 64 // world if 64 % world == 0 else 64
     tA = (torch.rand(4096 * 4096 * slab, dtype=torch.float32, device=dev) * 2 - 1)
-    A = colmajor_view(S, tA, (4096, 4096, slab))
     out = torch.zeros(1, dtype=torch.float32, device=dev)
-    O = S.StridedView(out, A.size, (0, 0, 0), 0)
-    p = S.make_plan(fn.abs2, "+", None, A.size, (O, A))
-    if world > 1:
+    dims = (4096, 4096, 64 if world > 1 and slab * world == 64 else slab)
+    A = S.StridedView(tA, dims, (1, 4096, 4096 * 4096), 0)  # logical box over the slab's memory
+    O = S.StridedView(out, dims, (0, 0, 0), 0)
+    sharded = world > 1 and slab * world == 64
+    if sharded:
         import torch.distributed as dist
+        uid = [D.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        D.comm_init(world, rank, uid[0])
 
-    def c4():
-        out.zero_()
-        p.execute(cur())
-        if world > 1:
-            dist.all_reduce(out)
+        def c4():
+            out.zero_()
+            D.comm_mapreduce_sharded_(fn.abs2, "+", None, dims, (O, A), local=(False, True))
+        desc = "smr_mapreduce_sharded_ex (C ABI): shards=%d, slab-local input, ncclAllReduce(1 x f32)" % world
+    else:
+        p = S.make_plan(fn.abs2, "+", None, dims, (O, A))
 
+        def c4():
+            out.zero_()
+            p.execute(cur())
+        desc = p.describe()
     for _ in range(3):
         c4()
     torch.cuda.synchronize()
     got = float(out.item())
     ms = min(event_time_ms(torch, c4, 10) for _ in range(3))
-    b = 4 * 4096 * 4096 * slab * world
-    truth = float((tA.double() ** 2).sum().item())
     if world > 1:
+        tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+    b = 4 * 4096 * 4096 * slab * (world if sharded else 1)
+    truth = float((tA.double() ** 2).sum().item())
+    if sharded:
         tt = torch.tensor([truth], dtype=torch.float64, device=dev)
         dist.all_reduce(tt)
         truth = float(tt.item())
+        D.comm_destroy()
     res["c4_mapreduce_abs2_4096x4096x64_f32"] = {
-        "us": round(ms * 1e3, 2), "GB/s_total": round(b / (ms * 1e-3) / 1e9, 1), "shards": world,
-        "frac_of_8TBs_per_gpu": round(b / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "rel_err_vs_f64": abs(got - truth) / truth, "plan": p.describe(),
-        "collective": "RCCL all_reduce(1 x f32)" if world > 1 else "none"}
+        "us": round(ms * 1e3, 2), "GB/s_total": round(b / (ms * 1e-3) / 1e9, 1), "shards": world if sharded else 1,
+        "frac_of_8TBs_per_gpu": round(b / (world if sharded else 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "rel_err_vs_f64": abs(got - truth) / truth, "plan": desc,
+        "collective": "RCCL ncclAllReduce(1 x f32) issued by libstrided_hip (smr_comm.cpp)" if sharded else "none"}
     return res
 
 

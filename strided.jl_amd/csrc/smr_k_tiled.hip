@@ -47,6 +47,14 @@
 #ifndef SMR_CT
 #error "compile with -DSMR_CT=0..3"
 #endif
+// 1: compute the per-lane rows (bit slices of the lane id, fold swizzle) instead of loading them from the
+// device table.  Measured on MI355X (tools/perm_ab.py, round 2): SLOWER where it was meant to help -- permutedims!
+// 32^4 f64 3.57 vs 3.32 us, f32 2.79 vs 2.57 us, transpose 8192^2 225 vs 209 us (only permutedims! 128^4 f64
+// gained, 866 vs 935 us) -- the table row is one coalesced 8-byte load that overlaps the kernel-argument loads,
+// the arithmetic needs ~30 more scalar argument words and ~15 VALU per operand.  Kept as a build-time experiment.
+#ifndef SMR_TILED_BITS
+#define SMR_TILED_BITS 0
+#endif
 
 namespace smr {
 
@@ -92,6 +100,11 @@ struct TiledArgs {
     i64 gdims[MAXN];
     int32_t glog[MAXN];
     uint32_t ord16[NORD16 / 2];  // ordmode 1: the same as 16-bit entries inside the kernel arguments
+    // BITS form (narrow offsets, no ragged tile): the per-lane table rows are COMPUTED -- bit slices of the lane
+    // id -- instead of loaded, which takes one dependent memory round trip out of the prologue
+    int32_t bpos[MAXM][MAXT], blen[MAXM][MAXT], blsh[MAXM][MAXT];  // slice p of operand k's enumeration (blen 0 = unused)
+    uint32_t bstr[MAXM][MAXT];                                     // its byte stride
+    uint32_t fs1, fs2, fmask, fpad;                                // fold swizzle l ^ (((l >> fs1) ^ (l >> fs2)) & fmask)
 };
 
 SMR_DEV uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s) { return (__umulhi(m, n) + n) >> s; }
@@ -167,13 +180,30 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     const int nin = (NIN_STATIC >= 0) ? NIN_STATIC : a.M - 1;
     const uint32_t tid = threadIdx.x;
 
-    // ---- per-lane table rows: the very first memory instructions of the kernel ----------------------
+    // ---- per-lane rows (byte offset + swizzled LDS index of the lane's first element, per operand) ----
+    // tables in device memory (first memory instructions of the kernel) or, BITS, bit slices of the lane id
+    constexpr bool BITS = SMR_TILED_BITS && !WIDE && !EDGE;
     LaneRow<WIDE> row[NINMAX + 1];
 #pragma unroll
     for (int k = 0; k <= NINMAX; ++k) {
         row[k].g = 0;
         row[k].l = 0;
-        if (k <= nin) row[k] = a.lanetab[k * NT + tid];
+        if constexpr (BITS) {
+            if (NIN_STATIC >= 0 || k <= nin) {
+                const uint32_t e0 = tid << VLOG;
+                uint32_t g = 0, idx = 0;
+#pragma unroll
+                for (int p = 0; p < MAXT; ++p) {
+                    const uint32_t c = __builtin_amdgcn_ubfe(e0, (uint32_t)a.bpos[k][p], (uint32_t)a.blen[k][p]);
+                    g += c * a.bstr[k][p];
+                    idx |= c << a.blsh[k][p];
+                }
+                row[k].g = g;
+                row[k].l = idx ^ (((idx >> a.fs1) ^ (idx >> a.fs2)) & a.fmask);
+            }
+        } else {
+            if (k <= nin) row[k] = a.lanetab[k * NT + tid];
+        }
     }
 
     // ---- which tile ---------------------------------------------------------------------------------
@@ -381,12 +411,29 @@ SMR_DEV void tiled_map_pipe_body(const TiledArgs<WIDE> a, F f) {
     const int nin = (NIN_STATIC >= 0) ? NIN_STATIC : a.M - 1;
     const uint32_t tid = threadIdx.x;
 
+    constexpr bool BITS = SMR_TILED_BITS && !WIDE;
+    constexpr int VLOGP = (V == 1) ? 0 : (V == 2 ? 1 : 2);
     LaneRow<WIDE> row[NINMAX + 1];
 #pragma unroll
     for (int k = 0; k <= NINMAX; ++k) {
         row[k].g = 0;
         row[k].l = 0;
-        if (k <= nin) row[k] = a.lanetab[k * NT + tid];
+        if constexpr (BITS) {
+            if (NIN_STATIC >= 0 || k <= nin) {
+                const uint32_t e0 = tid << VLOGP;
+                uint32_t g = 0, idx = 0;
+#pragma unroll
+                for (int p = 0; p < MAXT; ++p) {
+                    const uint32_t c = __builtin_amdgcn_ubfe(e0, (uint32_t)a.bpos[k][p], (uint32_t)a.blen[k][p]);
+                    g += c * a.bstr[k][p];
+                    idx |= c << a.blsh[k][p];
+                }
+                row[k].g = g;
+                row[k].l = idx ^ (((idx >> a.fs1) ^ (idx >> a.fs2)) & a.fmask);
+            }
+        } else {
+            if (k <= nin) row[k] = a.lanetab[k * NT + tid];
+        }
     }
 
     // work-list entry -> tile id (0xffffffff: none, and none after it for this workgroup)
@@ -780,7 +827,52 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         pats.push_back(r);
     }
     int cost0 = 0, cost1 = 0;
-    const Swizzle swz = choose_swizzle(t.tilelog, w, pats, &cost0, &cost1);
+    constexpr bool BITS = SMR_TILED_BITS && !WIDE && !EDGE;
+    Swizzle swz = choose_swizzle(t.tilelog, w, pats, &cost0, &cost1);
+    uint32_t fs1 = 31, fs2 = 31, fmask = 0;
+    if (BITS && swz.w != 32) {
+        // the kernel computes the swizzle itself: restrict it to XOR folds of the index onto its low w bits,
+        // i ^ (((i >> s1) ^ (i >> s2)) & (2^w - 1)), s1 >= w; pick the fold with the fewest bank conflicts
+        auto fold = [&](int s1, int s2) {
+            Swizzle f;
+            f.w = w;
+            for (int b = 0; b < 32; ++b) {
+                f.mask[b] = 0;
+                if (b >= s1 && b < t.tilelog) f.mask[b] ^= (1u << (b - s1)) & ((1u << w) - 1u);
+                if (b >= s2 && b < t.tilelog) f.mask[b] ^= (1u << (b - s2)) & ((1u << w) - 1u);
+            }
+            return f;
+        };
+        auto fcost = [&](const Swizzle& f) {
+            int cst = 0;
+            for (const LanePattern& pt : pats) {
+                uint32_t img[8];
+                const uint32_t sm = (1u << pt.slotbits) - 1u;
+                for (int i2 = 0; i2 < pt.n; ++i2) {
+                    const int b = pt.bits[i2];
+                    uint32_t v = 1u << b;
+                    if (b >= w) v ^= f.mask[b];
+                    img[i2] = v & sm;
+                }
+                cst += (1 << (pt.n - gf2_rank(img, pt.n))) - 1;
+            }
+            return cst;
+        };
+        int bestc = 1 << 30;
+        for (int s1 = w; s1 < t.tilelog; ++s1)
+            for (int s2 = s1 + 1; s2 <= t.tilelog; ++s2) {  // s2 == tilelog: one-term fold
+                const Swizzle f = fold(s1, s2 == t.tilelog ? 32 : s2);
+                const int cst = fcost(f);
+                if (cst < bestc) {
+                    bestc = cst;
+                    swz = f;
+                    fs1 = (uint32_t)s1;
+                    fs2 = s2 == t.tilelog ? 31u : (uint32_t)s2;
+                    fmask = (1u << w) - 1u;
+                }
+            }
+        cost1 = bestc;
+    }
     if (std::getenv("SMR_DEBUG_SWIZZLE"))
         std::fprintf(stderr, "[smr] tiled swizzle: w=%d V=%d patterns=%zu conflict cost fold=%d searched=%d\n", w, V, pats.size(), cost0, cost1);
     // grid dims: canonical dims with more than one tile, in canonical order
@@ -842,8 +934,11 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         if (!base32 || ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
     }
 
-    // per-lane table: built once per (plan, kernel variant), kept in device memory
-    const bool build_tab = plan.lanetab[variant] == nullptr && !jit_dry_run();
+    // per-lane table: built once per (plan, kernel variant), kept in device memory (not needed by the BITS form)
+    const bool build_tab = !BITS && plan.lanetab[variant] == nullptr && !jit_dry_run();
+    a.fs1 = fs1;
+    a.fs2 = fs2;
+    a.fmask = fmask;
     std::vector<LaneRow<WIDE>> rows;
     if (build_tab) rows.assign((size_t)c.M * NT, LaneRow<WIDE>{});
 
@@ -869,6 +964,10 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         for (int jj = 0; jj < t.nt; ++jj) {
             const int j = own ? t.order[k][jj] : jj;
             a.esh[k][j] = pos;
+            a.bpos[k][jj] = pos;
+            a.blen[k][jj] = t.tlog[j];
+            a.blsh[k][jj] = lsh[j];
+            a.bstr[k][jj] = (uint32_t)(c.strides[k][t.tdim[j]] * es);
             for (int bit = 0; bit < t.tlog[j]; ++bit) {
                 gbit[pos + bit] = c.strides[k][t.tdim[j]] * ((i64)1 << bit) * es;
                 lbit[pos + bit] = swz.apply(1u << (lsh[j] + bit));
