@@ -32,6 +32,13 @@
 #error "compile with -DSMR_CT=0..3"
 #endif
 
+// 1: the per-lane offsets (byte offset in a tile + one LDS read index per permuted view) come from a small
+// device table -- one vector load per lane, issued next to the origin row's scalar load -- instead of
+// bit-slice arithmetic on kernel arguments (measured on the classic kernel: the table is the faster form)
+#ifndef SMR_ORBIT_TABLE
+#define SMR_ORBIT_TABLE 0  // measured: no difference (5.01 vs 5.00 us at 32^4) -> arithmetic, no table to upload
+#endif
+
 namespace smr {
 
 constexpr int OMAXT = 4;  // tiled dims = dims of the unit class <= |G| <= 4
@@ -40,6 +47,7 @@ struct OrbitArgs {
     const char* src;  // the shared buffer, element offset applied
     char* dst;
     const uint32_t* list;  // per workgroup: the NG slot origins (element offsets; [0] = 0xffffffff: idle)
+    const uint32_t* lanetab;  // [(r * NT + tid) * rowlen]: byte offset, then the LDS read index of every non-own view
     int32_t nin, tilelog, ntlog, conj0, nts, pad0;
     uint32_t swz_s1, swz_s2, swz_mask, pad1;
     // element enumeration inside a tile (natural order of the buffer); unused tiled dims have elen = 0
@@ -112,8 +120,27 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
         for (int g = 0; g < NG; ++g) org[g] = live ? (i64)o32[g] * (i64)sizeof(T) : 0;
     }
 
-    // ---- per-lane byte offsets inside a tile: bit slices of the element number -----------------------
-    uint32_t goff[NREP], cj[NREP][OMAXT];
+    // ---- per-lane byte offsets inside a tile + LDS read indices -----------------------------------------
+    constexpr int NLR = NK - (OWN0 ? 1 : 0);      // views read from LDS
+    constexpr int ROWLEN = (1 + NLR) <= 2 ? 2 : ((1 + NLR) <= 4 ? 4 : 8);
+    uint32_t goff[NREP];
+    uint32_t lr[NK][NREP];  // LDS index of the lane's first element seen through view k
+#if SMR_ORBIT_TABLE
+    {
+        typedef uint32_t trow __attribute__((ext_vector_type(ROWLEN)));
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            const trow t = reinterpret_cast<const trow*>(a.lanetab)[((uint32_t)r << a.ntlog) | tid];
+            goff[r] = t[0];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                lr[k][r] = 0;
+                if (!(OWN0 && k == 0)) lr[k][r] = t[1 + k - (OWN0 ? 1 : 0)];
+            }
+        }
+    }
+#else
+    uint32_t cj[NREP][OMAXT];
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
         const uint32_t e = (((uint32_t)r << a.ntlog) | tid) * V;
@@ -125,6 +152,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
         }
         goff[r] = g;
     }
+#endif
 
     // ---- load every slot (natural order) --------------------------------------------------------------
     VT x[NG][NREP];
@@ -136,7 +164,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     // ---- while the loads fly: everything the exchange needs from the kernel arguments ---------------
     // (left to itself the compiler sinks these scalar loads below the barrier: one more serial scalar-memory
     // round trip in a 5 us launch; the empty asm statements pin the values in registers here)
-    uint32_t lr[NK][NREP];  // LDS index of the lane's first element seen through view k
+#if !SMR_ORBIT_TABLE
 #pragma unroll
     for (int r = 0; r < NREP; ++r)
 #pragma unroll
@@ -148,6 +176,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
             }
             lr[k][r] = l;
         }
+#endif
     uint32_t swz_s1 = a.swz_s1, swz_s2 = a.swz_s2, swz_mask = a.swz_mask;
     asm volatile("" : "+s"(swz_s1), "+s"(swz_s2), "+s"(swz_mask));
     uint32_t sbase[NG][NK], hbit[NK], cbit[NK];
@@ -370,6 +399,34 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             plan.ordtab = dptr;
         }
         a.list = reinterpret_cast<const uint32_t*>(plan.ordtab);
+        if (!plan.lanetab[V > 1 ? 1 : 0] && !jit_dry_run()) {
+            // per-lane rows: {byte offset in a tile, LDS read index of every view read from LDS}
+            const int nk = is_jit<F>::value ? c.M - 1 : ((F::NIN >= 0) ? F::NIN : MAXIN);  // = NK of the device functor
+            const int nlr = nk - (OWN0 ? 1 : 0);
+            const int rowlen = (1 + nlr) <= 2 ? 2 : ((1 + nlr) <= 4 ? 4 : 8);
+            const uint32_t nt = 1u << a.ntlog;
+            std::vector<uint32_t> rows((size_t)NREP * nt * rowlen, 0u);
+            for (uint32_t r = 0; r < (uint32_t)NREP; ++r)
+                for (uint32_t tid = 0; tid < nt; ++tid) {
+                    const uint32_t e = ((r << a.ntlog) | tid) * V;
+                    uint32_t* row = &rows[((size_t)(r << a.ntlog) | tid) * rowlen];
+                    for (int j = 0; j < OMAXT; ++j) {
+                        const uint32_t cj = (e >> a.esh[j]) & ((1u << a.elen[j]) - 1u);
+                        row[0] += cj * a.estride[j];
+                        for (int k = OWN0 ? 1 : 0; k < nk && k < c.M - 1; ++k) row[1 + k - (OWN0 ? 1 : 0)] |= cj << a.lsh[k][j];
+                    }
+                }
+            void* dptr = nullptr;
+            hipError_t e2 = hipMalloc(&dptr, rows.size() * sizeof(uint32_t));
+            if (e2 != hipSuccess) return hip_error(e2, "hipMalloc(orbit lane table)");
+            e2 = hipMemcpy(dptr, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) {
+                (void)hipFree(dptr);
+                return hip_error(e2, "hipMemcpy(orbit lane table)");
+            }
+            plan.lanetab[V > 1 ? 1 : 0] = dptr;
+        }
+        a.lanetab = reinterpret_cast<const uint32_t*>(plan.lanetab[V > 1 ? 1 : 0]);
         if (!jit_dry_run()) {
             cached.resize(sizeof a);
             std::memcpy(cached.data(), &a, sizeof a);

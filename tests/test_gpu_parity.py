@@ -124,7 +124,8 @@ def test_aliased_permuted_inputs_with_orbit_tile_order(shape, T):
     want = a.transpose(perms[0]).copy()
     for q in perms[1:]:
         want = want + a.transpose(q)
-    for order in (1, 0):
+    for orbit, order in ((1, 1), (0, 1), (0, 0)):
+        S.set_option("orbit", orbit)
         S.set_option("tile_order", order)
         try:
             A = dview(a)
@@ -136,12 +137,18 @@ def test_aliased_permuted_inputs_with_orbit_tile_order(shape, T):
             B.assign(e)
             plan = S.make_plan((lambda *xs: sum(xs[1:], xs[0])), None, None, B.size, (B, *views))
             d = plan.describe()
-            assert "family=tiled" in d
-            assert ("order=orbits" in d) == (order == 1 and bool(plan.tile_order()))
+            if orbit == 0:
+                assert "family=tiled" in d
+                assert ("order=orbits" in d) == (order == 1 and bool(plan.tile_order()))
+            else:
+                # FAM_ORBIT where the sizes allow it (power-of-two divisible unit dims, enough orbits)
+                # (200 = 8 * 25, 1000 = 8 * 125, 20, 33, 65: no tile of >= 256 elements divides them -> classic kernel, ragged tiles)
+                assert ("family=orbit" in d) == (shape == (48, 16, 48, 16)), d
             torch.cuda.synchronize()
-            assert np.array_equal(B.toarray(), want), f"{shape} {np.dtype(T).name} tile_order={order}: {d}"
+            assert np.array_equal(B.toarray(), want), f"{shape} {np.dtype(T).name} orbit={orbit} tile_order={order}: {d}"
         finally:
             S.set_option("tile_order", 1)
+            S.set_option("orbit", 1)
 
 
 def test_mapreduce_scalar_returns_the_complete_reduction_to_the_host():
