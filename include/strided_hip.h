@@ -130,6 +130,9 @@ typedef enum {
     SMR_OP_ROUND32 = 21, /* round to Float32 (each part of a complex value): the host inserts it after
                             every operation Julia would have carried out in Float32 / ComplexF32 while
                             the call as a whole computes in Float64 (per-operation typing)         */
+    SMR_OP_WIDEN = 22,   /* identity; its presence makes the call compute in the 64-bit class although no
+                            operand is 64-bit: a Float64 / ComplexF64 scalar meets Float32 arrays
+                            (`B32 .= A32 .* 0.1` multiplies in Float64 in Julia and rounds once on store) */
     /* binary: pop b, pop a, push a (op) b */
     SMR_OP_ADD = 32,
     SMR_OP_SUB = 33,

@@ -132,9 +132,10 @@ struct real_ops {
             case SMR_OP_SUB: return a - b;
             case SMR_OP_MUL: return a * b;
             case SMR_OP_DIV: return a / b;
-            // Julia min/max propagate NaN; the reference tests never feed NaN here.
-            case SMR_OP_MIN: return (b < a) ? b : a;
-            case SMR_OP_MAX: return (a < b) ? b : a;
+            // Julia's min / max (Base/math.jl): NaN if either argument is NaN, min(-0.0, 0.0) = -0.0,
+            // max(-0.0, 0.0) = 0.0
+            case SMR_OP_MIN: return (a != a) ? a : ((b != b) ? b : ((b < a) ? b : ((a < b) ? a : (std::signbit(a) ? a : b))));
+            case SMR_OP_MAX: return (a != a) ? a : ((b != b) ? b : ((a < b) ? b : ((b < a) ? a : (std::signbit(a) ? b : a))));
             case SMR_OP_LT: return a < b ? R(1) : R(0);
             case SMR_OP_LE: return a <= b ? R(1) : R(0);
             case SMR_OP_GT: return a > b ? R(1) : R(0);
@@ -233,7 +234,7 @@ int check_prog(const Prog& p, int M) {
         } else if (op == SMR_OP_CONST) {
             if (imm >= p.nconst) return -1;
             ++sp;
-        } else if (op >= 8 && op <= SMR_OP_ROUND32) {
+        } else if (op >= 8 && op <= SMR_OP_WIDEN) {
             if (sp < 1) return -1;
         } else if (op >= 32 && op <= SMR_OP_NE) {
             if (sp < 2) return -1;
@@ -887,6 +888,8 @@ int compute_class(const smr_problem* p) {
     }
     for (int i = 0; i < p->nconsts; ++i)
         if (p->fconsts[2 * i + 1] != 0.0) cplx = true;
+    for (int pc = 0; pc < p->fprog_len; ++pc)
+        if (p->fprog[2 * pc] == SMR_OP_WIDEN) dbl = true;  // a Float64 scalar among Float32 arrays: Julia computes in Float64
     return cplx ? (dbl ? SMR_C64 : SMR_C32) : (dbl ? SMR_F64 : SMR_F32);
 }
 

@@ -31,7 +31,7 @@ SMR_RED_NONE, SMR_RED_ADD, SMR_RED_MUL, SMR_RED_MIN, SMR_RED_MAX, SMR_RED_AND, S
 OPCODES = dict(
     ARG=0, CONST=1,
     NEG=8, ABS=9, ABS2=10, CONJ=11, REAL=12, IMAG=13, SQRT=14, EXP=15, LOG=16, SIN=17, COS=18,
-    TANH=19, INV=20, ROUND32=21,
+    TANH=19, INV=20, ROUND32=21, WIDEN=22,
     ADD=32, SUB=33, MUL=34, DIV=35, MIN=36, MAX=37, LT=38, LE=39, GT=40, GE=41, EQ=42, NE=43,
     SELECT=64,
 )

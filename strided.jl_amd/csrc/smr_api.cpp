@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <list>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -86,6 +87,7 @@ struct smr_plan {
     Plan plan;
     int nops = 0;  // M of the originating problem (length of a `bases` rebinding array)
     void* stream = nullptr;
+    void* obase[SMR_MAXM] = {nullptr};  // the base pointers the plan was created with (aliasing pattern)
 };
 
 static int plan_build(const smr_problem* p, smr_plan** out) {
@@ -99,6 +101,7 @@ static int plan_build(const smr_problem* p, smr_plan** out) {
     }
     h->nops = p->M;
     h->stream = p->stream;
+    for (int k = 0; k < p->M; ++k) h->obase[k] = p->ops[k].base;
     *out = h;
     return SMR_OK;
 }
@@ -125,13 +128,27 @@ static void plan_free(smr_plan* h) {
 }
 
 // ---- plan cache for the one-shot entry point ---------------------------------------------------------
+// Plans are held by shared_ptr: a thread that found a plan keeps it alive while it executes, eviction only
+// drops the cache's reference (the last owner frees the device tables -- after draining the plan's stream,
+// outside the cache lock).  The key describes the problem's SHAPE, not its addresses: operands are
+// identified by alias class (which operands share a base pointer) and 256-byte alignment, and the
+// actual base pointers are bound at launch -- a loop over freshly allocated arrays hits one entry.
 namespace {
+struct PlanDeleter {
+    void operator()(smr_plan* h) const {
+        if (!h) return;
+        if (h->plan.scratch || h->plan.ordtab || h->plan.lanetab[0] || h->plan.lanetab[1] || h->plan.lanetab[2] || h->plan.lanetab[3])
+            (void)hipStreamSynchronize((hipStream_t)h->stream);  // queued kernels may still read the tables
+        plan_free(h);
+    }
+};
+typedef std::shared_ptr<smr_plan> PlanRef;
+
 struct Cache {
     std::mutex mu;
-    std::list<std::pair<std::string, smr_plan*>> lru;
-    std::unordered_map<std::string, std::list<std::pair<std::string, smr_plan*>>::iterator> map;
+    std::list<std::pair<std::string, PlanRef>> lru;
+    std::unordered_map<std::string, std::list<std::pair<std::string, PlanRef>>::iterator> map;
     static constexpr size_t CAP = 512;
-    uint64_t epoch = 0;  // bumped by smr_set_option: plans depend on the options
     ~Cache() {}
 };
 Cache& cache() {
@@ -146,7 +163,17 @@ std::string signature(const smr_problem* p) {
     put(&p->M, sizeof p->M);
     put(p->dims, sizeof(int64_t) * (size_t)p->N);
     for (int k = 0; k < p->M; ++k) {
-        put(&p->ops[k].base, sizeof(void*));
+        // alias class = first operand with the same base; byte distance to it (views of one buffer may sit
+        // at different offsets); alignment of the base itself
+        int32_t cls = k;
+        for (int j = 0; j < k; ++j)
+            if (p->ops[j].base == p->ops[k].base) {
+                cls = j;
+                break;
+            }
+        const uint32_t align = (uint32_t)((uintptr_t)p->ops[k].base & 255u);
+        put(&cls, sizeof cls);
+        put(&align, sizeof align);
         put(&p->ops[k].offset, sizeof(int64_t));
         put(p->ops[k].strides, sizeof(int64_t) * (size_t)p->N);
         put(&p->ops[k].dtype, sizeof(int32_t));
@@ -163,8 +190,8 @@ std::string signature(const smr_problem* p) {
     return s;
 }
 
-void cache_clear_locked(Cache& c) {
-    for (auto& kv : c.lru) plan_free(kv.second);
+void cache_clear_locked(Cache& c, std::vector<PlanRef>& dropped) {
+    for (auto& kv : c.lru) dropped.push_back(std::move(kv.second));
     c.lru.clear();
     c.map.clear();
 }
@@ -194,8 +221,12 @@ int smr_init(int device) {
 
 int smr_shutdown(void) {
     Cache& c = cache();
-    std::lock_guard<std::mutex> g(c.mu);
-    cache_clear_locked(c);
+    std::vector<PlanRef> dropped;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        cache_clear_locked(c, dropped);
+    }
+    dropped.clear();  // frees outside the lock
     return SMR_OK;
 }
 
@@ -231,6 +262,14 @@ int smr_plan_create(const smr_problem* problem, smr_plan** out) {
 
 int smr_plan_execute(smr_plan* plan, void* const* bases, void* stream) {
     if (!plan) return set_error(SMR_EINVAL, "null plan");
+    if (bases) {
+        // the planner merged operands that were the same view of one buffer and co-located views that shared a
+        // buffer: a rebinding must keep exactly that aliasing pattern
+        for (int k = 0; k < plan->nops; ++k)
+            for (int j = 0; j < k; ++j)
+                if ((plan->obase[j] == plan->obase[k]) != (bases[j] == bases[k]))
+                    return set_error(SMR_EINVAL, "smr_plan_execute: the rebound base pointers change which operands share a buffer; create a new plan");
+    }
     int rc = ensure_device();
     if (rc) return rc;
     rc = ensure_scratch(plan);
@@ -317,7 +356,7 @@ int smr_mapreduce(const smr_problem* problem) {
     if (rc) return rc;
     Cache& c = cache();
     std::string key = signature(problem);
-    smr_plan* h = nullptr;
+    PlanRef h, evicted;
     {
         std::lock_guard<std::mutex> g(c.mu);
         auto it = c.map.find(key);
@@ -327,23 +366,34 @@ int smr_mapreduce(const smr_problem* problem) {
         }
     }
     if (!h) {
-        rc = plan_build(problem, &h);
+        smr_plan* raw = nullptr;
+        rc = plan_build(problem, &raw);
         if (rc) return rc;
+        PlanRef fresh(raw, PlanDeleter());
         std::lock_guard<std::mutex> g(c.mu);
-        c.lru.emplace_front(key, h);
-        c.map[key] = c.lru.begin();
-        if (c.lru.size() > Cache::CAP) {
-            auto& last = c.lru.back();
-            // the evicted plan's scratch may still be in use by queued kernels of its stream
-            (void)hipStreamSynchronize((hipStream_t)last.second->stream);
-            plan_free(last.second);
-            c.map.erase(last.first);
-            c.lru.pop_back();
+        auto it = c.map.find(key);  // another thread may have inserted the same key meanwhile: use its plan
+        if (it != c.map.end()) {
+            c.lru.splice(c.lru.begin(), c.lru, it->second);
+            h = it->second->second;
+        } else {
+            c.lru.emplace_front(key, fresh);
+            c.map[key] = c.lru.begin();
+            h = fresh;
+            if (c.lru.size() > Cache::CAP) {
+                evicted = std::move(c.lru.back().second);  // released after the lock is gone
+                c.map.erase(c.lru.back().first);
+                c.lru.pop_back();
+            }
         }
     }
-    rc = ensure_scratch(h);
+    evicted.reset();
+    rc = ensure_scratch(h.get());
     if (rc) return rc;
-    return execute(h->plan, nullptr, (hipStream_t)problem->stream);
+    // the plan was built for another set of base pointers with the same aliasing / alignment: bind the
+    // caller's at launch
+    void* bases[SMR_MAXM];
+    for (int k = 0; k < problem->M; ++k) bases[k] = problem->ops[k].base;
+    return execute(h->plan, bases, (hipStream_t)problem->stream);
 }
 
 int smr_shard(const smr_problem* p, int nshards, int shard, smr_problem* out, int* needs_allreduce) {
@@ -446,9 +496,12 @@ int smr_set_option(const char* name, int64_t value) {
     else ok = false;
     if (!ok) return set_error(SMR_EINVAL, "unknown option " + n);
     Cache& c = cache();
-    std::lock_guard<std::mutex> g(c.mu);
-    (void)hipDeviceSynchronize();
-    cache_clear_locked(c);
+    std::vector<PlanRef> dropped;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        cache_clear_locked(c, dropped);
+    }
+    dropped.clear();
     return SMR_OK;
 }
 

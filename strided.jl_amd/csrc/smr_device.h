@@ -106,8 +106,9 @@ struct mathx_real {
             case SMR_OP_SUB: return a - b;
             case SMR_OP_MUL: return a * b;
             case SMR_OP_DIV: return a / b;
-            case SMR_OP_MIN: return (b < a) ? b : a;
-            case SMR_OP_MAX: return (a < b) ? b : a;
+            // Julia's min / max (Base/math.jl): NaN if either argument is NaN; min(-0.0, 0.0) = -0.0, max(-0.0, 0.0) = 0.0
+            case SMR_OP_MIN: return (a != a) ? a : ((b != b) ? b : ((b < a) ? b : ((a < b) ? a : (__builtin_signbit(a) ? a : b))));
+            case SMR_OP_MAX: return (a != a) ? a : ((b != b) ? b : ((a < b) ? b : ((b < a) ? a : (__builtin_signbit(a) ? b : a))));
             case SMR_OP_LT: return a < b ? R(1) : R(0);
             case SMR_OP_LE: return a <= b ? R(1) : R(0);
             case SMR_OP_GT: return a > b ? R(1) : R(0);
@@ -229,7 +230,13 @@ SMR_DEV void st_as(void* base, i64 idx, int dt, T v) {
         case SMR_I32: ((int32_t*)base)[idx] = (int32_t)llrint((double)re); break;
         case SMR_U32: ((uint32_t*)base)[idx] = (uint32_t)llrint((double)re); break;
         case SMR_I64: ((long long*)base)[idx] = (long long)llrint((double)re); break;
-        case SMR_U64: ((unsigned long long*)base)[idx] = (unsigned long long)llrint((double)re); break;
+        case SMR_U64: {
+            // llrint saturates at 2^63: values of the upper half are shifted into range first
+            const double d = (double)re;
+            ((unsigned long long*)base)[idx] = d >= 9223372036854775808.0 ? (unsigned long long)llrint(d - 9223372036854775808.0) + 9223372036854775808ull
+                                                                          : (unsigned long long)llrint(d);
+            break;
+        }
     }
 }
 

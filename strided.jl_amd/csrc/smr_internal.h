@@ -55,6 +55,13 @@ struct ProgD {
     double consts[2 * SMR_MAXCONST];
 };
 
+// Constants of a runtime-compiled f-program: passed as the SECOND kernel argument, so that the generated
+// source (and the compiled-code cache key) depends on the program's structure only -- a loop whose captured
+// scalar changes every iteration compiles once.
+struct JitConsts {
+    double c[2 * SMR_MAXCONST];
+};
+
 // Recognised shapes of f that have a natively compiled functor (smr_device.h).
 enum FKind : int {
     FK_PROG = 0,   // bytecode interpreter

@@ -90,7 +90,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         l.family = "generic";
         l.tname = tname<T>();
         l.argtype = "smr::GenArgs";
-        l.entry = std::string("smr::generic_map_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ">(a, smr::FJit{});";
+        l.entry = std::string("smr::generic_map_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ">(a, smr::FJit{kc});";
         l.grid = (unsigned)blocks;
         l.block = 256;
         l.args = &a;

@@ -123,6 +123,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     // ---- per-lane byte offsets inside a tile + LDS read indices -----------------------------------------
     constexpr int NLR = NK - (OWN0 ? 1 : 0);      // views read from LDS
     constexpr int ROWLEN = (1 + NLR) <= 2 ? 2 : ((1 + NLR) <= 4 ? 4 : 8);
+    (void)ROWLEN;
     uint32_t goff[NREP];
     uint32_t lr[NK][NREP];  // LDS index of the lane's first element seen through view k
 #if SMR_ORBIT_TABLE
@@ -445,7 +446,7 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         l.tname = tname<T>();
         l.argtype = "smr::OrbitArgs";
         l.entry = std::string("smr::orbit_map_body<") + tname<T>() + ", smr::FJit, " + std::to_string(V) + ", " + std::to_string(NREP) + ", " +
-                  std::to_string(NG) + ", " + (OWN0 ? "true" : "false") + ">(a, smr::FJit{});";
+                  std::to_string(NG) + ", " + (OWN0 ? "true" : "false") + ">(a, smr::FJit{kc});";
         l.grid = grid;
         l.block = block;
         l.lds = lds;

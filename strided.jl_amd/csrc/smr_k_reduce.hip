@@ -602,7 +602,7 @@ static int launch_all(const Canon& c, const RedArgs& a, int blocks, hipStream_t 
         l.tname = tname<T>();
         l.argtype = "smr::RedArgs";
         l.entry = std::string("smr::reduce_all_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ", " +
-                  std::to_string(V) + ">(a, smr::FJit{});";
+                  std::to_string(V) + ">(a, smr::FJit{kc});";
         l.grid = (unsigned)blocks;
         l.block = 256;
         l.args = &a;
@@ -681,7 +681,7 @@ static int launch_part(const Canon& c, const RedArgs& a, i64 blocks, hipStream_t
         l.tname = tname<T>();
         l.argtype = "smr::RedArgs";
         l.entry = std::string("smr::") + body[KIND] + "<" + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") +
-                  (KIND ? ", " + std::to_string(V) : std::string()) + ">(a, smr::FJit{});";
+                  (KIND ? ", " + std::to_string(V) : std::string()) + ">(a, smr::FJit{kc});";
         l.grid = (unsigned)blocks;
         l.block = 256;
         l.args = &a;

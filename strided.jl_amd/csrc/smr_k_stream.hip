@@ -168,7 +168,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         l.tname = tname<T>();
         l.argtype = "smr::StreamArgs";
         l.entry = std::string("smr::stream_map_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ", " +
-                  std::to_string(V) + ", " + std::to_string(U) + ", " + (a.txlog == 8 ? "true" : "false") + ">(a, smr::FJit{});";
+                  std::to_string(V) + ", " + std::to_string(U) + ", " + (a.txlog == 8 ? "true" : "false") + ">(a, smr::FJit{kc});";
         l.grid = (unsigned)grid;
         l.block = 256;
         l.args = &a;

@@ -719,10 +719,10 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             l.argtype = WIDE ? "smr::TiledArgs<true>" : "smr::TiledArgs<false>";
             if (pgrid)
                 l.entry = std::string("smr::tiled_map_pipe_body<") + tname<T>() + ", smr::FJit, " + b2s(MIXED) + ", " + b2s(WIDE) + ", " +
-                          std::to_string(V) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
+                          std::to_string(V) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{kc});";
             else
                 l.entry = std::string("smr::tiled_map_body<") + tname<T>() + ", smr::FJit, " + b2s(MIXED) + ", " + b2s(WIDE) + ", " +
-                          std::to_string(V) + ", " + std::to_string(MODE) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{});";
+                          std::to_string(V) + ", " + std::to_string(MODE) + ", " + std::to_string(THRLOG) + ">(a, smr::FJit{kc});";
             l.grid = pgrid ? pgrid : grid_;
             l.block = 1u << THRLOG;
             l.lds = lds;

@@ -50,7 +50,7 @@ static int check_prog(const ProgD& p, int M, int& maxdepth) {
         } else if (op == SMR_OP_CONST) {
             if (imm >= p.nconst) return -1;
             ++sp;
-        } else if (op >= SMR_OP_NEG && op <= SMR_OP_ROUND32) {
+        } else if (op >= SMR_OP_NEG && op <= SMR_OP_WIDEN) {
             if (sp < 1) return -1;
         } else if (op >= SMR_OP_ADD && op <= SMR_OP_NE) {
             if (sp < 2) return -1;
@@ -159,6 +159,8 @@ int canonicalise(const smr_problem* p, Canon& c) {
     }
     for (int i = 0; i < prog.nconst; ++i)
         if (prog.consts[2 * i + 1] != 0.0) cplx = true;
+    for (int pc = 0; pc < prog.len; ++pc)
+        if (prog.code[2 * pc] == SMR_OP_WIDEN) dbl = true;  // a 64-bit scalar takes part (strided_hip.h)
     c.ct = cplx ? (dbl ? SMR_C64 : SMR_C32) : (dbl ? SMR_F64 : SMR_F32);
     c.redop = p->redop;
     c.initop = p->initop;
@@ -169,6 +171,17 @@ int canonicalise(const smr_problem* p, Canon& c) {
         bool pure = p->redop == SMR_RED_NONE && M0 == 2 && p->ops[0].dtype == p->ops[1].dtype && prog.len == 1 &&
                     prog.code[0] == SMR_OP_ARG;
         if (pure) c.bitcopy = true;
+        // Integer data that is not merely moved is computed in Float64 (the four float classes are the device
+        // scope): exact for every value of an 8/16/32-bit type and for sums / counts below
+        // 2^53, which is what the reference's integer tests need (counting reductions, test/othertests.jl:116,123).
+        // 64-bit integer INPUTS can hold values a double cannot: refuse them instead of rounding silently -- the
+        // reference-side binding falls back to the CPU method (Julia's wrapping Int64 arithmetic).
+        if (!pure)
+            for (int k = 1; k < M0; ++k)
+                if (p->ops[k].dtype == SMR_I64 || p->ops[k].dtype == SMR_U64)
+                    return set_error(SMR_EUNSUPPORTED,
+                                     "64-bit integer inputs are supported as pure moves only (copy!/permutedims!): arithmetic on them would run in Float64, "
+                                     "which is exact only below 2^53");
     }
 
     // working copies
@@ -891,11 +904,14 @@ int make_plan(const smr_problem* p, Plan& plan) {
             plan.scratch_bytes = (size_t)nb * es;
         } else {
             const i64 red = c.total / std::max<i64>(1, c.nout);
-            const i64 L0 = c.dims[c.NK];  // inner reduced dim
-            const i64 Q = red / L0;        // outer reduced index (dims NK+1..)
+            // no reduced dim at all (an accumulating map, dest[I] = op(dest[I], f(...)), over up to MAXN kept
+            // dims): nothing to index at position NK -- the general form handles it
+            const bool nored = c.NK >= c.N;
+            const i64 L0 = nored ? 1 : c.dims[c.NK];  // inner reduced dim
+            const i64 Q = red / L0;                    // outer reduced index (dims NK+1..)
             // which vectorisable form applies?
-            bool row = true, col = c.strides[0][0] == 1, any_row = false, any_col = false;
-            for (int k = 1; k < c.M; ++k) {
+            bool row = !nored, col = !nored && c.strides[0][0] == 1, any_row = false, any_col = false;
+            for (int k = 1; k < c.M && !nored; ++k) {
                 const i64 sr = c.strides[k][c.NK], sc = c.strides[k][0];
                 if (sr == 1) any_row = true;
                 else if (sr != 0) row = false;

@@ -211,9 +211,28 @@ def serialize(e: Expr, arg_dtypes=None, wide: bool = False):
             raise TypeError(type(node))
 
     emit(e)
+    if wide and arg_dtypes is not None and not any(
+            np.dtype(t) in (np.dtype(np.float64), np.dtype(np.complex128)) or np.issubdtype(np.dtype(t), np.integer) or np.dtype(t) == np.bool_
+            for t in arg_dtypes):
+        # the 64-bit class comes from a scalar, not from an operand: tell the library (SMR_OP_WIDEN)
+        code.extend((OPCODES["WIDEN"], 0))
     if len(code) // 2 > SMR_MAXPROG:
         raise NotImplementedError("fused expression too long for the device f-program")
     return bytes(code), consts
+
+
+def needs_wide(e: Expr, arg_dtypes) -> bool:
+    """Does Julia evaluate some part of f in a 64-bit (or integer) type?  True for Float64 / ComplexF64 /
+    integer arrays, and for strongly typed 64-bit scalars (`A32 .* 0.1`: a Float64 literal)."""
+    wide = (np.dtype(np.float64), np.dtype(np.complex128))
+
+    def walk(n):
+        t = node_dtype(n, arg_dtypes)
+        if t is not None and (t in wide or np.issubdtype(t, np.integer)):
+            return True
+        return isinstance(n, Call) and any(walk(a) for a in n.args)
+
+    return walk(e)
 
 
 def max_arg(e: Expr) -> int:

@@ -100,6 +100,8 @@ def build_problem(f, op, initop, dims, arrays, stream=None):
     # canonicalise); operations Julia would carry out in Float32 get a ROUND32 when that class is wider
     dts = [np.dtype(a.dtype) for a in arrays]
     wide = any(d in (np.dtype(np.float64), np.dtype(np.complex128)) or np.issubdtype(d, np.integer) or d == np.bool_ for d in dts)
+    # ... or a strongly typed 64-bit scalar inside f (`A32 .* 0.1`: Julia multiplies in Float64): SMR_OP_WIDEN
+    wide = wide or E.needs_wide(e, [a.dtype for a in arrays[1:]])
     code, consts = E.serialize(e, [a.dtype for a in arrays[1:]], wide)
     p = L.smr_problem()
     p.N, p.M = N, M

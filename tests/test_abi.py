@@ -316,3 +316,42 @@ def test_shard_ex_local_operands_and_reported_slab():
             out2 = L.smr_problem()
             assert lib.smr_shard(C.byref(p), nsh, r, C.byref(out2), C.byref(need)) == 0
             assert out2.ops[1].offset == 30 * lo.value  # replicated operand: shifted inside the whole parent
+
+
+def test_64bit_integer_inputs_are_moves_only():
+    """integer arithmetic runs in Float64 (exact below 2^53); 64-bit integer inputs could hold more,
+    so anything but a pure move of them is SMR_EUNSUPPORTED (the Julia shim falls back to the CPU method)."""
+    lib = L.load()
+    h = C.c_void_p()
+    a, b = _views((16, 16), [(1, 16), (16, 1)], np.int64)
+    p, keep = S.build_problem(lambda v: v, None, None, (16, 16), (a, b), stream=0)     # permutedims! of Int64: fine
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == 0
+    lib.smr_plan_destroy(h)
+    p, keep = S.build_problem(lambda v: v + 1, None, None, (16, 16), (a, b), stream=0)
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EUNSUPPORTED and b"2^53" in lib.smr_last_error()
+    o = S.StridedView(np.zeros(1, dtype=np.int64), (16, 16), (0, 0), 0)
+    p, keep = S.build_problem(lambda v: v, "+", None, (16, 16), (o, b), stream=0)       # sum of Int64
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EUNSUPPORTED
+    c32, = _views((16, 16), [(1, 16)], np.int32)
+    p, keep = S.build_problem(lambda v: v, "+", None, (16, 16), (o, c32), stream=0)     # Int32 -> Int64 sum: allowed
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == 0
+    lib.smr_plan_destroy(h)
+
+
+def test_plan_rebinding_must_keep_the_aliasing_pattern():
+    """canonicalise merges identical views of one buffer (A .+ A); rebinding such a plan to two different
+    buffers would silently ignore one of them -> SMR_EINVAL."""
+    lib = L.load()
+    x, y = _views((64, 64), [(1, 64), (1, 64)])
+    p, keep = S.build_problem(lambda u, v: u + v, None, None, (64, 64), (x, y, y), stream=0)
+    h = C.c_void_p()
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == 0
+    buf = (C.c_char * 64)()
+    addr = C.addressof(buf)
+    same = (C.c_void_p * 3)(addr, addr + 8, addr + 8)
+    diff = (C.c_void_p * 3)(addr, addr + 8, addr + 16)
+    # (no device here: the aliasing check comes before anything touches the GPU; a consistent rebinding gets
+    # as far as the device check)
+    assert lib.smr_plan_execute(h, diff, None) == L.SMR_EINVAL and b"share a buffer" in lib.smr_last_error()
+    assert lib.smr_plan_execute(h, same, None) != L.SMR_EINVAL or b"share a buffer" not in lib.smr_last_error()
+    lib.smr_plan_destroy(h)

@@ -19,11 +19,14 @@ def test_generated_functor_mirrors_the_f_program():
     src = plan.jit_source()
     assert "static constexpr int NIN = 2;" in src
     assert "typedef double JT;" in src
-    # postfix order: a[0] 2 * a[1] 3 / + 1 -   with exact hex-float constants
+    # postfix order: a[0] 2 * a[1] 3 / + 1 -   constants are kernel arguments (k.c[2i], k.c[2i+1] = re, im of
+    # constant i): the text -- the key of the compiled-code cache -- depends on the program's structure only
     body = [ln.strip() for ln in src.splitlines() if ln.strip().startswith("const JT v")]
-    assert body[0].endswith("= a[0];") and "0x1p+1" in body[1] and "bin(34, v0, v1)" in body[2]
-    assert body[3].endswith("= a[1];") and "0x1.8p+1" in body[4] and "bin(35, v3, v4)" in body[5]
-    assert "bin(32, v2, v5)" in body[6] and "bin(33, v6, v7)" in body[8]
+    assert body[0].endswith("= a[0];") and "k.c[0]" in body[1] and "bin(34, v0, v1)" in body[2]
+    assert body[3].endswith("= a[1];") and "k.c[2]" in body[4] and "bin(35, v3, v4)" in body[5]
+    assert "bin(32, v2, v5)" in body[6] and "k.c[4]" in body[7] and "bin(33, v6, v7)" in body[8]
+    other = S.make_plan(lambda a, c: a * 7.5 + c / 0.1 - 3, None, None, A.size, (B, A, C)).jit_source()
+    assert other == src  # a different scalar does not make a different program
     # select(cond, then, else) pops three
     plan = S.make_plan(lambda a, c: fn.select(a < c, a, c), None, None, A.size, (B, A, C))
     assert "truthy(v2) ? v3 : v4" in plan.jit_source()
@@ -87,7 +90,7 @@ def test_disk_cache_is_opt_in_and_reused(tmp_path, monkeypatch):
     source (same library build) is served from disk instead of running the compiler."""
     monkeypatch.setenv("SMR_JIT_CACHE_DIR", str(tmp_path))
     A, B = _v((96, 96)), _v((96, 96))
-    f = lambda a: a * a - a * 0.123456789  # noqa: E731  (a constant no other test uses)
+    f = lambda a: (a * a - a * 0.123456789) * a + a  # noqa: E731  (a program no other test compiles: constants do not distinguish programs)
     c0 = S.get_option("jit_compiles")
     n1 = S.make_plan(f, None, None, A.size, (B, A)).jit_compile()
     assert n1 > 0 and S.get_option("jit_compiles") == c0 + 1
@@ -101,7 +104,7 @@ def test_missing_compiler_helper_is_reported_not_fatal(monkeypatch):
     monkeypatch.setenv("SMR_JITC", "/nonexistent/smr_jitc")
     A, B = _v((80, 80)), _v((80, 80))
     f0 = S.get_option("jit_failures")
-    plan = S.make_plan(lambda a: a * a - a * 0.987654321, None, None, A.size, (B, A))   # a source no other test compiles
+    plan = S.make_plan(lambda a: fn.tanh(a) * a - fn.cos(a) * 0.987654321, None, None, A.size, (B, A))   # a program no other test compiles
     with pytest.raises(S.UnsupportedOnDevice):
         plan.jit_compile()
     assert S.get_option("jit_failures") == f0 + 1

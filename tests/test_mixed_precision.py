@@ -39,6 +39,40 @@ def _check(mk, sync=lambda: None):
     outT.assign(A.permutedims((1, 0)) * B.permutedims((1, 0)) + 1.25)
     sync()
     assert np.array_equal(outT.toarray(), (a.T * b.T).astype(np.float64) + 1.25)
+    # a Float64 SCALAR among Float32 arrays: Julia multiplies in Float64 and rounds once on store (SMR_OP_WIDEN)
+    o32 = mk(np.zeros((70, 50), dtype=np.float32))
+    o32.assign(A * 0.1)
+    sync()
+    assert np.array_equal(o32.toarray(), (a.astype(np.float64) * 0.1).astype(np.float32))
+    assert not np.array_equal(o32.toarray(), a * np.float32(0.1))  # the Float32 product differs in the last bit somewhere
+    o32.assign(A * B + 0.3)   # Float32 product (rounded), Float64 sum, one rounding on store
+    sync()
+    assert np.array_equal(o32.toarray(), ((a * b).astype(np.float64) + 0.3).astype(np.float32))
+    o32.assign(A * np.float32(0.1) + 2)   # a Float32 scalar and a weak integer: everything stays Float32
+    sync()
+    assert np.array_equal(o32.toarray(), a * np.float32(0.1) + np.float32(2))
+    # min / max follow Julia: NaN if either argument is NaN, min(-0.0, 0.0) = -0.0, max(-0.0, 0.0) = 0.0
+    x = np.array([[np.nan, 1.0, -0.0, 0.0, 3.0, np.nan]] * 2, dtype=np.float64)
+    y = np.array([[2.0, np.nan, 0.0, -0.0, -1.0, np.nan]] * 2, dtype=np.float64)
+    X, Y, o = mk(x), mk(y), mk(np.zeros_like(x))
+    o.assign(fn.min(X, Y))
+    sync()
+    got = o.toarray()[0]
+    assert np.isnan(got[0]) and np.isnan(got[1]) and np.isnan(got[5]) and got[4] == -1.0
+    assert np.signbit(got[2]) and np.signbit(got[3]) and got[2] == 0 and got[3] == 0
+    o.assign(fn.max(X, Y))
+    sync()
+    got = o.toarray()[0]
+    assert np.isnan(got[0]) and np.isnan(got[1]) and np.isnan(got[5]) and got[4] == 3.0
+    assert not np.signbit(got[2]) and not np.signbit(got[3])
+    # ... and so do minimum / maximum: one NaN anywhere gives NaN (the reference seeds with first(A),
+    # src/mapreduce.jl:62-66,184-185; seeding with +-inf and Julia's min / max gives the same value for every input)
+    z = rng.standard_normal((33, 21))
+    z[17, 5] = np.nan
+    assert np.isnan(S.minimum(mk(z))) and np.isnan(S.maximum(mk(z)))
+    zz = np.where(np.isnan(z), 0.5, z)
+    assert S.minimum(mk(zz)) == zz.min() and S.maximum(mk(zz)) == zz.max()
+    assert np.signbit(S.minimum(mk(np.array([[0.0, -0.0], [0.0, 0.0]])))) and not np.signbit(S.maximum(mk(np.array([[-0.0, 0.0], [-0.0, -0.0]]))))
     # reductions: the mapped value is a Float32 product, accumulated in the destination's Float64
     acc = mk(np.zeros((70, 1)))
     S.mapreducedim_(lambda x, y: x * y, "+", acc, A, B)
