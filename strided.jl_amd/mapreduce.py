@@ -81,6 +81,57 @@ def _current_stream() -> int:
     return 0
 
 
+_FPROG_CACHE: dict = {}
+
+
+def _closure_key(f):
+    """Hashable identity of a plain Python function INCLUDING the values it closes over (a lambda capturing a
+    scalar that changes between calls must not hit a stale entry); None when that cannot be established."""
+    code = getattr(f, "__code__", None)
+    if code is None or getattr(f, "__self__", None) is not None:
+        return None
+    cells = ()
+    if f.__closure__:
+        try:
+            cells = tuple(c.cell_contents for c in f.__closure__)
+        except ValueError:
+            return None
+        if not all(isinstance(v, (int, float, complex, bool, np.generic, type(None))) or callable(v) for v in cells):
+            return None
+        cells = tuple((type(v).__name__, v if not callable(v) else id(v)) for v in cells)
+    if code.co_names and any(isinstance(f.__globals__.get(n, None), (int, float, complex, np.generic)) for n in code.co_names):
+        return None  # reads a module-level scalar that may change
+    return (code, cells, f.__defaults__)
+
+
+def _serialized(f, M, dts):
+    """(code, consts) of f for these operand dtypes.  Tracing a closure and serialising the expression costs
+    tens of microseconds of Python -- more than the kernels of a 32^4 problem run -- so the result is kept per
+    (closure, captured values, dtypes)."""
+    key = None
+    if not isinstance(f, E.Expr) and not isinstance(f, str):
+        ck = _closure_key(f)
+        if ck is not None:
+            key = (ck, M, dts)
+            hit = _FPROG_CACHE.get(key)
+            if hit is not None:
+                return hit
+    e = E.trace(f, M - 1)
+    if E.max_arg(e) > M - 1:
+        raise ValueError("f uses more arguments than arrays were given")
+    # the library computes the call in the widest float class among ALL operands (csrc/smr_plan.cpp:
+    # canonicalise); operations Julia would carry out in Float32 get a ROUND32 when that class is wider
+    wide = any(d in (np.dtype(np.float64), np.dtype(np.complex128)) or np.issubdtype(d, np.integer) or d == np.bool_ for d in dts)
+    # ... or a strongly typed 64-bit scalar inside f (`A32 .* 0.1`: Julia multiplies in Float64): SMR_OP_WIDEN
+    wide = wide or E.needs_wide(e, list(dts[1:]))
+    out = E.serialize(e, list(dts[1:]), wide)
+    if key is not None:
+        if len(_FPROG_CACHE) > 4096:
+            _FPROG_CACHE.clear()
+        _FPROG_CACHE[key] = out
+    return out
+
+
 def build_problem(f, op, initop, dims, arrays, stream=None):
     """Serialise the funnel's arguments into an `smr_problem` (plus the buffers it points to,
     which the caller must keep alive for the duration of the call)."""
@@ -93,16 +144,8 @@ def build_problem(f, op, initop, dims, arrays, stream=None):
         raise L.UnsupportedOnDevice(L.SMR_EUNSUPPORTED, f"rank {N} > {L.SMR_MAXN}")
     if M > L.SMR_MAXM:
         raise L.UnsupportedOnDevice(L.SMR_EUNSUPPORTED, f"{M} operands > {L.SMR_MAXM}")
-    e = E.trace(f, M - 1)
-    if E.max_arg(e) > M - 1:
-        raise ValueError("f uses more arguments than arrays were given")
-    # the library computes the call in the widest float class among ALL operands (csrc/smr_plan.cpp:
-    # canonicalise); operations Julia would carry out in Float32 get a ROUND32 when that class is wider
     dts = [np.dtype(a.dtype) for a in arrays]
-    wide = any(d in (np.dtype(np.float64), np.dtype(np.complex128)) or np.issubdtype(d, np.integer) or d == np.bool_ for d in dts)
-    # ... or a strongly typed 64-bit scalar inside f (`A32 .* 0.1`: Julia multiplies in Float64): SMR_OP_WIDEN
-    wide = wide or E.needs_wide(e, [a.dtype for a in arrays[1:]])
-    code, consts = E.serialize(e, [a.dtype for a in arrays[1:]], wide)
+    code, consts = _serialized(f, M, tuple(dts))
     p = L.smr_problem()
     p.N, p.M = N, M
     for i, d in enumerate(dims):

@@ -136,3 +136,29 @@ def test_initop_tracing_covers_the_five_reference_forms():
     assert _initop_code("conj")[0] == L.SMR_INIT_CONJ and _initop_code(fn.conj)[0] == L.SMR_INIT_CONJ
     with pytest.raises(NotImplementedError):
         _initop_code(lambda x: x * x)
+
+
+def test_traced_f_programs_are_cached_per_closure_including_captured_values():
+    """_mapreduce_fuse_ re-traced f on every call.  The cache key holds the values a
+    closure captures, so a loop whose scalar changes does not see stale constants."""
+    import ctypes as C
+    import importlib
+    MR = importlib.import_module("strided_jl_amd.mapreduce")  # the package attribute `mapreduce` is the front-end function
+    a = S.StridedView(np.zeros((8, 8), order="F"))
+    b = a.similar()
+    MR._FPROG_CACHE.clear()
+    consts = []
+    for c in (0.5, 0.75, 0.5):
+        p, keep = S.build_problem(lambda x: x * c + 1, None, None, a.size, (b, a), stream=0)
+        consts.append([p.fconsts[i] for i in range(2 * p.nconsts)])
+    assert consts[0] != consts[1] and consts[0] == consts[2]
+    assert len(MR._FPROG_CACHE) == 2          # two distinct captured values, the third call was a hit
+    f = lambda x: x * x - 2                   # noqa: E731
+    p1, k1 = S.build_problem(f, None, None, a.size, (b, a), stream=0)
+    n = len(MR._FPROG_CACHE)
+    p2, k2 = S.build_problem(f, None, None, a.size, (b, a), stream=0)
+    assert len(MR._FPROG_CACHE) == n and bytes(p1.fprog[0:2 * p1.fprog_len]) == bytes(p2.fprog[0:2 * p2.fprog_len])
+    # another operand dtype is another program (ROUND32 placement depends on the types)
+    a32 = S.StridedView(np.zeros((8, 8), dtype=np.float32, order="F"))
+    S.build_problem(f, None, None, a.size, (b, a32), stream=0)
+    assert len(MR._FPROG_CACHE) == n + 1
