@@ -2,18 +2,33 @@
 # StridedViews whose parent lives in MI355X memory run on libstrided_hip.so.
 #
 # NOT EXECUTED IN THIS REPOSITORY: there is no Julia runtime in the build image or on the GPU
-# box.  It is kept deliberately thin: every method below only *serialises* what the reference's
-# funnel already holds -- `_mapreduce_fuse!(f, op, initop, dims, arrays)`, src/mapreduce.jl:98 --
-# into the C struct of include/strided_hip.h and `ccall`s it.  All view algebra, broadcasting
-# style rules, `promoteshape`, argument checks and the `@strided` macro stay the reference's own.
+# box.  tests/test_julia_shim.py checks by parsing this file that its C structs, opcode / dtype /
+# redop / initop tables equal include/strided_hip.h.  It is kept deliberately thin: every method only
+# *serialises* what the reference's funnel already holds -- `_mapreduce_fuse!(f, op, initop, dims,
+# arrays)`, src/mapreduce.jl:98 -- into the C struct of include/strided_hip.h and `ccall`s it.  All view
+# algebra, `promoteshape`, argument checks, the `@strided` macro AND the BroadcastStyle rules stay the
+# reference's own: a device view mixed with a plain host `Array` resolves to DefaultArrayStyle
+# (src/broadcast.jl:11-18), i.e. Base's scalar-indexing broadcast, which `HipBuffer` refuses -- upload first.
 module StridedHIP
 
 using Strided, StridedViews
-using Strided: CaptureArgs, Arg
+using Strided: CaptureArgs, Arg, StridedArrayStyle, capturestridedargs
+using Base.Broadcast: Broadcasted, DefaultArrayStyle
 import Strided: _mapreduce_fuse!
 
 const lib = get(ENV, "STRIDED_HIP_LIB", "libstrided_hip.so")
 const MAXN, MAXM = 8, 8
+
+struct Unsupported <: Exception
+    msg::String
+end
+function check(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:smr_last_error, lib), Cstring, ()))
+    rc == -2 && throw(Unsupported(msg))          # SMR_EUNSUPPORTED -> CPU fallback below
+    rc == -1 && throw(ArgumentError(msg))        # SMR_EINVAL
+    error("libstrided_hip: $msg (status $rc)")
+end
 
 # ---- device memory: a DenseArray whose storage is a HIP allocation (smr_malloc) ---------------
 mutable struct HipBuffer{T,N} <: DenseArray{T,N}
@@ -28,29 +43,32 @@ mutable struct HipBuffer{T,N} <: DenseArray{T,N}
     end
 end
 Base.size(b::HipBuffer) = b.dims
-Base.similar(b::HipBuffer, ::Type{T}, dims::Dims) where {T} = HipBuffer{T}(undef, dims)
+Base.strides(b::HipBuffer) = Base.size_to_strides(1, b.dims...)
+Base.elsize(::Type{<:HipBuffer{T}}) where {T} = sizeof(T)
+Base.pointer(b::HipBuffer) = b.ptr
 Base.unsafe_convert(::Type{Ptr{T}}, b::HipBuffer{T}) where {T} = b.ptr
-function upload(a::Array{T,N}) where {T,N}
-    b = HipBuffer{T}(undef, size(a))
-    check(ccall((:smr_memcpy_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), b.ptr, a, sizeof(a), C_NULL))
-    return b
-end
-function download(b::HipBuffer{T,N}) where {T,N}
-    a = Array{T,N}(undef, size(b))
-    check(ccall((:smr_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), a, b.ptr, sizeof(a), C_NULL))
+Base.similar(b::HipBuffer, ::Type{T}, dims::Dims) where {T} = HipBuffer{T}(undef, dims)
+Base.getindex(::HipBuffer, I...) = error("scalar indexing of device memory: download(...) first")
+Base.setindex!(::HipBuffer, v, I...) = error("scalar indexing of device memory: upload(...) instead")
+function Base.copyto!(dst::HipBuffer{T,N}, src::Array{T,N}) where {T,N}   # host -> device
+    check(ccall((:smr_memcpy_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dst.ptr, src, sizeof(src), C_NULL))
     check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))
-    return a
+    return dst
 end
+function Base.copyto!(dst::Array{T,N}, src::HipBuffer{T,N}) where {T,N}   # device -> host
+    check(ccall((:smr_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dst, src.ptr, sizeof(dst), C_NULL))
+    check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))
+    return dst
+end
+upload(a::Array{T,N}) where {T,N} = copyto!(HipBuffer{T}(undef, size(a)), a)
+download(b::HipBuffer{T,N}) where {T,N} = copyto!(Array{T,N}(undef, size(b)), b)
 
-function check(rc::Cint)
-    rc == 0 && return nothing
-    msg = unsafe_string(ccall((:smr_last_error, lib), Cstring, ()))
-    rc == -2 && throw(Unsupported(msg))          # SMR_EUNSUPPORTED -> CPU fallback below
-    rc == -1 && throw(ArgumentError(msg))        # SMR_EINVAL
-    error("libstrided_hip: $msg (status $rc)")
-end
-struct Unsupported <: Exception
-    msg::String
+const HipView = StridedView{<:Any,<:Any,<:HipBuffer}
+# out-of-place `@strided A .+ B` on device views allocates its result on the device (the reference's method,
+# src/broadcast.jl:20-22, makes a host Array); more specific than the reference's `<:StridedArrayStyle{N}`
+function Base.similar(bc::Broadcasted{StridedArrayStyle{N}}, ::Type{T}) where {N,T}
+    any(a -> a isa HipView, capturestridedargs(bc)) && return StridedView(HipBuffer{T}(undef, map(length, axes(bc))))
+    return StridedView(similar(convert(Broadcasted{DefaultArrayStyle{N}}, bc), T))
 end
 
 # ---- C structs (include/strided_hip.h) -------------------------------------------------------------
@@ -76,83 +94,104 @@ struct SmrProblem
     stream::Ptr{Cvoid}
 end
 
-dtypecode(::Type{Float32}) = 0; dtypecode(::Type{Float64}) = 1
-dtypecode(::Type{ComplexF32}) = 2; dtypecode(::Type{ComplexF64}) = 3
-dtypecode(::Type{Int8}) = 4; dtypecode(::Type{Int16}) = 5; dtypecode(::Type{Int32}) = 6; dtypecode(::Type{Int64}) = 7
-dtypecode(::Type{UInt8}) = 8; dtypecode(::Type{Bool}) = 8
-dtypecode(T) = throw(Unsupported("eltype $T"))
+const DTYPES = Dict(Float32 => 0, Float64 => 1, ComplexF32 => 2, ComplexF64 => 3, Int8 => 4, Int16 => 5, Int32 => 6, Int64 => 7,
+                    UInt8 => 8, Bool => 8, UInt16 => 9, UInt32 => 10, UInt64 => 11)
+dtypecode(T) = get(() -> throw(Unsupported("eltype $T")), DTYPES, T)
 
 pad(t::NTuple{N,Int}, v) where {N} = ntuple(i -> i <= N ? Int64(t[i]) : Int64(v), MAXN)
-function operand(a::StridedView{T,N}) where {T,N}
-    return SmrOperand(pointer(a.parent), a.offset, pad(a.strides, 0), dtypecode(T), a.op === conj ? 1 : 0)
-end
+operand(a::StridedView{T}) where {T} = SmrOperand(pointer(a.parent), a.offset, pad(a.strides, 0), dtypecode(T), a.op === conj ? 1 : 0)
 const NULLOP = SmrOperand(C_NULL, 0, ntuple(_ -> Int64(0), MAXN), 0, 0)
 
 # ---- f -> postfix f-program (walks the CaptureArgs tree of src/broadcast.jl:67-83) ---------------------
-const UNARY = Dict(:- => 8, abs => 9, abs2 => 10, conj => 11, real => 12, imag => 13, sqrt => 14, exp => 15,
+const UNARY = Dict((-) => 8, abs => 9, abs2 => 10, conj => 11, real => 12, imag => 13, sqrt => 14, exp => 15,
                    log => 16, sin => 17, cos => 18, tanh => 19, inv => 20)
-const BINARY = Dict(+ => 32, - => 33, * => 34, / => 35, min => 36, max => 37, < => 38, <= => 39, > => 40,
-                    >= => 41, == => 42, != => 43)
+const BINARY = Dict((+) => 32, (-) => 33, (*) => 34, (/) => 35, min => 36, max => 37, (<) => 38, (<=) => 39, (>) => 40,
+                    (>=) => 41, (==) => 42, (!=) => 43)
+const OP_ARG, OP_CONST, OP_ROUND32, OP_WIDEN, OP_SELECT = 0x00, 0x01, 0x15, 0x16, 0x40
+const NARROW, WIDE = (Float32, ComplexF32), (Float64, ComplexF64)
 mutable struct Prog
     code::Vector{UInt8}
     consts::Vector{Float64}
     nextarg::Int
+    eltypes::Vector{DataType}   # of the inputs, in argument order
+    wide::Bool                  # the library computes this call in a 64-bit class
 end
-emit!(p::Prog, ::Arg) = (p.nextarg += 1; push!(p.code, 0x00, UInt8(p.nextarg)))
+# every emit! returns the Julia type of the value it pushed: Julia types each operation of a fused expression
+# separately, the library computes one class per call -> ROUND32 after operations Julia carries out in 32 bits
+function emit!(p::Prog, ::Arg)
+    p.nextarg += 1
+    push!(p.code, OP_ARG, UInt8(p.nextarg))
+    return p.eltypes[p.nextarg]
+end
 function emit!(p::Prog, x::Number)
     push!(p.consts, real(x), imag(x))
-    push!(p.code, 0x01, UInt8(length(p.consts) ÷ 2 - 1))
+    push!(p.code, OP_CONST, UInt8(length(p.consts) ÷ 2 - 1))
+    return typeof(x)
+end
+function round32!(p::Prog, T)
+    p.wide && T in NARROW && push!(p.code, OP_ROUND32, 0x00)
+    return T
 end
 function emit!(p::Prog, c::CaptureArgs)
     f, args = c.f, c.args
-    if length(args) == 1
-        f === (-) ? (emit!(p, args[1]); push!(p.code, 8, 0)) :
-        haskey(UNARY, f) ? (emit!(p, args[1]); push!(p.code, UNARY[f], 0)) : throw(Unsupported("function $f"))
+    if length(args) == 1 && haskey(UNARY, f)
+        T = emit!(p, args[1])
+        push!(p.code, UNARY[f], 0x00)
+        return round32!(p, Base.promote_op(f, T))
     elseif haskey(BINARY, f) && (length(args) == 2 || f in (+, *, min, max))
-        emit!(p, args[1])                      # Julia's +(a,b,c,d) folds left
+        T = emit!(p, args[1])                  # Julia's +(a,b,c,d) folds left
         for a in args[2:end]
-            emit!(p, a); push!(p.code, BINARY[f], 0)
+            T = Base.promote_op(f, T, emit!(p, a))
+            push!(p.code, BINARY[f], 0x00)
+            round32!(p, T)
         end
+        return T
     elseif f === ifelse && length(args) == 3
-        foreach(a -> emit!(p, a), args); push!(p.code, 64, 0)
-    else
-        throw(Unsupported("function $f"))
+        Ts = map(a -> emit!(p, a), args)
+        push!(p.code, OP_SELECT, 0x00)
+        return promote_type(Ts[2], Ts[3])
     end
+    throw(Unsupported("function $f"))
 end
 emit!(p::Prog, x) = throw(Unsupported("captured $(typeof(x))"))
-# map!'s plain functions: identity / conj / a few arities of + and *
-fprogram(::typeof(identity), M) = Prog(UInt8[0, 1], Float64[], 1)
-fprogram(::typeof(conj), M) = Prog(UInt8[0, 1, 11, 0], Float64[], 1)
-fprogram(c::CaptureArgs, M) = (p = Prog(UInt8[], Float64[], 0); emit!(p, c); p)
-function fprogram(f::Union{typeof(+),typeof(*)}, M)
-    p = Prog(UInt8[0, 1], Float64[], 1)
-    for k in 2:(M - 1)
-        push!(p.code, 0, UInt8(k), BINARY[f], 0)
+function fprogram(c::CaptureArgs, eltypes, desttype)
+    p = Prog(UInt8[], Float64[], 0, collect(eltypes), false)
+    T = emit!(p, c)                            # dry pass: does a 64-bit type occur anywhere?
+    arrays64 = any(t -> t in WIDE || t <: Integer, (desttype, eltypes...))
+    if arrays64 || T in WIDE
+        p = Prog(UInt8[], Float64[], 0, collect(eltypes), true)
+        emit!(p, c)
+        arrays64 || push!(p.code, OP_WIDEN, 0x00)   # the 64-bit class comes from a scalar (`A32 .* 0.1`)
     end
     return p
 end
-fprogram(f, M) = throw(Unsupported("closure $(typeof(f))"))   # arbitrary closures stay on the CPU
+# map!'s plain functions: identity / conj / a few arities of + and *
+fprogram(::typeof(identity), eltypes, desttype) = Prog(UInt8[OP_ARG, 1], Float64[], 1, DataType[], false)
+fprogram(::typeof(conj), eltypes, desttype) = Prog(UInt8[OP_ARG, 1, 11, 0], Float64[], 1, DataType[], false)
+function fprogram(f::Union{typeof(+),typeof(*)}, eltypes, desttype)
+    p = Prog(UInt8[OP_ARG, 1], Float64[], 1, DataType[], false)
+    for k in 2:length(eltypes)
+        push!(p.code, OP_ARG, UInt8(k), BINARY[f], 0x00)
+    end
+    return p
+end
+fprogram(f, eltypes, desttype) = throw(Unsupported("closure $(typeof(f))"))   # arbitrary closures stay on the CPU
 
-redcode(::Nothing) = 0
-redcode(::Union{typeof(+),typeof(Base.add_sum)}) = 1
-redcode(::Union{typeof(*),typeof(Base.mul_prod)}) = 2
-redcode(::typeof(min)) = 3; redcode(::typeof(max)) = 4
-redcode(::typeof(&)) = 5; redcode(::typeof(|)) = 6           # neutral elements true / false (src/mapreduce.jl:188-189)
-redcode(op) = throw(Unsupported("reduction $op"))
-initcode(::Nothing) = (0, 0.0 + 0im); initcode(::typeof(identity)) = (1, 0.0 + 0im)
-initcode(::typeof(zero)) = (2, 0.0 + 0im); initcode(::typeof(conj)) = (5, 0.0 + 0im)
-initcode(f) = throw(Unsupported("initop $(typeof(f))"))      # x->x*β / x->β: see `Scale`, `Const`
-struct Scale{T}; β::T; end; (s::Scale)(x) = x * s.β; initcode(s::Scale) = (3, complex(s.β))
-struct Const{T}; β::T; end; (s::Const)(x) = s.β; initcode(s::Const) = (4, complex(s.β))
-
-const HipView = StridedView{<:Any,<:Any,<:HipBuffer}
+const REDOPS = Dict(nothing => 0, (+) => 1, Base.add_sum => 1, (*) => 2, Base.mul_prod => 2, min => 3, max => 4, (&) => 5, (|) => 6)
+redcode(op) = get(() -> throw(Unsupported("reduction $op")), REDOPS, op)
+const INITOPS = Dict(nothing => 0, identity => 1, zero => 2, conj => 5)
+struct Scale{T}; β::T; end; (s::Scale)(x) = x * s.β     # x -> x*β and x -> β (src/linalg.jl:150,158) are opaque
+struct Const{T}; β::T; end; (s::Const)(x) = s.β         # closures in Julia: __mul! passes these structs instead
+initcode(s::Scale) = (3, complex(s.β))
+initcode(s::Const) = (4, complex(s.β))
+initcode(f) = (get(() -> throw(Unsupported("initop $(typeof(f))")), INITOPS, f), 0.0 + 0im)
 
 # ---- the drop-in: one more method at the reference's funnel -----------------------------------------------
 function _mapreduce_fuse!(f, op, initop, dims::Dims, arrays::Tuple{HipView,Vararg{HipView}})
     M, N = length(arrays), length(dims)
     try
         (N <= MAXN && M <= MAXM) || throw(Unsupported("rank/operand count"))
-        prog = fprogram(f, M)
+        prog = fprogram(f, map(eltype, Base.tail(arrays)), eltype(arrays[1]))
         ic, β = initcode(initop)
         ops = ntuple(k -> k <= M ? operand(arrays[k]) : NULLOP, MAXM)
         GC.@preserve arrays prog begin
@@ -165,15 +204,14 @@ function _mapreduce_fuse!(f, op, initop, dims::Dims, arrays::Tuple{HipView,Varar
             check(ccall((:smr_mapreduce_sharded, lib), Cint, (Ptr{SmrProblem},), p))
             check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))   # the reference is synchronous
         end
-        return arrays[1]
     catch e
         e isa Unsupported || rethrow()
-        # outside the device whitelist: run the reference's own CPU method on host copies
+        # outside the device whitelist: run the reference's own CPU method on host copies, copy the result back
         host = map(a -> StridedView(download(a.parent), a.size, a.strides, a.offset, a.op), arrays)
         invoke(_mapreduce_fuse!, Tuple{Any,Any,Any,Dims,Tuple{Vararg{StridedView}}}, f, op, initop, dims, host)
-        copyto!(arrays[1].parent, upload(host[1].parent))
-        return arrays[1]
+        copyto!(arrays[1].parent, host[1].parent)
     end
+    return arrays[1]
 end
 
 end # module

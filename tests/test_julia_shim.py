@@ -1,0 +1,102 @@
+"""julia/StridedHIP.jl cannot be executed here (no Julia runtime), so it is checked by inspection-proof
+means: its C struct mirrors, opcode / dtype / redop / initop tables are parsed and compared with
+include/strided_hip.h (through the ctypes mirror, whose layout tests/test_abi.py ties to the header), and the
+methods VERDICT r1 found missing are asserted present.  Reference lines: src/broadcast.jl:3-24 (style rules,
+`similar`), src/macros.jl:31-43 (maybeunstrided), src/mapreduce.jl:98 (the funnel the shim adds a method to)."""
+import os
+import re
+
+import ctypes as C
+
+from strided_jl_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "julia", "StridedHIP.jl")).read()
+HDR = open(os.path.join(ROOT, "include", "strided_hip.h")).read()
+
+
+def _enum(prefix):
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"\b" + prefix + r"(\w+)\s*=\s*(\d+)", HDR)}
+
+
+def _struct(name):
+    body = re.search(r"struct " + name + r"\n(.*?)\nend", SRC, re.S).group(1)
+    return [tuple(x.strip() for x in ln.split("::")) for ln in body.strip().splitlines()]
+
+
+JL2C = {"Ptr{Cvoid}": C.c_void_p, "Int64": C.c_int64, "Int32": C.c_int32, "Ptr{UInt8}": C.POINTER(C.c_uint8), "Ptr{Float64}": C.POINTER(C.c_double),
+        "NTuple{MAXN,Int64}": C.c_int64 * 8, "NTuple{2,Float64}": C.c_double * 2}
+
+
+def test_struct_mirrors_match_the_header():
+    for jl, ct in (("SmrOperand", L.smr_operand), ("SmrProblem", L.smr_problem)):
+        fields = _struct(jl)
+        assert [f for f, _ in fields] == [f for f, _ in ct._fields_], jl
+        for (fname, jt), (_, cty) in zip(fields, ct._fields_):
+            if jt == "NTuple{MAXM,SmrOperand}":
+                assert cty._type_ is L.smr_operand and cty._length_ == 8
+            else:
+                want = JL2C[jt]
+                assert C.sizeof(want) == C.sizeof(cty), (jl, fname, jt)
+    assert re.search(r"const MAXN, MAXM = 8, 8", SRC) and "#define SMR_MAXN 8" in HDR and "#define SMR_MAXM 8" in HDR
+
+
+def _dict(name):
+    body = re.search(r"const " + name + r" = Dict\((.*?)\)\n", SRC, re.S).group(1)
+    out = {}
+    for item in re.split(r",\s*", body.replace("\n", " ")):
+        k, v = item.rsplit(" => ", 1)
+        k = k.strip()
+        if k.startswith("(") and k.endswith(")"):
+            k = k[1:-1]
+        out[k] = int(v)
+    return out
+
+
+def test_opcode_tables_match_the_header():
+    ops = _enum("SMR_OP_")
+    un = _dict("UNARY")
+    names = {"-": "NEG", "abs": "ABS", "abs2": "ABS2", "conj": "CONJ", "real": "REAL", "imag": "IMAG", "sqrt": "SQRT", "exp": "EXP",
+             "log": "LOG", "sin": "SIN", "cos": "COS", "tanh": "TANH", "inv": "INV"}
+    assert set(un) == set(names) and all(un[k] == ops[v] for k, v in names.items())
+    bi = _dict("BINARY")
+    names = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "min": "MIN", "max": "MAX", "<": "LT", "<=": "LE", ">": "GT", ">=": "GE",
+             "==": "EQ", "!=": "NE"}
+    assert set(bi) == set(names) and all(bi[k] == ops[v] for k, v in names.items())
+    m = re.search(r"const OP_ARG, OP_CONST, OP_ROUND32, OP_WIDEN, OP_SELECT = (0x\w+), (0x\w+), (0x\w+), (0x\w+), (0x\w+)", SRC)
+    assert [int(x, 16) for x in m.groups()] == [ops["ARG"], ops["CONST"], ops["ROUND32"], ops["WIDEN"], ops["SELECT"]]
+    assert ops == {k: v for k, v in L.OPCODES.items()}  # and the ctypes mirror agrees with the header too
+
+
+def test_dtype_redop_initop_codes_match_the_header():
+    dt = _enum("SMR_(?=[FCIU]\\d)")
+    jl = _dict("DTYPES")
+    want = {"Float32": "F32", "Float64": "F64", "ComplexF32": "C32", "ComplexF64": "C64", "Int8": "I8", "Int16": "I16", "Int32": "I32",
+            "Int64": "I64", "UInt8": "U8", "Bool": "U8", "UInt16": "U16", "UInt32": "U32", "UInt64": "U64"}
+    assert set(jl) == set(want) and all(jl[k] == dt[v] for k, v in want.items())
+    red = _enum("SMR_RED_")
+    jr = _dict("REDOPS")
+    assert jr == {"nothing": red["NONE"], "+": red["ADD"], "Base.add_sum": red["ADD"], "*": red["MUL"], "Base.mul_prod": red["MUL"],
+                  "min": red["MIN"], "max": red["MAX"], "&": red["AND"], "|": red["OR"]}
+    ini = _enum("SMR_INIT_")
+    ji = _dict("INITOPS")
+    assert ji == {"nothing": ini["NONE"], "identity": ini["IDENTITY"], "zero": ini["ZERO"], "conj": ini["CONJ"]}
+    assert re.search(r"initcode\(s::Scale\) = \(%d," % ini["SCALE"], SRC) and re.search(r"initcode\(s::Const\) = \(%d," % ini["CONST"], SRC)
+    assert "rc == -2 && throw(Unsupported" in SRC and "SMR_EUNSUPPORTED = -2" in HDR
+
+
+def test_shim_surface_required_by_the_reference():
+    # device result of an out-of-place broadcast (src/broadcast.jl:20-22 allocates a host Array)
+    assert re.search(r"function Base\.similar\(bc::Broadcasted\{StridedArrayStyle\{N\}\}, ::Type\{T\}\)", SRC)
+    # StridedView(parent::DenseArray) needs strides / elsize / pointer of the parent
+    for sig in ("Base.strides(b::HipBuffer)", "Base.elsize(::Type{<:HipBuffer{T}})", "Base.pointer(b::HipBuffer)", "Base.size(b::HipBuffer)"):
+        assert sig in SRC, sig
+    # host <-> device copies used by upload/download and by the CPU-fallback branch
+    assert "function Base.copyto!(dst::HipBuffer{T,N}, src::Array{T,N})" in SRC and "function Base.copyto!(dst::Array{T,N}, src::HipBuffer{T,N})" in SRC
+    assert "copyto!(arrays[1].parent, host[1].parent)" in SRC
+    # a5: the reference's BroadcastStyle rules stay untouched (Strided o plain Array -> Base's broadcast)
+    assert "BroadcastStyle(" not in SRC.replace("# algebra, `promoteshape`, argument checks, the `@strided` macro AND the BroadcastStyle rules", "")
+    # every ccall names a function the header declares
+    for fn in set(re.findall(r"ccall\(\(:(\w+), lib\)", SRC)):
+        assert re.search(r"\b" + fn + r"\(", HDR), fn
+    assert len(SRC.splitlines()) <= 230
