@@ -26,6 +26,7 @@ constexpr int MAXN = SMR_MAXN;
 constexpr int MAXM = SMR_MAXM;
 constexpr int MAXIN = SMR_MAXM - 1;
 constexpr int STACK = 8;  // device evaluator stack depth (register-rotated)
+constexpr int MAXG = 4;   // FAM_ORBIT: largest permutation group handled (slots of LDS per workgroup)
 
 #ifndef SMR_JIT
 int set_error(int code, const std::string& msg);  // returns code
@@ -139,7 +140,6 @@ struct TilePlan {
 // the identity view's strides permuted by pi_k; G = <pi_k> (|G| <= MAXG).  A workgroup owns the G-orbit of
 // one tile (tile extents are equal along every cycle of G, so G permutes tiles): slot a holds the buffer
 // on tile g_a . t, the outputs of that tile read input k from slot (pi_k o g_a).
-constexpr int MAXG = 4;
 struct OrbitPlan {
     int ng = 0;               // |G|
     int k0 = 1;               // identity view: the input whose strides equal the destination's

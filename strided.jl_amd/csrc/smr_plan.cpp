@@ -601,6 +601,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
         if (n0 & (((i64)1 << l) - 1)) continue;
         if ((size_t)o.ng * ((size_t)es << (l * nu)) > (size_t)128 * 1024) continue;
         if (((i64)es << l) < 32 || l < vlog) continue;  // runs of at least 32 bytes
+        if (l * nu < 8) continue;                        // at least 256 elements per tile (128 lanes x 16 B)
         if (opt.orbit_lg >= 0) {
             if (l == opt.orbit_lg) best = l;
             continue;
@@ -611,7 +612,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
         if (tiles / o.ng >= opt.orbit_min) break;
         // a handful of big workgroups loses against the classic kernel's many small ones (measured: 24^4 f32,
         // 20 orbits of 8^4: 3.96 vs 3.38 us)
-        if (l == 1 || (((i64)es << (l - 1)) < 32) || l - 1 < vlog)
+        if (l == 1 || (((i64)es << (l - 1)) < 32) || l - 1 < vlog || (l - 1) * nu < 8)
             if (tiles / o.ng < opt.orbit_few) best = -1;
     }
     if (best < 0) return false;

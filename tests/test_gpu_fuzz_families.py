@@ -1,0 +1,212 @@
+"""Randomised parity aimed at the FAST kernel families: the generic fuzz of
+tests/test_gpu_fuzz.py draws small boxes and almost always lands in GENERIC / small STREAM.  Here every
+recipe is built to select one family -- STREAM (flat and strided rows), TILED (1024- and 4096-element tiles,
+ragged tiles, reversed dims = wide offsets, persistent form, orbit-major order), ORBIT, GENERIC, REDUCE_ALL,
+REDUCE_PART (ROW / COL / general, split reductions) -- at sizes of 10^5..2*10^6 elements, four element types
+(Float32, Float64, ComplexF32, ComplexF64), NaN-carrying min / max.  HIP path vs the CPU oracle on identical
+inputs; + - * / maps bit for bit, the rest within the reference's tolerance.  The families actually hit are
+counted from smr_plan_describe and printed (>= 200 problems per family)."""
+import collections
+import sys
+
+import numpy as np
+import pytest
+
+import oraclelib
+import strided_jl_amd as S
+from test_gpu_fuzz import EXPRS, _random_view, dview
+from util import fview, rtol
+
+pytestmark = pytest.mark.gpu
+fn = S.fn
+TYPES = [np.float32, np.float64, np.complex64, np.complex128]
+COUNTS = collections.Counter()
+
+
+def _data(rng, T):
+    def data(shape):
+        x = rng.random(shape) + 0.25
+        if np.issubdtype(np.dtype(T), np.complexfloating):
+            x = x + 1j * (rng.random(shape) - 0.5)
+        return np.asfortranarray(x.astype(T))
+    return data
+
+
+def _perm_view(rng, mk, data, dims, reverse=False):
+    """dense parent with a random dim permutation (unit stride lands on a random dim); optionally reversed dims"""
+    N = len(dims)
+    perm = [int(q) for q in rng.permutation(N)]
+    pshape = [0] * N
+    for i in range(N):
+        pshape[perm[i]] = dims[i]
+    V = mk(data(tuple(pshape))).permutedims(tuple(perm))
+    if reverse:
+        idx = [slice(None, None, -1) if rng.integers(0, 2) else slice(None) for _ in range(N)]
+        V = V.sview(*idx)
+    assert V.size == tuple(dims)
+    return V
+
+
+def recipe(name, seed, T):
+    rng0 = np.random.default_rng(seed)
+    f, nin, exact = EXPRS[int(rng0.integers(0, len(EXPRS)))]
+    op = initop = None
+    reduce_dims = ()
+    opts = {}
+    nan = False
+    pick = lambda xs: xs[int(rng0.integers(0, len(xs)))]  # noqa: E731
+    coin = [int(c) for c in rng0.integers(0, 6, size=8)]  # per-input decisions, drawn ONCE (run() is called for both backends)
+    if name == "stream":
+        dims = pick([(4096, 37), (100, 70, 9), (24, 50, 40), (250000,), (512, 16, 16)])
+        mkview = lambda rng, mk, data, k: mk(data(dims)) if k != 1 or coin[k] % 3 else _random_view(rng, mk, data, list(dims))  # noqa: E731
+    elif name == "stream_strided":
+        dims = pick([(300, 41, 5), (64, 900), (1000, 33)])
+        mkview = lambda rng, mk, data, k: _random_view(rng, mk, data, list(dims))  # noqa: E731
+    elif name in ("tiled", "tiled_reversed", "tiled_persistent"):
+        dims = pick([(512, 384), (1000, 700), (96, 40, 64), (33, 65, 130), (64, 16, 48, 20), (200, 200, 9)])
+        rev = name == "tiled_reversed"
+        if name == "tiled_persistent":
+            opts = {"tiled_persist_min": 1}
+        mkview = lambda rng, mk, data, k: _perm_view(rng, mk, data, dims, rev)  # noqa: E731
+    elif name == "tiled_big":
+        f, nin, exact = EXPRS[4] if rng0.integers(0, 2) else EXPRS[3]
+        dims = pick([(32, 32, 32, 32), (64, 16, 32, 40), (48, 48, 24, 24)])
+        mkview = None  # distinct arrays, cyclically permuted: three or more unit axes
+    elif name in ("orbit", "aliased_classic"):
+        dims = pick([(256, 256), (1024, 1024), (96, 96, 24), (32, 32, 32, 32), (16, 16, 16, 16), (64, 8, 64, 8)])
+        f, nin, exact = pick([EXPRS[1], EXPRS[2], EXPRS[4], EXPRS[7]])
+        if len(dims) == 4 and len(set(dims)) == 1:
+            f, nin, exact = EXPRS[4]  # all four cyclic views (two of them alone fuse into a plain 2-d transpose)
+        if name == "aliased_classic":
+            opts = {"orbit": 0}
+        mkview = None
+    elif name == "generic":
+        dims = pick([(7, 9, 5, 3), (13, 3, 11), (5, 6, 7, 2), (3, 3, 3, 3, 3), (9, 11, 7), (2, 3, 2, 3, 2, 3)])
+        mkview = lambda rng, mk, data, k: _random_view(rng, mk, data, list(dims))  # noqa: E731
+    elif name == "reduce_all":
+        dims = pick([(500, 300, 7), (1 << 20,), (128, 128, 64), (90, 41, 33, 4)])
+        reduce_dims = tuple(range(len(dims)))
+        mkview = lambda rng, mk, data, k: _perm_view(rng, mk, data, dims) if coin[k] % 2 else mk(data(dims))  # noqa: E731
+    else:  # reduce_part
+        dims = pick([(2048, 600), (600, 2048), (64, 300, 50), (40, 3, 5000), (300, 40, 40, 4)])
+        k = int(rng0.integers(1, len(dims)))
+        reduce_dims = tuple(sorted(rng0.choice(len(dims), size=k, replace=False).tolist()))
+        mkview = lambda rng, mk, data, k: _perm_view(rng, mk, data, dims) if coin[k] % 3 == 0 else mk(data(dims))  # noqa: E731
+    cplx = np.issubdtype(np.dtype(T), np.complexfloating)
+    if reduce_dims:
+        op = ["+", "+", "max", "min"][int(rng0.integers(0, 2 if cplx else 4))]
+        initop = [None, "identity", "zero", ("scale", 0.5), ("const", 2.0)][int(rng0.integers(0, 5))]
+        exact = False
+        nan = op in ("max", "min") and rng0.integers(0, 4) == 0
+    vseed = int(rng0.integers(0, 2 ** 31))
+    N = len(dims)
+
+    def run(mk, describe=None):
+        rng = np.random.default_rng(vseed)
+        data = _data(rng, T)
+        if name == "tiled_big":
+            ins = [mk(data(dims)).permutedims(tuple((d + k) % N for d in range(N))) if len(set(dims)) == 1
+                   else _perm_view(rng, mk, data, dims) for k in range(nin)]
+        elif name in ("orbit", "aliased_classic"):
+            base = mk(data(dims))
+            group = [tuple(range(N))]
+            if N == 2:
+                group.append((1, 0))
+            elif N == 3:
+                group.append((1, 0, 2))
+            elif len(set(dims)) == 1:
+                group += [tuple((d + k) % 4 for d in range(4)) for k in (1, 2, 3)]
+            else:
+                group += [(2, 1, 0, 3), (0, 3, 2, 1), (2, 3, 0, 1)]
+            ins = [base.permutedims(group[k % len(group)]) for k in range(nin)]
+        else:
+            ins = [mkview(rng, mk, data, k) for k in range(nin)]
+        if nan:
+            x = ins[0].parent  # same linear position in the column-major host array and in the flat device tensor
+            flat = x.reshape(-1, order="A") if isinstance(x, np.ndarray) else x.reshape(-1)
+            flat[int(vseed % max(1, int(np.prod(dims)) // 2))] = np.nan
+        odims = [1 if i in reduce_dims else dims[i] for i in range(N)]
+        out = mk(data(tuple(odims))) if name != "stream_strided" else _random_view(rng, mk, data, odims)
+        mod = sys.modules["strided_jl_amd.mapreduce"]
+        if describe is not None:
+            arrs = S.promoteshape(tuple(dims), out, *ins)
+            describe.append(S.make_plan(f, op, _initop_fn(initop), tuple(dims), arrs).describe())
+        if op is None:
+            mod._mapreduce_fuse_(f, None, None, tuple(dims), S.promoteshape(tuple(dims), out, *ins))
+        else:
+            S._mapreducedim_(f, op, initop, tuple(dims), (out, *ins))
+        return out.toarray()
+
+    return run, exact, opts, dict(recipe=name, dims=dims, nin=nin, reduce=reduce_dims, op=op, initop=initop, nan=nan)
+
+
+def _initop_fn(i):
+    if isinstance(i, tuple):
+        return (lambda x: x * i[1]) if i[0] == "scale" else (lambda x: i[1])
+    return i
+
+
+RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_big", "orbit", "aliased_classic", "generic",
+           "reduce_all", "reduce_part"]
+
+
+@pytest.mark.parametrize("name", RECIPES)
+def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
+    import torch
+
+    def funnel(f, op, initop, dims, arrays):
+        p, keep = S.build_problem(f, op, initop, dims, arrays, stream=0)
+        oraclelib.mapreduce(p, 4)
+        return arrays[0]
+
+    n = {"tiled_big": 40, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40}.get(name, 60)
+    fam = collections.Counter()
+    for i in range(n):
+        for T in TYPES:
+            seed = 7919 * RECIPES.index(name) + i
+            run, exact, opts, info = recipe(name, seed, T)
+            with monkeypatch.context() as m:
+                m.setattr(sys.modules["strided_jl_amd.mapreduce"], "_mapreduce_fuse_", funnel)
+                want = run(fview)
+            for k, v in opts.items():
+                S.set_option(k, v)
+            try:
+                desc = []
+                got = run(dview, desc)
+                torch.cuda.synchronize()
+            finally:
+                for k in opts:
+                    S.set_option(k, {"tiled_persist_min": 32, "orbit": 1}[k])
+            d = desc[0]
+            key = d[d.find("family=") + 7:d.find(" ct=")]
+            if key == "reduce_part":
+                key += ":" + d[d.find("form=") + 5:].split()[0]
+            if key == "tiled":
+                key += ":4096" if "threads=1024" in d else ":1024"
+                key += "+orbit-order" if "order=orbits" in d else ""
+            fam[key] += 1
+            msg = f"seed {seed} {np.dtype(T).name} {info} | {d}"
+            assert got.shape == want.shape, msg
+            if exact and not np.issubdtype(np.dtype(T), np.complexfloating):
+                assert np.array_equal(got, want), msg
+            else:
+                g, w = got.astype(np.complex128).ravel(), want.astype(np.complex128).ravel()
+                assert np.array_equal(np.isnan(g), np.isnan(w)), msg
+                g, w = np.nan_to_num(g), np.nan_to_num(w)
+                nred = int(np.prod([info["dims"][j] for j in info["reduce"]])) if info["reduce"] else 1
+                tol = rtol(T) + nred * float(np.finfo(np.dtype(T)).eps) / 8  # the oracle accumulates serially like the reference
+                assert np.linalg.norm(g - w) <= tol * max(np.linalg.norm(g), np.linalg.norm(w), 1e-300), msg
+    COUNTS.update(fam)
+    print(f"[fuzz families] {name}: " + ", ".join(f"{k} x{v}" for k, v in sorted(fam.items())))
+
+
+def test_every_family_was_hit_often_enough():
+    """runs after the recipes (file order): >= 200 problems per kernel family"""
+    print("[fuzz families] total: " + ", ".join(f"{k} x{v}" for k, v in sorted(COUNTS.items())))
+    if not COUNTS:
+        pytest.skip("recipes did not run in this session")
+    by_family = collections.Counter()
+    for k, v in COUNTS.items():
+        by_family[k.split(":")[0]] += v
+    for famname in ("stream", "tiled", "orbit", "generic", "reduce_all", "reduce_part"):
+        assert by_family[famname] >= 200, (famname, dict(by_family))

@@ -32,6 +32,11 @@ def test_generated_functor_mirrors_the_f_program():
     assert "truthy(v2) ? v3 : v4" in plan.jit_source()
 
 
+def _orbit_views(shape, dtype, perms):
+    a = _v(shape, dtype)  # ONE buffer, permuted views: the ORBIT family
+    return (a.similar(),) + tuple(a.permutedims(q) for q in perms)
+
+
 CASES = {
     "stream_f64": lambda: (lambda a, c: a * 2 + c / 3 - 1, None, (_v((256, 256)), _v((256, 256)), _v((256, 256)))),
     "stream_c32": lambda: (lambda a, c: fn.conj(a) * c - 1j, None,
@@ -41,6 +46,8 @@ CASES = {
     "tiled_big_f64": lambda: (lambda a, b, c, d: a * b - c * d, None,
                               (_v((32,) * 4),) + tuple(_v((32,) * 4).permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)])),
     "tiled_ragged_c64": lambda: (lambda a: fn.exp(a) * 2, None, (_v((100, 70), np.complex128), _v((70, 100), np.complex128).permutedims((1, 0)))),
+    "orbit_f64": lambda: (lambda a, b, c, d: a * b - c * d, None, _orbit_views((32,) * 4, np.float64, [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)])),
+    "orbit_c32": lambda: (lambda a, b: fn.conj(a) * b - np.complex64(1j), None, _orbit_views((256, 256), np.complex64, [(0, 1), (1, 0)])),
     "generic_f64": lambda: (lambda a: fn.sqrt(fn.abs(a)), None, (_v((7, 9, 5)), _v((5, 9, 7)).permutedims((2, 1, 0)))),
     "reduce_all_f32": lambda: (lambda a: fn.sin(a) * a, "+", None),
     "reduce_part_f64": lambda: (fn.sin, "+", None),
