@@ -734,6 +734,13 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     // least one big tile per CU).
     int tl_cap = 10;
     if (o.tile_log2 == 12) tl_cap = 12;
+    // true-HBM sized transposes (two unit axes, >= 2 GiB moved): 64 x 64 tiles on 1024 lanes = 512-byte runs on both
+    // sides.  Measured (tools/perm_tiles.py): permutedims! 128^4 f64 942 -> 846 us (4.56 -> 5.07 TB/s), transposes
+    // 8192^2 / 16384^2 unchanged within noise; below that size the 32 x 32 tiles win (more workgroups in flight)
+    else if (o.tile_log2 == 0 && na == 2 && nst == 1 && es >= 8 && (long double)c.total * es * 2 >= 2147483648.0L) {  // (f32: 493 vs 450 us, worse)
+        tl_cap = 12;
+        runbytes = 64 * es;
+    }
     else if (o.tile_log2 == 0 && na >= 3 && (size_t)nst * 4096 * es <= (size_t)128 * 1024 && c.total >= (i64)4096 * 256) {
         bool fits = true;  // every axis must be able to reach its share of the 12 bits
         int bits = 0;
