@@ -149,3 +149,67 @@ def test_transposes_beyond_4_gib_use_64_bit_tile_arithmetic():
         torch.cuda.synchronize()
         assert torch.equal(back, t)
         del t, out, back, want
+
+
+def test_c4_full_size_4_gib_abs2_sum_f32():
+    """configs[3] at its full single-array size (4096 x 4096 x 64 Float32 = 4 GiB) on one GPU: rtol 1e-6 against
+    the float64 truth (full size was only exercised inside bench.py), and the block-partitioned
+    form -- 8 slab-local sub-problems as smr_shard_ex hands them to 8 ranks -- adds up to the same value."""
+    import torch
+    from strided_jl_amd import distributed as D
+    shape = (4096, 4096, 64)
+    tA = torch.rand(int(np.prod(shape)), device="cuda", dtype=torch.float32) * 2 - 1
+    V = cm(tA, shape)
+    total = S.mapreduce(fn.abs2, "+", V)
+    truth = 0.0
+    for k in range(8):  # float64 truth slab by slab (a full float64 copy would be 8 GiB)
+        truth += float((tA[k * 2 ** 27:(k + 1) * 2 ** 27].double() ** 2).sum().item())
+    assert abs(total - truth) <= 1e-6 * truth
+    acc = 0.0
+    for r in range(8):
+        slab = tA[r * 2 ** 27:(r + 1) * 2 ** 27]                  # this "rank" holds only its 512 MiB
+        out = torch.zeros(1, device="cuda", dtype=torch.float32)
+        O = S.StridedView(out, shape, (0, 0, 0), 0)
+        A = S.StridedView(slab, shape, (1, 4096, 4096 * 4096), 0)   # logical box, slab memory
+        sdims, sarr, need, sinit = D.shard(fn.abs2, "+", None, shape, (O, A), 8, r, local=(False, True))
+        assert need and sdims == (4096, 4096, 8)
+        S._mapreduce_fuse_(fn.abs2, "+", sinit, sdims, sarr)
+        torch.cuda.synchronize()
+        acc += float(out.item())
+    assert abs(acc - truth) <= 1e-6 * truth
+
+
+def test_orbit_family_at_64_4_and_128_4_properties():
+    """The ORBIT kernel beyond what NumPy checks in seconds: the 4-way permuted sum of an INTEGER-valued array is
+    exact in Float64, invariant under the cyclic permutation of its own indices (B[r i] uses the same four
+    values; with integers every association gives the same sum), and equal to the classic tiled kernel's result."""
+    import torch
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    for n in (64, 128):
+        tA = torch.randint(-1000, 1000, (n ** 4,), device="cuda", dtype=torch.int32).to(torch.float64)
+        tB = torch.empty_like(tA)
+        tC = torch.empty_like(tA)
+        A, B, C = cm(tA, (n,) * 4), cm(tB, (n,) * 4), cm(tC, (n,) * 4)
+        plan = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (B,) + tuple(A.permutedims(q) for q in perms))
+        assert "family=orbit" in plan.describe()
+        plan.execute(int(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        b4 = tB.reshape((n,) * 4)
+        assert torch.equal(b4, b4.permute(3, 0, 1, 2).contiguous())      # invariant under the rotation
+        assert float(tB.sum().item()) == 4 * float(tA.sum().item())    # exact checksum
+        S.set_option("orbit", 0)
+        try:
+            plan2 = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (C,) + tuple(A.permutedims(q) for q in perms))
+            assert "family=tiled" in plan2.describe()
+            plan2.execute(int(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+        finally:
+            S.set_option("orbit", 1)
+        assert torch.equal(tB, tC)
+        # in place: A .= sum of its four rotations (an orbit is read completely before it is written)
+        plan3 = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (A,) + tuple(A.permutedims(q) for q in perms))
+        if "family=orbit" in plan3.describe():
+            plan3.execute(int(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            assert torch.equal(tA, tB)
+        del tA, tB, tC
