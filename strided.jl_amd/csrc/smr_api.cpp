@@ -485,7 +485,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_col_txlog") o.reduce_col_txlog = value;
     else if (n == "reduce_part_wgs") o.reduce_part_wgs = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
-    else if (n == "nt_store_max") o.nt_store_max = value;
+    else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "orbit_min") o.orbit_min = value;
     else if (n == "orbit_few") o.orbit_few = value;
@@ -526,7 +526,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "jit_failures") return jit_stats().failures;
     if (n == "jit_compile_ms") return (int64_t)jit_stats().compile_ms;
     if (n == "tiled_vec") return o.tiled_vec;
-    if (n == "nt_store_max") return o.nt_store_max;
+    if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
     if (n == "orbit_min") return o.orbit_min;
     if (n == "orbit_few") return o.orbit_few;

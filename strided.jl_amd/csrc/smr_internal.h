@@ -207,9 +207,10 @@ struct Options {
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
     i64 orbit_min = 150;     // pick the largest tile edge that still yields this many orbits (measured: tools/orbit_sweep.py)
     i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
-    i64 nt_store = 0;        // non-temporal stores: -1 = when the destination is at most nt_store_max bytes, 0 never, 1 always
-                             // (measured on MI355X: no gain on the library's kernels at any size -> off)
-    i64 nt_store_max = (i64)32 << 20;
+    i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes and
+                             // TILED tiles that write whole 128-byte lines (profiles/r02_nt_store_ab.txt: configs[4]
+                             // 91.8 -> 80.2 us, 32^4 permutedims! 3.36 -> 2.76 us); ORBIT's 32-byte runs get slower (4.8 -> 6.3 us)
+    i64 nt_stream_min = 0;
     i64 max_lds_bytes = 65536;
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override
 };

@@ -71,25 +71,6 @@ SMR_DEV c64 ocj(c64 x, uint32_t bit) {
     return c64{x.re, __longlong_as_double(__double_as_longlong(x.im) ^ ((long long)bit << 32))};
 }
 
-template <class VT>
-SMR_DEV void ostore(char* p, const VT& v, bool nts) {
-    if (nts) {
-        if constexpr (sizeof(VT) == 16) {
-            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(p));
-            return;
-        } else if constexpr (sizeof(VT) == 8) {
-            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-            __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(p));
-            return;
-        } else if constexpr (sizeof(VT) == 4) {
-            __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(p));
-            return;
-        }
-    }
-    *reinterpret_cast<VT*>(p) = v;
-}
-
 // NG = |G| (2 or 4; a group of order 3 is padded with a copy of slot 0), OWN0: view 0 is the identity view
 // (its value is the lane's own register).  Apart from the rare > 4 grid dims there is no branch on a
 // kernel argument before the stores: every scalar branch on a just-loaded argument is a serial
@@ -258,7 +239,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < NREP; ++r) ostore<VT>(a.dst + org[g] + goff[r], x[g][r], nts);
+        for (int r = 0; r < NREP; ++r) store_vec<VT>(a.dst + org[g] + goff[r], x[g][r], nts);
 }
 
 #ifndef SMR_JIT
@@ -436,7 +417,9 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     a.src = (const char*)tab.base[o.k0];
     a.dst = (char*)tab.base[0];
     const Options& opt = options();
-    a.nts = (opt.nt_store > 0 || (opt.nt_store < 0 && c.nout * (i64)sizeof(T) <= opt.nt_store_max)) ? 1 : 0;
+    // automatic: only tiles that write whole 128-byte lines (symmetrise 4000^2: 40.2 -> 38.5 us); the 32-/64-byte
+    // runs of the 4-D orbits rely on line partners meeting in L2 and get slower (4.8 -> 6.3 us at 32^4)
+    a.nts = (opt.nt_store > 0 || (opt.nt_store < 0 && plan.c.strides[0][0] == 1 && (sizeof(T) << o.lg[0]) >= 128)) ? 1 : 0;
     const unsigned grid = (unsigned)o.list.size();
     const unsigned block = 1u << a.ntlog;
     const size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);

@@ -16,7 +16,7 @@ struct StreamArgs {
     i64 n0v;   // vectors along dim 0
     i64 rows;  // product of the outer dims
     i64 bpr;   // workgroups per row
-    int32_t txlog, pad_;  // 8: a workgroup covers U x 256 vectors of ONE row; < 8 (short rows): 2^txlog lanes
+    int32_t txlog, nts;   // nts: non-temporal stores (big streaming outputs, Options::nt_store); txlog 8: a workgroup covers U x 256 vectors of ONE row; < 8 (short rows): 2^txlog lanes
                           // along dim 0 x (256 >> txlog) x U entries of dim 1 -- then `rows` counts dims >= 2
     i64 dims[MAXN];
     i64 strides[MAXM][MAXN];
@@ -120,7 +120,7 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
                         for (int e = 0; e < V; ++e) out.v[e] = cj(out.v[e]);
                     }
                 }
-                *reinterpret_cast<VT*>((T*)a.ops.base[0] + joff[u][0] + col[u] * V) = out;
+                store_vec<VT>(reinterpret_cast<char*>((T*)a.ops.base[0] + joff[u][0] + col[u] * V), out, a.nts);
             }
         }
     }
@@ -147,6 +147,13 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.N = c.N;
     a.M = c.M;
     a.n0v = c.dims[0] / V;
+    {
+        // Streaming outputs of at least half the Infinity Cache (256 MiB) bypass it: caching them would only evict the
+        // inputs.  Measured on configs[4] (8192^2 f32, 256 MiB in / out, tools/c5_proto.hip): 91 -> 74 us.
+        const Options& o = options();
+        const i64 outbytes = c.nout * (i64)c.esize[0];
+        a.nts = (o.nt_store > 0 || (o.nt_store < 0 && outbytes >= o.nt_stream_min)) ? 1 : 0;
+    }
     // short rows (sub-boxes): pack (256 >> txlog) entries of dim 1 into a workgroup instead of leaving
     // most of its lanes idle (measured on 100-element rows: 0.93 -> TB/s below)
     a.txlog = 8;
