@@ -40,31 +40,35 @@ template <> struct tr<b8> { typedef float real; static constexpr bool cx = false
 template <> struct tr<b16> { typedef float real; static constexpr bool cx = false; static constexpr bool arith = false; static constexpr int dt = SMR_U16; };
 
 // ---- construction / parts ----------------------------------------------------------------
-// 16-/8-/4-byte vector store, optionally non-temporal (wave-uniform switch).  The asm lines are not
-// decoration: without them the optimiser hoists/sinks the two stores of the if/else into one and drops `nt`.
+// 16-/8-/4-byte vector store, plain or non-temporal.  A run-time switch between the two must not be written
+// as if (nts) store_nt else store: the optimiser hoists/sinks the pair into ONE store and drops `nt`
+// (seen in the ISA).  store_vec() keeps them apart with asm statements; loops over several stores
+// branch once and bracket the non-temporal block with nt_block_guard().
+template <bool NT, class VT>
+SMR_DEV void store_vec_ct(char* p, const VT& v) {
+    if constexpr (NT && sizeof(VT) == 16) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(p));
+    } else if constexpr (NT && sizeof(VT) == 8) {
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(p));
+    } else if constexpr (NT && sizeof(VT) == 4) {
+        __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(p));
+    } else {
+        *reinterpret_cast<VT*>(p) = v;
+    }
+}
+SMR_DEV void nt_block_guard() { asm volatile("; nt stores" ::: "memory"); }
+
 template <class VT>
 SMR_DEV void store_vec(char* p, const VT& v, int nts) {
     if (nts) {
-        if constexpr (sizeof(VT) == 16) {
-            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            asm volatile("; nt store" ::: "memory");
-            __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(p));
-            asm volatile("; nt store" ::: "memory");
-            return;
-        } else if constexpr (sizeof(VT) == 8) {
-            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-            asm volatile("; nt store" ::: "memory");
-            __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(p));
-            asm volatile("; nt store" ::: "memory");
-            return;
-        } else if constexpr (sizeof(VT) == 4) {
-            asm volatile("; nt store" ::: "memory");
-            __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(p));
-            asm volatile("; nt store" ::: "memory");
-            return;
-        }
+        nt_block_guard();
+        store_vec_ct<true>(p, v);
+        nt_block_guard();
+    } else {
+        store_vec_ct<false>(p, v);
     }
-    *reinterpret_cast<VT*>(p) = v;
 }
 
 template <class T> SMR_DEV T mk(typename tr<T>::real re, typename tr<T>::real im);

@@ -48,7 +48,7 @@ struct OrbitArgs {
     char* dst;
     const uint32_t* list;  // per workgroup: the NG slot origins (element offsets; [0] = 0xffffffff: idle)
     const uint32_t* lanetab;  // [(r * NT + tid) * rowlen]: byte offset, then the LDS read index of every non-own view
-    int32_t nin, tilelog, ntlog, conj0, nts, pad0;
+    int32_t nin, tilelog, ntlog, conj0, nts, nlist;  // nlist: rows of `list` (PIPE form)
     uint32_t swz_s1, swz_s2, swz_mask, pad1;
     // element enumeration inside a tile (natural order of the buffer); unused tiled dims have elen = 0
     int32_t esh[OMAXT], elen[OMAXT];
@@ -75,7 +75,10 @@ SMR_DEV c64 ocj(c64 x, uint32_t bit) {
 // (its value is the lane's own register).  Apart from the rare > 4 grid dims there is no branch on a
 // kernel argument before the stores: every scalar branch on a just-loaded argument is a serial
 // scalar-cache round trip, and at 32^4 the whole launch lasts 4-5 us.
-template <class T, class F, int V, int NREP, int NG, bool OWN0>
+// PIPE: persistent form for orbits whose LDS footprint leaves one workgroup per CU -- the workgroup walks the
+// list with stride gridDim.x (a multiple of 8: it stays on its XCD's run) and issues the loads of its next orbit
+// right after the barrier, so that they fly during the exchange and the stores of the current one.
+template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE = false>
 SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     typedef OVec<T, V> VT;
     constexpr int NIN_STATIC = F::NIN;
@@ -88,18 +91,19 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     // ---- slot origins: one wide scalar load of this workgroup's table row -----------------------------
     i64 org[NG];
     bool live;
-    {
+    auto load_row = [&](uint32_t b, i64(&og)[NG], bool& lv) {
         typedef uint32_t rowv __attribute__((ext_vector_type(NG)));
-        const rowv row = reinterpret_cast<const rowv*>(a.list)[blockIdx.x];
+        const rowv row = reinterpret_cast<const rowv*>(a.list)[b];
         uint32_t o32[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) o32[g] = row[g];
         // a padding workgroup (first word 0xffffffff) runs on slot origins 0 and only skips its stores: an early
         // exit here would keep every other kernel-argument load behind this row's round trip
-        live = o32[0] != 0xffffffffu;
+        lv = o32[0] != 0xffffffffu;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) org[g] = live ? (i64)o32[g] * (i64)sizeof(T) : 0;
-    }
+        for (int g = 0; g < NG; ++g) og[g] = lv ? (i64)o32[g] * (i64)sizeof(T) : 0;
+    };
+    load_row(blockIdx.x, org, live);
 
     // ---- per-lane byte offsets inside a tile + LDS read indices -----------------------------------------
     constexpr int NLR = NK - (OWN0 ? 1 : 0);      // views read from LDS
@@ -179,73 +183,135 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     asm volatile("" : "+s"(conj0), "+s"(nts_flag));
     auto swz = [&](uint32_t i) { return i ^ (((i >> swz_s1) ^ (i >> swz_s2)) & swz_mask); };
 
+    uint32_t wg = blockIdx.x, tidp = tid;
+    for (;;) {
+    if constexpr (PIPE) {
+        // loop-invariant LDS addresses (one per view x repeat x slot) would be hoisted and spill: recompute them
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(lr[k][r]));
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(goff[r]));
+        asm volatile("" : "+v"(tidp));
+    }
     // ---- park the slots in LDS ---------------------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         T* L = lds + ((size_t)g << a.tilelog);
 #pragma unroll
         for (int r = 0; r < NREP; ++r) {
-            const uint32_t e = (((uint32_t)r << a.ntlog) | tid) * V;
+            const uint32_t e = (((uint32_t)r << a.ntlog) | tidp) * V;
 #pragma unroll
             for (int h = 0; h < V; ++h) L[swz(e + h)] = x[g][r].v[h];
         }
     }
     __syncthreads();
-
-    // ---- outputs of every slot: all LDS reads of a repeat are issued before the first use ----------------
+    i64 norg[NG];
+    bool nlive = false, more = false;
+    VT xn[NG][NREP];
+    if constexpr (PIPE) {
+        wg += gridDim.x;
+        more = wg < (uint32_t)a.nlist;
+        if (more) {
+            load_row(wg, norg, nlive);
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        T val[NG][V][NK];
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int h = 0; h < V; ++h)
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    if (OWN0 && k == 0) {
-                        val[g][h][k] = x[g][r].v[h];
-                    } else {
-                        // sub-element h moves along tiled dim 0 of the natural order
-                        const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
-                        val[g][h][k] = lds[sbase[g][k] + swz(idx)];
-                    }
-                }
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads together: one LDS latency per repeat, not one per output
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            VT out;
-#pragma unroll
-            for (int h = 0; h < V; ++h) {
-                T arg[MAXIN];
-#pragma unroll
-                for (int k = 0; k < MAXIN; ++k) {
-                    arg[k] = T{};
-                    if (k < NK) {
-                        T v = val[g][h][k < NK ? k : 0];
-                        if constexpr (tr<T>::cx) v = ocj(v, cbit[k < NK ? k : 0]);
-                        arg[k] = v;
-                    }
-                }
-                (void)nin;
-                T o = f(arg);
-                if constexpr (tr<T>::cx) o = ocj(o, conj0);
-                out.v[h] = o;
-            }
-            x[g][r] = out;
+                for (int r = 0; r < NREP; ++r) xn[g][r] = *reinterpret_cast<const VT*>(a.src + norg[g] + goff[r]);
         }
     }
-    if (!live) return;
+
+    // ---- outputs of every slot: all LDS reads of a repeat are issued before the first use ----------------
+    // (the one-shot form batches the reads of all slots: one LDS latency per repeat; the persistent form has the
+    // next orbit's loads in registers as well and batches per slot)
+    constexpr int GB = PIPE ? 1 : NG;
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += GB) {
+            T val[GB][V][NK];
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi)
+#pragma unroll
+                for (int h = 0; h < V; ++h)
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const int g = g0 + gi;
+                        if (OWN0 && k == 0) {
+                            val[gi][h][k] = x[g][r].v[h];
+                        } else {
+                            // sub-element h moves along tiled dim 0 of the natural order
+                            const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
+                            val[gi][h][k] = lds[sbase[g][k] + swz(idx)];
+                        }
+                    }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads together: one LDS latency per batch, not one per output
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi) {
+                const int g = g0 + gi;
+                VT out;
+#pragma unroll
+                for (int h = 0; h < V; ++h) {
+                    T arg[MAXIN];
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k) {
+                        arg[k] = T{};
+                        if (k < NK) {
+                            T v = val[gi][h][k < NK ? k : 0];
+                            if constexpr (tr<T>::cx) v = ocj(v, cbit[k < NK ? k : 0]);
+                            arg[k] = v;
+                        }
+                    }
+                    (void)nin;
+                    T o = f(arg);
+                    if constexpr (tr<T>::cx) o = ocj(o, conj0);
+                    out.v[h] = o;
+                }
+                x[g][r] = out;
+            }
+            if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);  // one slot at a time: the registers hold two orbits
+        }
+    }
+    if constexpr (!PIPE) {
+        if (!live) return;
+    }
     const bool nts = nts_flag != 0;
+    if (!PIPE || live) {
+        if (nts) {
+            nt_block_guard();
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < NREP; ++r) store_vec<VT>(a.dst + org[g] + goff[r], x[g][r], nts);
+                for (int r = 0; r < NREP; ++r) store_vec_ct<true, VT>(a.dst + org[g] + goff[r], x[g][r]);
+            nt_block_guard();
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < NREP; ++r) store_vec_ct<false, VT>(a.dst + org[g] + goff[r], x[g][r]);
+        }
+    }
+    if constexpr (!PIPE) {
+        return;
+    } else {
+        if (!more) return;
+        __syncthreads();  // every lane has read its LDS values: the slots may be overwritten
+        live = nlive;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            org[g] = norg[g];
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) x[g][r] = xn[g][r];
+        }
+    }
+    }
 }
 
 #ifndef SMR_JIT
-template <class T, class F, int V, int NREP, int NG, bool OWN0>
+template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE>
 __global__ void __launch_bounds__(1024) k_orbit_map(const OrbitArgs a, F f) {
-    orbit_map_body<T, F, V, NREP, NG, OWN0>(a, f);
+    orbit_map_body<T, F, V, NREP, NG, OWN0, PIPE>(a, f);
 }
 
 // XOR-fold swizzle l ^ (((l >> s1) ^ (l >> s2)) & mask): parameters picked per plan by counting the
@@ -310,8 +376,8 @@ static OSwz choose_orbit_swizzle(const OrbitArgs& a, int nin, bool own0, int esi
     return best;
 }
 
-template <class T, class F, int V, int NREP, int NG, bool OWN0>
-static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE>
+static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     const Canon& c = plan.c;
     const OrbitPlan& o = plan.orbit;
     OrbitArgs a;
@@ -420,16 +486,18 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     // automatic: only tiles that write whole 128-byte lines (symmetrise 4000^2: 40.2 -> 38.5 us); the 32-/64-byte
     // runs of the 4-D orbits rely on line partners meeting in L2 and get slower (4.8 -> 6.3 us at 32^4)
     a.nts = (opt.nt_store > 0 || (opt.nt_store < 0 && plan.c.strides[0][0] == 1 && (sizeof(T) << o.lg[0]) >= 128)) ? 1 : 0;
-    const unsigned grid = (unsigned)o.list.size();
     const unsigned block = 1u << a.ntlog;
     const size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);
+    a.nlist = (int32_t)o.list.size();
+    unsigned grid = (unsigned)o.list.size();
+    if (PIPE) grid = std::min<unsigned>(grid, 256u * (unsigned)std::max<size_t>(1, (160 * 1024) / lds));
     if constexpr (is_jit<F>::value) {
         JitLaunch l;
         l.family = "orbit";
         l.tname = tname<T>();
         l.argtype = "smr::OrbitArgs";
         l.entry = std::string("smr::orbit_map_body<") + tname<T>() + ", smr::FJit, " + std::to_string(V) + ", " + std::to_string(NREP) + ", " +
-                  std::to_string(NG) + ", " + (OWN0 ? "true" : "false") + ">(a, smr::FJit{kc});";
+                  std::to_string(NG) + ", " + (OWN0 ? "true" : "false") + ", " + (PIPE ? "true" : "false") + ">(a, smr::FJit{kc});";
         l.grid = grid;
         l.block = block;
         l.lds = lds;
@@ -439,7 +507,7 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        auto kern = k_orbit_map<T, F, V, NREP, NG, OWN0>;
+        auto kern = k_orbit_map<T, F, V, NREP, NG, OWN0, PIPE>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
@@ -447,6 +515,20 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a, f);
         return check_launch("k_orbit_map");
     }
+}
+
+// persistent pipelined form: when the LDS footprint leaves one workgroup per CU and every CU gets several orbits
+template <class T, class F, int V, int NREP, int NG, bool OWN0>
+static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+    const OrbitPlan& o = plan.orbit;
+    const size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);
+    const i64 want = options().orbit_pipe;
+    bool pipe = false;
+    if constexpr (V * sizeof(T) == 16) {
+        pipe = want > 0 ? o.list.size() > 256 : (want < 0 && lds > 80 * 1024 && o.list.size() >= 4 * 256);
+        if (pipe) return go4<T, F, V, NREP, NG, OWN0, true>(plan, s, f, tab);
+    }
+    return go4<T, F, V, NREP, NG, OWN0, false>(plan, s, f, tab);
 }
 
 template <class T, class F, int V, int NREP>

@@ -72,8 +72,11 @@ def recipe(name, seed, T):
         f, nin, exact = EXPRS[4] if rng0.integers(0, 2) else EXPRS[3]
         dims = pick([(32, 32, 32, 32), (64, 16, 32, 40), (48, 48, 24, 24)])
         mkview = None  # distinct arrays, cyclically permuted: three or more unit axes
-    elif name in ("orbit", "aliased_classic"):
+    elif name in ("orbit", "aliased_classic", "orbit_pipe"):
         dims = pick([(256, 256), (1024, 1024), (96, 96, 24), (32, 32, 32, 32), (16, 16, 16, 16), (64, 8, 64, 8)])
+        if name == "orbit_pipe":  # persistent pipelined form: needs more orbits than CUs
+            dims = pick([(1024, 1024), (32, 32, 32, 32), (1536, 1536), (24, 24, 24, 24)])
+            opts = {"orbit_pipe": 1}
         f, nin, exact = pick([EXPRS[1], EXPRS[2], EXPRS[4], EXPRS[7]])
         if len(dims) == 4 and len(set(dims)) == 1:
             f, nin, exact = EXPRS[4]  # all four cyclic views (two of them alone fuse into a plain 2-d transpose)
@@ -107,7 +110,7 @@ def recipe(name, seed, T):
         if name == "tiled_big":
             ins = [mk(data(dims)).permutedims(tuple((d + k) % N for d in range(N))) if len(set(dims)) == 1
                    else _perm_view(rng, mk, data, dims) for k in range(nin)]
-        elif name in ("orbit", "aliased_classic"):
+        elif name in ("orbit", "aliased_classic", "orbit_pipe"):
             base = mk(data(dims))
             group = [tuple(range(N))]
             if N == 2:
@@ -146,7 +149,7 @@ def _initop_fn(i):
     return i
 
 
-RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_big", "orbit", "aliased_classic", "generic",
+RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_big", "orbit", "orbit_pipe", "aliased_classic", "generic",
            "reduce_all", "reduce_part"]
 
 
@@ -159,7 +162,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
         oraclelib.mapreduce(p, 4)
         return arrays[0]
 
-    n = {"tiled_big": 40, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40}.get(name, 60)
+    n = {"tiled_big": 40, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30}.get(name, 60)
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:
@@ -176,7 +179,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
                 torch.cuda.synchronize()
             finally:
                 for k in opts:
-                    S.set_option(k, {"tiled_persist_min": 32, "orbit": 1}[k])
+                    S.set_option(k, {"tiled_persist_min": 32, "orbit": 1, "orbit_pipe": -1}[k])
             d = desc[0]
             key = d[d.find("family=") + 7:d.find(" ct=")]
             if key == "reduce_part":
