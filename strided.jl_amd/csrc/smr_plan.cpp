@@ -733,13 +733,17 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     // 4-way permuted sum: 32^4 8.0 vs 8.4 us, 64^4 141 vs 175 us, 128^4 3.24 vs 4.64 ms (needs at
     // least one big tile per CU).
     int tl_cap = 10;
+    bool big_transpose = false;
     if (o.tile_log2 == 12) tl_cap = 12;
-    // true-HBM sized transposes (two unit axes, >= 2 GiB moved): 64 x 64 tiles on 1024 lanes = 512-byte runs on both
-    // sides.  Measured (tools/perm_tiles.py): permutedims! 128^4 f64 942 -> 846 us (4.56 -> 5.07 TB/s), transposes
-    // 8192^2 / 16384^2 unchanged within noise; below that size the 32 x 32 tiles win (more workgroups in flight)
-    else if (o.tile_log2 == 0 && na == 2 && nst == 1 && es >= 8 && (long double)c.total * es * 2 >= 2147483648.0L) {  // (f32: 493 vs 450 us, worse)
+    // true-HBM sized transposes (two unit axes, >= 1 GiB moved, 8-/16-byte elements): 128 x 32 tiles on 1024 lanes --
+    // 1-KiB non-temporal write runs along the destination's unit axis, 256-byte read runs along the source's.
+    // Measured (tools/perm_tiles2.py, Float64): permutedims! 128^4 32x32 940, 64x64 798, 128x32 792 us; transposes
+    // 16384^2 840 / 778 / 719 us, 8192^2 270 (218 persistent) / 215 / 206 us; sizes that are not powers of two
+    // (4000^2, 12000^2) tie.  Float32 stays with 32 x 32 (128^4: 451 vs 480 / 535 us)
+    else if (o.tile_log2 == 0 && na == 2 && nst == 1 && es >= 8 && (long double)c.total * es * 2 >= 1073741824.0L) {
         tl_cap = 12;
-        runbytes = 64 * es;
+        runbytes = 32 * es;
+        big_transpose = true;
     }
     else if (o.tile_log2 == 0 && na >= 3 && (size_t)nst * 4096 * es <= (size_t)128 * 1024 && c.total >= (i64)4096 * 256) {
         bool fits = true;  // every axis must be able to reach its share of the 12 bits
@@ -773,7 +777,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
         // big tiles: give the destination axis a full 128-B line first (stores and the direct
         // inputs then move whole lines; measured on the 4-way sum at 32^4: 16x8x8x4 7.7 us,
         // 16x8x4x8 7.6 us, 8x8x8x8 8.0 us), the other axes share the rest
-        const int want0 = std::max(1, nextpow2_log(std::max<i64>(1, 128 / es)));
+        const int want0 = big_transpose ? 7 : std::max(1, nextpow2_log(std::max<i64>(1, 128 / es)));
         while (lg[0] < want0 && ((i64)1 << lg[0]) < c.dims[0] && total < tl_cap) {
             ++lg[0];
             ++total;
