@@ -487,6 +487,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
+    else if (n == "nt_load") o.nt_load = value;
     else if (n == "orbit_min") o.orbit_min = value;
     else if (n == "orbit_few") o.orbit_few = value;
     else if (n == "orbit_pipe") o.orbit_pipe = value;
@@ -529,6 +530,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "tiled_vec") return o.tiled_vec;
     if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
+    if (n == "nt_load") return o.nt_load;
     if (n == "orbit_min") return o.orbit_min;
     if (n == "orbit_few") return o.orbit_few;
     if (n == "orbit_pipe") return o.orbit_pipe;

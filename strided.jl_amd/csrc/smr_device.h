@@ -60,6 +60,24 @@ SMR_DEV void store_vec_ct(char* p, const VT& v) {
 }
 SMR_DEV void nt_block_guard() { asm volatile("; nt stores" ::: "memory"); }
 
+// vector load, plain or non-temporal by a compile-time switch (a run-time switch belongs around the whole loop:
+// a diamond per load is folded like the stores, and guarding each one keeps the loads of a batch apart)
+template <bool B>
+struct BoolC {
+    static constexpr bool value = B;
+};
+template <bool NT, class VT>
+SMR_DEV VT load_vec_ct(const void* p) {
+    if constexpr (NT && sizeof(VT) == 16) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        VT v;
+        *reinterpret_cast<u4*>(&v) = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+        return v;
+    } else {
+        return *reinterpret_cast<const VT*>(p);
+    }
+}
+
 template <class VT>
 SMR_DEV void store_vec(char* p, const VT& v, int nts) {
     if (nts) {

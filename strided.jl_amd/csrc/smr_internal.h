@@ -212,6 +212,7 @@ struct Options {
                              // TILED tiles that write whole 128-byte lines (profiles/r02_nt_store_ab.txt: configs[4]
                              // 91.8 -> 80.2 us, 32^4 permutedims! 3.36 -> 2.76 us); ORBIT's 32-byte runs get slower (4.8 -> 6.3 us)
     i64 nt_stream_min = 0;
+    i64 nt_load = -1;        // non-temporal loads in REDUCE_ALL: 0 never, 1 always, -1 = inputs below 2 GiB
     i64 max_lds_bytes = 65536;
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override
 };

@@ -31,7 +31,7 @@ struct RedArgs {
     int32_t ngroups;  // REDUCE_PART: workgroups along the output index
     i64 chunk;        // reduced elements per chunk (multiple of tr)
     // vectorised forms (ROW / COL): reduced space = inner dim NK (extent L0) x outer index q in [0, Q)
-    int32_t g0log, g1log, txlog, xsplit, qsplit, pad_;
+    int32_t g0log, g1log, txlog, xsplit, qsplit, ntl;  // ntl: non-temporal loads in REDUCE_ALL (Options::nt_load)
     i64 L0, Q, xchunk, qchunk;
     i64 nkb0;         // COL: workgroups along kept dim 0
 };
@@ -108,48 +108,58 @@ SMR_DEV void reduce_all_body(const RedArgs a, F f) {
         // (measured on 4 GiB: 6.3 TB/s, against 6.1 TB/s for grid-strided single rows)
         const i64 lane_ = threadIdx.x & 63;
         const i64 nrows = (nvec + 63) >> 6;
-        for (i64 row = (t0 >> 6) * ACC; row < nrows; row += (nthreads >> 6) * ACC) {
-            const i64 i = row * 64 + lane_;
-            VT x[ACC][MAXIN];
+        // one run-time branch around the loop selects plain or non-temporal loads (a diamond per load costs 10 %: the loads of a batch no longer issue together)
+        auto sweep = [&](auto NTL) {
+            for (i64 row = (t0 >> 6) * ACC; row < nrows; row += (nthreads >> 6) * ACC) {
+                const i64 i = row * 64 + lane_;
+                VT x[ACC][MAXIN];
 #pragma unroll
-            for (int j = 0; j < ACC; ++j) {
-                const i64 ii = i + j * 64;
-                if (ii < nvec) {
+                for (int j = 0; j < ACC; ++j) {
+                    const i64 ii = i + j * 64;
+                    if (ii < nvec) {
 #pragma unroll
-                    for (int k = 0; k < MAXIN; ++k)
-                        if (k < nin) {
-                            if (a.strides[k + 1][0] == 0) {
-                                const T s = load_op<T, false>(a.ops, k + 1, 0);
+                        for (int k = 0; k < MAXIN; ++k)
+                            if (k < nin) {
+                                if (a.strides[k + 1][0] == 0) {
+                                    const T s = load_op<T, false>(a.ops, k + 1, 0);
 #pragma unroll
-                                for (int e = 0; e < V; ++e) x[j][k].v[e] = s;
-                            } else {
-                                x[j][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + ii * V);
-                                if constexpr (tr<T>::cx) {
-                                    if (a.ops.conj[k + 1]) {
+                                    for (int e = 0; e < V; ++e) x[j][k].v[e] = s;
+                                } else {
+                                    x[j][k] = load_vec_ct<decltype(NTL)::value, VT>((const T*)a.ops.base[k + 1] + ii * V);
+                                    if constexpr (tr<T>::cx) {
+                                        if (a.ops.conj[k + 1]) {
 #pragma unroll
-                                        for (int e = 0; e < V; ++e) x[j][k].v[e] = cj(x[j][k].v[e]);
+                                            for (int e = 0; e < V; ++e) x[j][k].v[e] = cj(x[j][k].v[e]);
+                                        }
                                     }
                                 }
                             }
-                        }
+                    }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < ACC; ++j) {
-                const i64 ii = i + j * 64;
-                if (ii < nvec) {
+                for (int j = 0; j < ACC; ++j) {
+                    const i64 ii = i + j * 64;
+                    if (ii < nvec) {
 #pragma unroll
-                    for (int e = 0; e < V; ++e) {
-                        T in[MAXIN];
+                        for (int e = 0; e < V; ++e) {
+                            T in[MAXIN];
 #pragma unroll
-                        for (int k = 0; k < MAXIN; ++k) {
-                            in[k] = T{};
-                            if (k < nin) in[k] = x[j][k].v[e];
+                            for (int k = 0; k < MAXIN; ++k) {
+                                in[k] = T{};
+                                if (k < nin) in[k] = x[j][k].v[e];
+                            }
+                            acc[j] = red_apply<T>(a.redop, acc[j], f(in));
                         }
-                        acc[j] = red_apply<T>(a.redop, acc[j], f(in));
                     }
                 }
             }
+        };
+        if (a.ntl) {
+            nt_block_guard();
+            sweep(BoolC<true>{});
+            nt_block_guard();
+        } else {
+            sweep(BoolC<false>{});
         }
     } else {
         for (i64 i = t0; i < a.total; i += nthreads * ACC) {
@@ -634,6 +644,8 @@ static void fill_args(const Plan& plan, void* const* bases, RedArgs& a) {
     for (int k = 0; k < MAXM; ++k)
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
     a.partials = plan.scratch;
+    // non-temporal loads: 64 MiB 18.5 -> 16.5 us, 512 MiB 96 -> 92 us, 4 GiB 700 +- 15 us either way (tools/reduce_nt.py)
+    a.ntl = (options().nt_load > 0 || (options().nt_load < 0 && (long double)c.total * c.esize[1] < 2147483648.0L)) ? 1 : 0;
 }
 
 template <class T, class F, bool MIXED>
