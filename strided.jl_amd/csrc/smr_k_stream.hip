@@ -97,10 +97,10 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
             }
         }
     }
+    VT out[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (live[u]) {
-            VT out;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 T x[MAXIN];
@@ -109,19 +109,33 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
                     x[k] = T{};
                     if (k < nin) x[k] = in[u][k].v[e];
                 }
-                out.v[e] = f(x);
+                out[u].v[e] = f(x);
             }
             if constexpr (MIXED || V == 1) {
-                store_op<T, MIXED>(a.ops, joff[u][0] + col[u] * a.strides[0][0], out.v[0]);
+                store_op<T, MIXED>(a.ops, joff[u][0] + col[u] * a.strides[0][0], out[u].v[0]);
             } else {
                 if constexpr (tr<T>::cx) {
                     if (a.ops.conj[0]) {
 #pragma unroll
-                        for (int e = 0; e < V; ++e) out.v[e] = cj(out.v[e]);
+                        for (int e = 0; e < V; ++e) out[u].v[e] = cj(out[u].v[e]);
                     }
                 }
-                store_vec<VT>(reinterpret_cast<char*>((T*)a.ops.base[0] + joff[u][0] + col[u] * V), out, a.nts);
             }
+        }
+    }
+    if constexpr (!(MIXED || V == 1)) {
+        // one wave-uniform branch around all vector stores (see smr_device.h:store_vec)
+        auto put = [&](auto NT) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (live[u]) store_vec_ct<decltype(NT)::value, VT>(reinterpret_cast<char*>((T*)a.ops.base[0] + joff[u][0] + col[u] * V), out[u]);
+        };
+        if (a.nts) {
+            nt_block_guard();
+            put(BoolC<true>{});
+            nt_block_guard();
+        } else {
+            put(BoolC<false>{});
         }
     }
 }

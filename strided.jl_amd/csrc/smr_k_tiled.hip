@@ -337,10 +337,10 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
             }
         }
     }
+    VT out[NREP];
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
         if (okd[r]) {
-            VT out;
 #pragma unroll
             for (int h = 0; h < V; ++h) {
                 T arg[MAXIN];
@@ -349,20 +349,33 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
                     arg[i] = T{};
                     if (i < NINMAX) arg[i] = x[i < NINMAX ? i : 0][r].v[h];
                 }
-                out.v[h] = f(arg);
+                out[r].v[h] = f(arg);
             }
-            char* p = bp0 + (O)(row[0].g + a.op[0].Gr[r]);
             if constexpr (V == 1) {
-                store_at<T, MIXED>(p, a.op[0].dtype, a.op[0].conj, out.v[0]);
+                store_at<T, MIXED>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), a.op[0].dtype, a.op[0].conj, out[r].v[0]);
             } else {
                 if constexpr (tr<T>::cx) {
                     if (a.op[0].conj) {
 #pragma unroll
-                        for (int h = 0; h < V; ++h) out.v[h] = cj(out.v[h]);
+                        for (int h = 0; h < V; ++h) out[r].v[h] = cj(out[r].v[h]);
                     }
                 }
-                store_vec<VT>(p, out, a.nts);
             }
+        }
+    }
+    if constexpr (V > 1) {
+        // one wave-uniform branch around all vector stores (see smr_device.h:store_vec)
+        auto put = [&](auto NT) {
+#pragma unroll
+            for (int r = 0; r < NREP; ++r)
+                if (okd[r]) store_vec_ct<decltype(NT)::value, VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
+        };
+        if (a.nts) {
+            nt_block_guard();
+            put(BoolC<true>{});
+            nt_block_guard();
+        } else {
+            put(BoolC<false>{});
         }
     }
 }
