@@ -491,6 +491,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "orbit_min") o.orbit_min = value;
     else if (n == "orbit_few") o.orbit_few = value;
     else if (n == "orbit_pipe") o.orbit_pipe = value;
+    else if (n == "orbit_lds_min") o.orbit_lds_min = value;
     else if (n == "orbit_lg") o.orbit_lg = value;
     else if (n == "orbit") o.orbit = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
@@ -534,6 +535,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "orbit_min") return o.orbit_min;
     if (n == "orbit_few") return o.orbit_few;
     if (n == "orbit_pipe") return o.orbit_pipe;
+    if (n == "orbit_lds_min") return o.orbit_lds_min;
     if (n == "orbit_lg") return o.orbit_lg;
     if (n == "orbit") return o.orbit;
     if (n == "max_lds_bytes") return o.max_lds_bytes;

@@ -207,6 +207,7 @@ struct Options {
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
     i64 orbit_min = 150;     // pick the largest tile edge that still yields this many orbits (measured: tools/orbit_sweep.py)
     i64 orbit_pipe = -1;     // persistent pipelined ORBIT form: 0 never, 1 whenever there are more orbits than CUs, -1 = when LDS leaves one workgroup per CU
+    i64 orbit_lds_min = 0;   // experiment: request at least this much LDS per ORBIT workgroup (limits residency)
     i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
     i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes and
                              // TILED tiles that write whole 128-byte lines (profiles/r02_nt_store_ab.txt: configs[4]

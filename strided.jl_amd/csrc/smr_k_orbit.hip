@@ -487,7 +487,8 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     // runs of the 4-D orbits rely on line partners meeting in L2 and get slower (4.8 -> 6.3 us at 32^4)
     a.nts = (opt.nt_store > 0 || (opt.nt_store < 0 && plan.c.strides[0][0] == 1 && (sizeof(T) << o.lg[0]) >= 128)) ? 1 : 0;
     const unsigned block = 1u << a.ntlog;
-    const size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);
+    size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);
+    if (opt.orbit_lds_min > 0) lds = std::max(lds, (size_t)opt.orbit_lds_min);  // experiment: fewer resident workgroups per CU
     a.nlist = (int32_t)o.list.size();
     unsigned grid = (unsigned)o.list.size();
     if (PIPE) grid = std::min<unsigned>(grid, 256u * (unsigned)std::max<size_t>(1, (160 * 1024) / lds));
