@@ -7,6 +7,7 @@ REDUCE_PART (ROW / COL / general, split reductions) -- at sizes of 10^5..2*10^6 
 inputs; + - * / maps bit for bit, the rest within the reference's tolerance.  The families actually hit are
 counted from smr_plan_describe and printed (>= 200 problems per family)."""
 import collections
+import os
 import sys
 
 import numpy as np
@@ -152,6 +153,8 @@ def _initop_fn(i):
 RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_big", "orbit", "orbit_pipe", "aliased_classic", "generic",
            "reduce_all", "reduce_part"]
 
+SEED_OFFSET = int(os.environ.get("SMR_FUZZ_SEED_OFFSET", "0"))  # other seeds for longer campaigns on a GPU box
+
 
 @pytest.mark.parametrize("name", RECIPES)
 def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
@@ -166,7 +169,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:
-            seed = 7919 * RECIPES.index(name) + i
+            seed = 7919 * RECIPES.index(name) + i + SEED_OFFSET
             run, exact, opts, info = recipe(name, seed, T)
             with monkeypatch.context() as m:
                 m.setattr(sys.modules["strided_jl_amd.mapreduce"], "_mapreduce_fuse_", funnel)
