@@ -55,6 +55,9 @@
 #ifndef SMR_TILED_BITS
 #define SMR_TILED_BITS 0
 #endif
+#ifndef SMR_TILED_NTL
+#define SMR_TILED_NTL 0
+#endif
 
 namespace smr {
 
@@ -290,7 +293,11 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
                     if constexpr (V == 1) {
                         x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
                     } else {
+#if SMR_TILED_NTL  // experiment (A/B build): non-temporal loads
+                        x[i][r] = load_vec_ct<true, VT>(p);
+#else
                         x[i][r] = *reinterpret_cast<const VT*>(p);
+#endif
                         if constexpr (tr<T>::cx) {
                             if (d.conj) {
 #pragma unroll
