@@ -49,17 +49,67 @@ class Ref:
         self.x = x
 
 
+# StridedArrayStyle x DefaultArrayStyle -> DefaultArrayStyle (src/broadcast.jl:11-18): a broadcast that mixes a
+# StridedView with a plain array leaves the strided path in the reference -- Base broadcasts it on the CPU and the
+# result is a plain Array (test/othertests.jl:64).  There is no CPU path here.  The default is to refuse; the
+# opt-in "upload" copies the plain array to the views' memory space, computes there and hands an out-of-place
+# result back as a plain host array (same values, same result type as the reference).
+_PLAIN_RULE = "error"
+
+
+def set_plain_array_rule(rule: str) -> str:
+    """'error' (default) or 'upload'.  Returns the previous rule."""
+    global _PLAIN_RULE
+    if rule not in ("error", "upload"):
+        raise ValueError("plain-array rule must be 'error' or 'upload'")
+    old, _PLAIN_RULE = _PLAIN_RULE, rule
+    return old
+
+
+def _is_plain(a) -> bool:
+    return isinstance(a, np.ndarray) or type(a).__module__.startswith("torch")
+
+
 def _check_leaf(a):
     if isinstance(a, (StridedView, Broadcasted, Ref, numbers.Number, np.generic)):
         return
     if hasattr(a, "numerator"):
         return
-    if isinstance(a, np.ndarray) or type(a).__module__.startswith("torch"):
-        # StridedArrayStyle x DefaultArrayStyle -> DefaultArrayStyle (src/broadcast.jl:12-14):
-        # the reference silently falls back to Base's CPU broadcast.  There is no CPU path here.
+    if _is_plain(a):
+        if _PLAIN_RULE == "upload":
+            return
         raise TypeError("broadcast mixes a StridedView with a plain array; the reference would fall back to "
-                        "Base broadcasting on the CPU -- wrap the array in StridedView instead")
+                        "Base broadcasting on the CPU -- wrap the array in StridedView, or opt in to "
+                        "set_plain_array_rule('upload')")
     raise TypeError(f"cannot broadcast over {type(a)}")
+
+
+def _lower_plain(bc, like: StridedView):
+    """Replace plain-array leaves by dense column-major StridedViews in `like`'s memory space.
+    Returns (tree, found_any)."""
+    found = [False]
+
+    def up(a):
+        found[0] = True
+        host = a.detach().cpu().numpy() if type(a).__module__.startswith("torch") else a
+        if host.ndim == 0:
+            return host.reshape(()).item()
+        dest = like.similar(host.dtype, host.shape)
+        if dest._device is None:
+            dest.parent[:] = np.asarray(host).reshape(-1, order="F")
+        else:
+            import torch
+            dest.parent.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(host).reshape(-1, order="F"))))
+        return dest
+
+    def go(n):
+        if isinstance(n, Broadcasted):
+            return Broadcasted(n.f, tuple(go(a) for a in n.args))
+        if _is_plain(n):
+            return up(n)
+        return n
+
+    return go(bc), found[0]
 
 
 # install the operators on StridedView
@@ -156,6 +206,7 @@ def copyto_(dest: StridedView, bc) -> StridedView:
     if not isinstance(bc, Broadcasted):  # dest .= scalar: a functor tree without Arg leaves
         _mapreduce_fuse_(E.as_expr(bc), None, None, dest.size, (dest,))
         return dest
+    bc, _ = _lower_plain(bc, dest)
     stridedargs = promoteshape(dest.size, *capturestridedargs(bc))
     c = make_capture(bc)
     _mapreduce_fuse_(c, None, None, dest.size, (dest,) + stridedargs)
@@ -170,10 +221,13 @@ def materialize(bc):
     leaves = capturestridedargs(bc)
     if not leaves:
         raise TypeError("materialize needs at least one StridedView operand")
+    bc, had_plain = _lower_plain(bc, leaves[0])
+    leaves = capturestridedargs(bc)
     c = make_capture(bc)
     T = E.result_dtype(c, [a.dtype for a in leaves])
     dest = leaves[0].similar(T, broadcast_shape(bc))
-    return copyto_(dest, bc)
+    out = copyto_(dest, bc)
+    return out.toarray() if had_plain else out  # "isa Array" when any argument is one (test/othertests.jl:64)
 
 
 def _assign(self: StridedView, bc):

@@ -361,3 +361,31 @@ def test_every_kernel_family_is_exercised():
     o = x.similar(size=(32, 1, 32, 1))
     d = S.make_plan(S.fn.sin, "+", None, x.size, S.promoteshape(x.size, o, x)).describe()
     assert "family=reduce_part" in d
+
+
+def test_plain_array_rule_upload_on_the_device():
+    """a5 opt-in: a broadcast that mixes device views with a plain host array uploads the array, runs on the GPU and
+    hands the out-of-place result back as a plain array (src/broadcast.jl:11-18, test/othertests.jl:64)."""
+    import torch
+    from strided_jl_amd.broadcast import set_plain_array_rule
+    fn = S.fn
+    rng = np.random.default_rng(5)
+    for T in (np.float32, np.float64, np.complex64, np.complex128):
+        R1, R2, R3 = (rng.random(sh).astype(T) for sh in ((10,), (10, 10), (10, 10, 10)))
+        B1 = S.StridedView(torch.from_numpy(R1).cuda())
+        B2 = S.StridedView(torch.from_numpy(R2).cuda()).permutedims((1, 0))
+        B3 = S.StridedView(torch.from_numpy(R3).cuda()).permutedims((2, 0, 1))
+        A3 = B3.toarray()
+        with pytest.raises(TypeError):
+            B2.adjoint() * A3
+        old = set_plain_array_rule("upload")
+        try:
+            got = (B2.adjoint() * A3 - fn.max(fn.abs(B1), fn.real(B3))).materialize()
+            assert isinstance(got, np.ndarray)
+            a1, a2 = B1.toarray(), B2.toarray()
+            want = a2.conj().T[:, :, None] * A3 - np.maximum(np.abs(a1)[:, None, None], A3.real)
+            assert np.allclose(got, want, rtol=50 * np.finfo(np.dtype(T)).eps, atol=0), np.dtype(T).name
+            dest = B3.similar()
+            assert dest.assign(B3 + A3) is dest and np.array_equal(dest.toarray(), A3 + A3)
+        finally:
+            set_plain_array_rule(old)

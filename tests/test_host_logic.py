@@ -162,3 +162,43 @@ def test_traced_f_programs_are_cached_per_closure_including_captured_values():
     a32 = S.StridedView(np.zeros((8, 8), dtype=np.float32, order="F"))
     S.build_problem(f, None, None, a.size, (b, a32), stream=0)
     assert len(MR._FPROG_CACHE) == n + 1
+
+
+def test_plain_array_rule_is_opt_in_and_returns_a_plain_array(monkeypatch):
+    """a5 (src/broadcast.jl:11-18, test/othertests.jl:64): Strided x plain Array leaves the strided path in the
+    reference and yields a plain Array.  Default here: TypeError; opt-in 'upload': computed on the views' memory
+    space, out-of-place result handed back as a plain host array, in-place destination stays a StridedView."""
+    import sys
+
+    import oraclelib
+
+    def funnel(f, op, initop, dims, arrays):
+        p, keep = S.build_problem(f, op, initop, dims, arrays, stream=0)
+        oraclelib.mapreduce(p, 1)
+        return arrays[0]
+
+    monkeypatch.setattr(sys.modules["strided_jl_amd.mapreduce"], "_mapreduce_fuse_", funnel)
+    monkeypatch.setattr(sys.modules["strided_jl_amd.broadcast"], "_mapreduce_fuse_", funnel, raising=False)
+    rng = np.random.default_rng(3)
+    R1, R2, R3 = rng.random(10), rng.random((10, 10)), rng.random((10, 10, 10))
+    B1, B2, B3 = F(R1), F(R2).permutedims((1, 0)), F(R3).permutedims((2, 0, 1))
+    A3 = B3.toarray()
+    with pytest.raises(TypeError, match="set_plain_array_rule"):
+        B2.adjoint() * A3
+    from strided_jl_amd.broadcast import set_plain_array_rule
+    old = set_plain_array_rule("upload")
+    try:
+        assert old == "error"
+        got = (B2.adjoint() * A3 - fn.max(fn.abs(B1), fn.real(B3))).materialize()
+        assert isinstance(got, np.ndarray)                     # "isa Array"
+        a1, a2 = B1.toarray(), B2.toarray()
+        want = a2.conj().T[:, :, None] * A3 - np.maximum(np.abs(a1)[:, None, None], A3.real)
+        assert np.allclose(got, want, rtol=1e-13, atol=0)
+        dest = F(np.zeros((10, 10, 10)))
+        assert dest.assign(B3 + A3) is dest                    # in place: the destination decides
+        assert np.array_equal(dest.toarray(), A3 + A3)
+        assert isinstance((B1 + fn.sin(B2 - 3)).materialize(), S.StridedView)   # no plain array: unchanged
+    finally:
+        set_plain_array_rule(old)
+    with pytest.raises(ValueError):
+        set_plain_array_rule("cpu")

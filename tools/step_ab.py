@@ -68,3 +68,16 @@ for x, y in (("perm", "permC"), ("perm", "perm2341"), ("perm", "copy"), ("sum4",
         plans[y].execute(cur())
     tp = t(pair)
     print(f"{x:8s} + {y:8s}: pair {tp:.2f} us, alone sum {alone[x] + alone[y]:.2f}, penalty {tp - alone[x] - alone[y]:+.2f}")
+# a tiny kernel (16 elements) in between: is the penalty about data in the caches or about switching kernels?
+tS = torch.randn(16, dtype=torch.float64, device="cuda")
+tT = torch.empty_like(tS)
+tiny = S.make_plan(lambda x: x, None, None, (16,), (S.StridedView(tT, (16,), (1,), 0), S.StridedView(tS, (16,), (1,), 0)))
+plans["tiny"] = tiny
+alone["tiny"] = t(lambda: tiny.execute(cur()))
+print("tiny alone", round(alone["tiny"], 2), tiny.describe()[:60])
+for x in ("sum4", "perm", "copy"):
+    def pair(x=x):
+        plans[x].execute(cur())
+        tiny.execute(cur())
+    tp = t(pair)
+    print(f"{x:8s} + tiny    : pair {tp:.2f} us, alone sum {alone[x] + alone['tiny']:.2f}, penalty {tp - alone[x] - alone['tiny']:+.2f}")
