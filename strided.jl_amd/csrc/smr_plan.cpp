@@ -796,6 +796,25 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
             }
         }
     }
+    // an operand whose unit axis is shorter than the run target (3 x H x W images, physical indices of 2..4 in front):
+    // its memory run continues along the dim whose stride equals that extent -- grow that one before the
+    // destination-order widening below (permutedims (3,1000,700) -> (700,1000,3): 256 x 4 tiles read 24-byte
+    // runs, 32 x 8 x 4 tiles read 192-byte runs)
+    if (!forced) {
+        for (int k = 0; k < c.M; ++k) {
+            if (k > 0 && t.staged[k] < 0) continue;
+            const int q = (k == 0) ? 0 : fast_axis(c, k);
+            if (q < 0 || ((i64)1 << lg[q]) < c.dims[q] || c.dims[q] >= ((i64)1 << want)) continue;
+            int v = -1;
+            for (int d = 0; d < c.N; ++d)
+                if (d != q && std::llabs(c.strides[k][d]) == c.dims[q]) v = d;
+            if (v < 0) continue;
+            while (total < tl_cap && (c.dims[q] << lg[v]) < ((i64)1 << want) && ((i64)1 << lg[v]) < c.dims[v]) {
+                ++lg[v];
+                ++total;
+            }
+        }
+    }
     // small problems / short axes: widen the tile with the remaining dims (destination order)
     // until a block has at least 1024 elements of work
     int minlog = forced ? 0 : tl_cap;
@@ -856,6 +875,20 @@ int make_plan(const smr_problem* p, Plan& plan) {
         for (int k = 0; k < c.M; ++k) {
             i64 s = c.strides[k][0];
             if (!(s == 1 || (k > 0 && s == 0))) stream = false;
+        }
+        if (stream && c.N >= 2 && o.force_family != FAM_STREAM) {
+            // short rows pack (256 >> txlog) entries of dim 1 into a workgroup; when dim 1 is short too (a permutation
+            // of a 4x4x4x... tensor) most lanes idle -- 8 of 256 for rows of 4 Float64 x 4 -- and the per-element
+            // decode of the GENERIC family wins (measured 4^8 Float64: 9.9 us -> tools/perf_sanity.py)
+            const int es0 = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+            const i64 vmax = std::max<i64>(1, 16 / es0);
+            const i64 n0v = (c.dims[0] % vmax == 0) ? c.dims[0] / vmax : c.dims[0];
+            if (n0v <= 128) {
+                int txlog = 0;
+                while (((i64)1 << txlog) < n0v) ++txlog;
+                const i64 used = n0v * std::min<i64>(c.dims[1], (i64)256 >> txlog);
+                if (used * 4 < 256) stream = false;
+            }
         }
         if (stream) {
             fam = FAM_STREAM;
