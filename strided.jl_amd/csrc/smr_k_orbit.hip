@@ -185,126 +185,126 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
 
     uint32_t wg = blockIdx.x, tidp = tid;
     for (;;) {
-    if constexpr (PIPE) {
-        // loop-invariant LDS addresses (one per view x repeat x slot) would be hoisted and spill: recompute them
+        if constexpr (PIPE) {
+            // loop-invariant LDS addresses (one per view x repeat x slot) would be hoisted and spill: recompute them
 #pragma unroll
-        for (int k = 0; k < NK; ++k)
+            for (int k = 0; k < NK; ++k)
 #pragma unroll
-            for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(lr[k][r]));
+                for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(lr[k][r]));
 #pragma unroll
-        for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(goff[r]));
-        asm volatile("" : "+v"(tidp));
-    }
-    // ---- park the slots in LDS ---------------------------------------------------------------------------
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        T* L = lds + ((size_t)g << a.tilelog);
-#pragma unroll
-        for (int r = 0; r < NREP; ++r) {
-            const uint32_t e = (((uint32_t)r << a.ntlog) | tidp) * V;
-#pragma unroll
-            for (int h = 0; h < V; ++h) L[swz(e + h)] = x[g][r].v[h];
+            for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(goff[r]));
+            asm volatile("" : "+v"(tidp));
         }
-    }
-    __syncthreads();
-    i64 norg[NG];
-    bool nlive = false, more = false;
-    VT xn[NG][NREP];
-    if constexpr (PIPE) {
-        wg += gridDim.x;
-        more = wg < (uint32_t)a.nlist;
-        if (more) {
-            load_row(wg, norg, nlive);
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int r = 0; r < NREP; ++r) xn[g][r] = *reinterpret_cast<const VT*>(a.src + norg[g] + goff[r]);
-        }
-    }
-
-    // ---- outputs of every slot: all LDS reads of a repeat are issued before the first use ----------------
-    // (the one-shot form batches the reads of all slots: one LDS latency per repeat; the persistent form has the
-    // next orbit's loads in registers as well and batches per slot)
-    constexpr int GB = PIPE ? 1 : NG;
-#pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-#pragma unroll
-        for (int g0 = 0; g0 < NG; g0 += GB) {
-            T val[GB][V][NK];
-#pragma unroll
-            for (int gi = 0; gi < GB; ++gi)
-#pragma unroll
-                for (int h = 0; h < V; ++h)
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        const int g = g0 + gi;
-                        if (OWN0 && k == 0) {
-                            val[gi][h][k] = x[g][r].v[h];
-                        } else {
-                            // sub-element h moves along tiled dim 0 of the natural order
-                            const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
-                            val[gi][h][k] = lds[sbase[g][k] + swz(idx)];
-                        }
-                    }
-            __builtin_amdgcn_sched_barrier(0);  // keep the reads together: one LDS latency per batch, not one per output
-#pragma unroll
-            for (int gi = 0; gi < GB; ++gi) {
-                const int g = g0 + gi;
-                VT out;
-#pragma unroll
-                for (int h = 0; h < V; ++h) {
-                    T arg[MAXIN];
-#pragma unroll
-                    for (int k = 0; k < MAXIN; ++k) {
-                        arg[k] = T{};
-                        if (k < NK) {
-                            T v = val[gi][h][k < NK ? k : 0];
-                            if constexpr (tr<T>::cx) v = ocj(v, cbit[k < NK ? k : 0]);
-                            arg[k] = v;
-                        }
-                    }
-                    (void)nin;
-                    T o = f(arg);
-                    if constexpr (tr<T>::cx) o = ocj(o, conj0);
-                    out.v[h] = o;
-                }
-                x[g][r] = out;
-            }
-            if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);  // one slot at a time: the registers hold two orbits
-        }
-    }
-    if constexpr (!PIPE) {
-        if (!live) return;
-    }
-    const bool nts = nts_flag != 0;
-    if (!PIPE || live) {
-        if (nts) {
-            nt_block_guard();
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int r = 0; r < NREP; ++r) store_vec_ct<true, VT>(a.dst + org[g] + goff[r], x[g][r]);
-            nt_block_guard();
-        } else {
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int r = 0; r < NREP; ++r) store_vec_ct<false, VT>(a.dst + org[g] + goff[r], x[g][r]);
-        }
-    }
-    if constexpr (!PIPE) {
-        return;
-    } else {
-        if (!more) return;
-        __syncthreads();  // every lane has read its LDS values: the slots may be overwritten
-        live = nlive;
+        // ---- park the slots in LDS ---------------------------------------------------------------------------
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            org[g] = norg[g];
+            T* L = lds + ((size_t)g << a.tilelog);
 #pragma unroll
-            for (int r = 0; r < NREP; ++r) x[g][r] = xn[g][r];
+            for (int r = 0; r < NREP; ++r) {
+                const uint32_t e = (((uint32_t)r << a.ntlog) | tidp) * V;
+#pragma unroll
+                for (int h = 0; h < V; ++h) L[swz(e + h)] = x[g][r].v[h];
+            }
         }
-    }
+        __syncthreads();
+        i64 norg[NG];
+        bool nlive = false, more = false;
+        VT xn[NG][NREP];
+        if constexpr (PIPE) {
+            wg += gridDim.x;
+            more = wg < (uint32_t)a.nlist;
+            if (more) {
+                load_row(wg, norg, nlive);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < NREP; ++r) xn[g][r] = *reinterpret_cast<const VT*>(a.src + norg[g] + goff[r]);
+            }
+        }
+
+        // ---- outputs of every slot: all LDS reads of a repeat are issued before the first use ----------------
+        // (the one-shot form batches the reads of all slots: one LDS latency per repeat; the persistent form has the
+        // next orbit's loads in registers as well and batches per slot)
+        constexpr int GB = PIPE ? 1 : NG;
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+#pragma unroll
+            for (int g0 = 0; g0 < NG; g0 += GB) {
+                T val[GB][V][NK];
+#pragma unroll
+                for (int gi = 0; gi < GB; ++gi)
+#pragma unroll
+                    for (int h = 0; h < V; ++h)
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) {
+                            const int g = g0 + gi;
+                            if (OWN0 && k == 0) {
+                                val[gi][h][k] = x[g][r].v[h];
+                            } else {
+                                // sub-element h moves along tiled dim 0 of the natural order
+                                const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
+                                val[gi][h][k] = lds[sbase[g][k] + swz(idx)];
+                            }
+                        }
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads together: one LDS latency per batch, not one per output
+#pragma unroll
+                for (int gi = 0; gi < GB; ++gi) {
+                    const int g = g0 + gi;
+                    VT out;
+#pragma unroll
+                    for (int h = 0; h < V; ++h) {
+                        T arg[MAXIN];
+#pragma unroll
+                        for (int k = 0; k < MAXIN; ++k) {
+                            arg[k] = T{};
+                            if (k < NK) {
+                                T v = val[gi][h][k < NK ? k : 0];
+                                if constexpr (tr<T>::cx) v = ocj(v, cbit[k < NK ? k : 0]);
+                                arg[k] = v;
+                            }
+                        }
+                        (void)nin;
+                        T o = f(arg);
+                        if constexpr (tr<T>::cx) o = ocj(o, conj0);
+                        out.v[h] = o;
+                    }
+                    x[g][r] = out;
+                }
+                if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);  // one slot at a time: the registers hold two orbits
+            }
+        }
+        if constexpr (!PIPE) {
+            if (!live) return;
+        }
+        const bool nts = nts_flag != 0;
+        if (!PIPE || live) {
+            if (nts) {
+                nt_block_guard();
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < NREP; ++r) store_vec_ct<true, VT>(a.dst + org[g] + goff[r], x[g][r]);
+                nt_block_guard();
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < NREP; ++r) store_vec_ct<false, VT>(a.dst + org[g] + goff[r], x[g][r]);
+            }
+        }
+        if constexpr (!PIPE) {
+            return;
+        } else {
+            if (!more) return;
+            __syncthreads();  // every lane has read its LDS values: the slots may be overwritten
+            live = nlive;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                org[g] = norg[g];
+#pragma unroll
+                for (int r = 0; r < NREP; ++r) x[g][r] = xn[g][r];
+            }
+        }
     }
 }
 
