@@ -981,7 +981,9 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 plan.part_kind = 2;
                 const i64 K0 = c.dims[0];
                 int txlog = std::min(8, p2ceil((K0 + vmax - 1) / vmax));
-                txlog = std::min<int>(txlog, (int)o.reduce_col_txlog);
+                // rows of the reduced space per workgroup: fewer when the reduction is short (sum over a trailing dim of 7:
+                // every lane then walks its 7 rows itself instead of 8 lanes sharing them through LDS)
+                txlog = std::min<int>(txlog, std::max<int>((int)o.reduce_col_txlog, 8 - p2ceil(std::max<i64>(1, red / 8))));
                 plan.part_txlog = txlog;
                 const int tylog = 8 - txlog;
                 plan.part_g0log = std::min(tylog, p2ceil(L0));
@@ -991,11 +993,10 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 const i64 rows_per_wg = (i64)1 << tylog;
                 if (kb < 2048 && red >= rows_per_wg * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / kb, red / (rows_per_wg * 8)));
                 split = std::min<i64>(split, 4096);
-                if (Q >= 2 * split * ((i64)1 << plan.part_g1log)) {
-                    plan.part_qsplit = (int)split;
-                } else {
-                    plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split, L0 / ((i64)4 << plan.part_g0log)));
-                }
+                // cut the outer reduced index first, the inner reduced dim with what is left (a short Q -- a trailing
+                // dim of 7 -- used to forbid any cut but 2 along L0: 160 workgroups for 19 MiB)
+                plan.part_qsplit = (int)std::max<i64>(1, std::min<i64>(split, Q >> plan.part_g1log));
+                plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split / plan.part_qsplit, L0 / ((i64)4 << plan.part_g0log)));
                 plan.part_split = plan.part_xsplit * plan.part_qsplit;
                 plan.part_tr = 1 << tylog;
             } else if (row) {
@@ -1009,11 +1010,8 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 i64 split = 1;
                 if (groups < 2048 && red >= ((i64)vmax << glog) * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / groups, red / (((i64)vmax << glog) * 8)));
                 split = std::min<i64>(split, 4096);
-                if (Q >= 2 * split * ((i64)1 << plan.part_g1log)) {
-                    plan.part_qsplit = (int)split;
-                } else {
-                    plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split, L0 / (((i64)vmax * 4) << plan.part_g0log)));
-                }
+                plan.part_qsplit = (int)std::max<i64>(1, std::min<i64>(split, Q >> plan.part_g1log));
+                plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split / plan.part_qsplit, L0 / (((i64)vmax * 4) << plan.part_g0log)));
                 plan.part_split = plan.part_xsplit * plan.part_qsplit;
                 plan.part_tr = 1 << glog;
             } else {
