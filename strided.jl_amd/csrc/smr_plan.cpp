@@ -697,6 +697,23 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
     return true;
 }
 
+// the dim along which operand k's memory continues after a (short) dim 0: stride == extent of dim 0, or -1
+static int continuation_of_dim0(const Canon& c, int k) {
+    if (c.strides[k][0] != 1) return -1;
+    for (int d = 1; d < c.N; ++d)
+        if (c.dims[d] > 1 && std::llabs(c.strides[k][d]) == c.dims[0]) return d;
+    return -1;
+}
+
+// A short common unit axis (a physical index of 2..4, the colour channel of an image) with operands that continue
+// along DIFFERENT dims behind it -- permutedims of (2,128,128) to (1,3,2) -- is a transposition one level up: rows
+// of dims[0] elements are all the STREAM family would move.  Such inputs are staged like transposed ones.
+static bool short_dim0_transposition(const Canon& c, int k, int es) {
+    if (c.N < 3 || c.dims[0] * es >= 64 || c.strides[0][0] != 1 || c.strides[k][0] != 1) return false;
+    const int d0 = continuation_of_dim0(c, 0), dk = continuation_of_dim0(c, k);
+    return d0 > 0 && dk > 0 && d0 != dk;
+}
+
 static bool plan_tiles(const Canon& c, TilePlan& t) {
     if (c.redop != SMR_RED_NONE) return false;
     if (c.N < 2 || c.strides[0][0] != 1) return false;
@@ -712,6 +729,10 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
         if (q > 0 && c.strides[k][0] != 0 && std::llabs(c.strides[k][0]) != 1) {
             t.staged[k] = nst++;
             axis_used[q] = true;
+        } else if (q == 0 && short_dim0_transposition(c, k, es)) {
+            t.staged[k] = nst++;
+            axis_used[continuation_of_dim0(c, 0)] = true;
+            axis_used[continuation_of_dim0(c, k)] = true;
         } else if (q > 0 && c.strides[k][0] == 0) {
             // broadcast along dim 0 with another unit axis: reads are wave-uniform along
             // dim 0 anyway; leave it direct
@@ -890,7 +911,17 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 if (used * 4 < 256) stream = false;
             }
         }
-        if (stream) {
+        if (stream && o.force_family != FAM_STREAM) {
+            const int es0 = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+            bool transposed = false;
+            for (int k = 1; k < c.M; ++k) transposed = transposed || short_dim0_transposition(c, k, es0);
+            if (transposed && plan_tiles(c, plan.tile)) {
+                stream = false;
+                fam = FAM_TILED;
+            }
+        }
+        if (fam == FAM_TILED) {
+        } else if (stream) {
             fam = FAM_STREAM;
         } else if (o.force_family != FAM_TILED && o.force_family != FAM_GENERIC && plan_orbit(c, plan.orbit)) {
             fam = FAM_ORBIT;

@@ -33,10 +33,13 @@ def _data(rng, T):
     return data
 
 
-def _perm_view(rng, mk, data, dims, reverse=False):
-    """dense parent with a random dim permutation (unit stride lands on a random dim); optionally reversed dims"""
+def _perm_view(rng, mk, data, dims, reverse=False, keep0=False):
+    """dense parent with a random dim permutation (unit stride lands on a random dim); optionally reversed dims;
+    keep0: dim 0 stays in front (a short common unit axis with different continuation dims behind it)"""
     N = len(dims)
     perm = [int(q) for q in rng.permutation(N)]
+    if keep0:
+        perm = [0] + [1 + int(q) for q in rng.permutation(N - 1)]
     pshape = [0] * N
     for i in range(N):
         pshape[perm[i]] = dims[i]
@@ -69,6 +72,9 @@ def recipe(name, seed, T):
         if name == "tiled_persistent":
             opts = {"tiled_persist_min": 1}
         mkview = lambda rng, mk, data, k: _perm_view(rng, mk, data, dims, rev)  # noqa: E731
+    elif name == "tiled_short0":
+        dims = pick([(2, 40, 36), (3, 50, 70), (4, 16, 20, 12), (2, 128, 128), (3, 33, 65, 9), (4, 4, 4, 4, 4, 4), (2, 64, 2, 64)])
+        mkview = lambda rng, mk, data, k: _perm_view(rng, mk, data, dims, keep0=True)  # noqa: E731
     elif name == "tiled_big":
         f, nin, exact = EXPRS[4] if rng0.integers(0, 2) else EXPRS[3]
         dims = pick([(32, 32, 32, 32), (64, 16, 32, 40), (48, 48, 24, 24)])
@@ -150,7 +156,7 @@ def _initop_fn(i):
     return i
 
 
-RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_big", "orbit", "orbit_pipe", "aliased_classic", "generic",
+RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_short0", "tiled_big", "orbit", "orbit_pipe", "aliased_classic", "generic",
            "reduce_all", "reduce_part"]
 
 SEED_OFFSET = int(os.environ.get("SMR_FUZZ_SEED_OFFSET", "0"))  # other seeds for longer campaigns on a GPU box
@@ -165,7 +171,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
         oraclelib.mapreduce(p, 4)
         return arrays[0]
 
-    n = {"tiled_big": 40, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30}.get(name, 60)
+    n = {"tiled_big": 40, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:
