@@ -355,3 +355,34 @@ def test_plan_rebinding_must_keep_the_aliasing_pattern():
     assert lib.smr_plan_execute(h, diff, None) == L.SMR_EINVAL and b"share a buffer" in lib.smr_last_error()
     assert lib.smr_plan_execute(h, same, None) != L.SMR_EINVAL or b"share a buffer" not in lib.smr_last_error()
     lib.smr_plan_destroy(h)
+
+
+def test_planner_rules_for_short_dims_big_transposes_and_short_reductions():
+    """Round-2 planner rules found by tools/perf_sanity.py (host arithmetic only)."""
+    def perm(dims, p, dt=np.float64):
+        a = S.StridedView(np.zeros(dims, dtype=dt, order="F"))
+        b = S.StridedView(np.zeros(tuple(dims[i] for i in p), dtype=dt, order="F"))
+        return S.make_plan(lambda x: x, None, None, b.size, (b, a.permutedims(p))).describe()
+
+    # a short common unit axis with different continuation dims behind it is a transposition one level up
+    d = perm((2, 128, 2, 128, 8), (0, 3, 1, 2, 4))
+    assert "family=tiled" in d and "tile=d0:2,d1:32,d2:16" in d, d
+    assert "family=stream" in perm((8, 64, 64), (0, 2, 1))            # 64-byte rows: STREAM keeps them
+    assert "family=stream" in perm((100, 90, 80), (0, 2, 1))
+    # a nearly idle short-row STREAM workgroup goes elsewhere
+    assert "family=stream" not in perm((4,) * 8, (0, 3, 5, 4, 2, 6, 7, 1))
+    # a unit axis shorter than the run target continues into the dim whose stride equals its extent
+    assert "tile=d0:32,d1:8,d2:4" in perm((3, 1000, 700), (2, 1, 0))
+    # HBM-sized transposes of 8-/16-byte elements: 128 x 32 tiles on 1024 lanes; Float32 and smaller problems: 32 x 32
+    assert "tile=d0:128,d1:32" in perm((8192, 8192), (1, 0)) and "threads=1024" in perm((8192, 8192), (1, 0))
+    assert "tile=d0:32,d1:32" in perm((8192, 8192), (1, 0), np.float32)
+    assert "tile=d0:32,d1:32" in perm((4000, 4000), (1, 0))
+
+    def red(dims, rd):
+        a = S.StridedView(np.zeros(dims, dtype=np.float32, order="F"))
+        out = a.similar(size=tuple(1 if i in rd else n for i, n in enumerate(dims)))
+        return S.make_plan(lambda x: x, "+", "zero", dims, S.promoteshape(dims, out, a)).describe()
+
+    assert "form=col lanes_per_out=1 " in red((100, 90, 80, 7), (3,))           # 7 rows per output: one lane walks them
+    assert "form=col lanes_per_out=8 " in red((512, 384, 64), (2,))             # 64 rows: shared through LDS as before
+    assert "split=7 " in red((100, 90, 80, 7), (1, 3)) + " "                      # outer (7) x inner (1) cuts together
