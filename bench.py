@@ -285,7 +285,10 @@ def main():
 
     extra = {}
     if not args.no_extra:
-        extra = secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur)
+        try:
+            extra = secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur)
+        except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
+            extra = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         out = {
