@@ -64,23 +64,23 @@ SMR_DEV void epilogue(const RedArgs& a, i64 off0, T acc) {
 }
 
 // offsets of box element `i` (decomposed over dims [d0, d1)) added into off[]
+// (a real loop over the dims, not an unrolled one: unrolled, every call site carried eight copies of the 64-bit
+// division -- the ROW kernel was 15,800 ISA lines, more than the instruction cache holds)
 SMR_DEV void decompose(const RedArgs& a, i64 i, int d0, int d1, i64* off) {
     i64 rem = i;
-#pragma unroll
-    for (int d = 0; d < MAXN; ++d) {
-        if (d >= d0 && d < d1) {
-            i64 c;
-            if (d == d1 - 1) {
-                c = rem;
-            } else {
-                const i64 q = rem / a.dims[d];
-                c = rem - q * a.dims[d];
-                rem = q;
-            }
-#pragma unroll
-            for (int k = 0; k < MAXM; ++k)
-                if (k < a.M) off[k] += c * a.strides[k][d];
+#pragma nounroll
+    for (int d = d0; d < d1; ++d) {
+        i64 c;
+        if (d == d1 - 1) {
+            c = rem;
+        } else {
+            const i64 q = rem / a.dims[d];
+            c = rem - q * a.dims[d];
+            rem = q;
         }
+#pragma unroll
+        for (int k = 0; k < MAXM; ++k)
+            if (k < a.M) off[k] += c * a.strides[k][d];
     }
 }
 
@@ -90,14 +90,15 @@ struct alignas(sizeof(T) * V) RVec {
     T v[V];
 };
 
-template <class T, class F, bool MIXED, int V>
-SMR_DEV void reduce_all_body(const RedArgs a, F f) {
+template <class T, class F, bool MIXED, int V, int OPC>
+SMR_DEV void reduce_all_impl(const RedArgs& a, F f) {
+    const int redop = (OPC >= 0) ? OPC : a.redop;  // compile-time for the sum: no op switch inside the loops
     __shared__ T wsum[4];
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     constexpr int ACC = 4;
     T acc[ACC];
 #pragma unroll
-    for (int j = 0; j < ACC; ++j) acc[j] = neutral<T>(a.redop);
+    for (int j = 0; j < ACC; ++j) acc[j] = neutral<T>(redop);
     const i64 nthreads = (i64)gridDim.x * 256;
     const i64 t0 = (i64)blockIdx.x * 256 + threadIdx.x;
     if constexpr (V > 1) {
@@ -148,7 +149,7 @@ SMR_DEV void reduce_all_body(const RedArgs a, F f) {
                                 in[k] = T{};
                                 if (k < nin) in[k] = x[j][k].v[e];
                             }
-                            acc[j] = red_apply<T>(a.redop, acc[j], f(in));
+                            acc[j] = red_apply<T>(redop, acc[j], f(in));
                         }
                     }
                 }
@@ -183,7 +184,7 @@ SMR_DEV void reduce_all_body(const RedArgs a, F f) {
                         in[k] = T{};
                         if (k < nin) in[k] = load_op<T, MIXED>(a.ops, k + 1, off[k + 1]);
                     }
-                    acc[j] = red_apply<T>(a.redop, acc[j], f(in));
+                    acc[j] = red_apply<T>(redop, acc[j], f(in));
                 }
             }
         }
@@ -191,20 +192,27 @@ SMR_DEV void reduce_all_body(const RedArgs a, F f) {
 #pragma unroll
     for (int w = ACC / 2; w > 0; w >>= 1) {  // pairwise tree over the per-lane accumulators
 #pragma unroll
-        for (int j = 0; j < w; ++j) acc[j] = red_apply<T>(a.redop, acc[j], acc[j + w]);
+        for (int j = 0; j < w; ++j) acc[j] = red_apply<T>(redop, acc[j], acc[j + w]);
     }
     T v = acc[0];
-    v = wave_reduce(v, a.redop, 64);
+    v = wave_reduce(v, redop, 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) wsum[wave] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        v = red_apply<T>(a.redop, red_apply<T>(a.redop, wsum[0], wsum[1]), red_apply<T>(a.redop, wsum[2], wsum[3]));
+        v = red_apply<T>(redop, red_apply<T>(redop, wsum[0], wsum[1]), red_apply<T>(redop, wsum[2], wsum[3]));
         if (gridDim.x == 1)
             epilogue<T, MIXED>(a, 0, v);
         else
             ((T*)a.partials)[blockIdx.x] = v;
     }
+}
+template <class T, class F, bool MIXED, int V>
+SMR_DEV void reduce_all_body(const RedArgs a, F f) {
+    if (a.redop == SMR_RED_ADD)
+        reduce_all_impl<T, F, MIXED, V, SMR_RED_ADD>(a, f);
+    else
+        reduce_all_impl<T, F, MIXED, V, -1>(a, f);
 }
 
 template <class T, bool MIXED>
@@ -226,8 +234,9 @@ __global__ void __launch_bounds__(256) k_reduce_final(RedArgs a) {
 // 256 threads = (256/TR) destination elements x TR lanes.  Lanes of one destination element
 // are consecutive threads, so when the inputs' unit-stride axis is a reduced dim the loads
 // coalesce; with TR == 1 consecutive threads own consecutive destination elements instead.
-template <class T, class F, bool MIXED>
-SMR_DEV void reduce_part_body(const RedArgs a, F f) {
+template <class T, class F, bool MIXED, int OPC>
+SMR_DEV void reduce_part_impl(const RedArgs& a, F f) {
+    const int redop = (OPC >= 0) ? OPC : a.redop;  // compile-time for the sum: no op switch inside the loops
     __shared__ T xbuf[256];
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     const int tr_ = a.tr;
@@ -244,7 +253,7 @@ SMR_DEV void reduce_part_body(const RedArgs a, F f) {
 #pragma unroll
     for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
     if (live) decompose(a, o, 0, a.NK, ooff);
-    T acc = neutral<T>(a.redop);
+    T acc = neutral<T>(redop);
     if (live) {
         for (i64 r = rbeg + rl; r < rend; r += tr_) {
             i64 off[MAXM];
@@ -257,17 +266,17 @@ SMR_DEV void reduce_part_body(const RedArgs a, F f) {
                 in[k] = T{};
                 if (k < nin) in[k] = load_op<T, MIXED>(a.ops, k + 1, off[k + 1]);
             }
-            acc = red_apply<T>(a.redop, acc, f(in));
+            acc = red_apply<T>(redop, acc, f(in));
         }
     }
     if (tr_ > 1) {
         const int w = tr_ < 64 ? tr_ : 64;
-        acc = wave_reduce(acc, a.redop, w);
+        acc = wave_reduce(acc, redop, w);
         if (tr_ > 64) {  // lanes of one output span several waves
             xbuf[threadIdx.x] = acc;
             __syncthreads();
             if (rl == 0) {
-                for (int j = 64; j < tr_; j += 64) acc = red_apply<T>(a.redop, acc, xbuf[threadIdx.x + j]);
+                for (int j = 64; j < tr_; j += 64) acc = red_apply<T>(redop, acc, xbuf[threadIdx.x + j]);
             }
         }
     }
@@ -277,6 +286,13 @@ SMR_DEV void reduce_part_body(const RedArgs a, F f) {
         else
             ((T*)a.partials)[o * a.nsplit + sp] = acc;
     }
+}
+template <class T, class F, bool MIXED>
+SMR_DEV void reduce_part_body(const RedArgs a, F f) {
+    if (a.redop == SMR_RED_ADD)
+        reduce_part_impl<T, F, MIXED, SMR_RED_ADD>(a, f);
+    else
+        reduce_part_impl<T, F, MIXED, -1>(a, f);
 }
 
 
@@ -288,8 +304,9 @@ SMR_DEV void reduce_part_body(const RedArgs a, F f) {
 // ROW: every input is unit-stride (or broadcast) along the inner reduced dim.  G = G0 x G1 consecutive
 // lanes cooperate on one destination element: G0 lanes walk the inner dim with V-element vector
 // loads, G1 lanes take different q.  sum(A; dims=1) of a column-major matrix is the model case.
-template <class T, class F, bool MIXED, int V>
-SMR_DEV void reduce_row_body(const RedArgs a, F f) {
+template <class T, class F, bool MIXED, int V, int OPC>
+SMR_DEV void reduce_row_impl(const RedArgs& a, F f) {
+    const int redop = (OPC >= 0) ? OPC : a.redop;  // compile-time for the sum: no op switch inside the loops
     __shared__ T xbuf[256];
     typedef RVec<T, V> VT;
     constexpr int U = 4;  // vectors in flight per lane
@@ -312,7 +329,7 @@ SMR_DEV void reduce_row_body(const RedArgs a, F f) {
     if (live) decompose(a, o, 0, a.NK, ooff);
     T acc[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc[u] = neutral<T>(a.redop);
+    for (int u = 0; u < U; ++u) acc[u] = neutral<T>(redop);
     // U loads in flight per lane: along the inner dim when it is long enough, else over q
     const bool unroll_q = (xend - xbeg) <= (i64)G0 * V;
     auto row_step = [&](const i64 (&off)[U][MAXM], const i64 (&xs)[U], const bool (&ok)[U]) {
@@ -352,7 +369,7 @@ SMR_DEV void reduce_row_body(const RedArgs a, F f) {
                         arg[k] = T{};
                         if (k < nin) arg[k] = in[u][k].v[e];
                     }
-                    acc[u] = red_apply<T>(a.redop, acc[u], f(arg));
+                    acc[u] = red_apply<T>(redop, acc[u], f(arg));
                 }
             }
         }
@@ -397,14 +414,14 @@ SMR_DEV void reduce_row_body(const RedArgs a, F f) {
             }
         }
     }
-    T v = red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3]));
+    T v = red_apply<T>(redop, red_apply<T>(redop, acc[0], acc[1]), red_apply<T>(redop, acc[2], acc[3]));
     const int G = 1 << glog;
-    v = wave_reduce(v, a.redop, G < 64 ? G : 64);
+    v = wave_reduce(v, redop, G < 64 ? G : 64);
     if (G > 64) {  // lanes of one output span several waves
         xbuf[threadIdx.x] = v;
         __syncthreads();
         if (gl == 0)
-            for (int j = 64; j < G; j += 64) v = red_apply<T>(a.redop, v, xbuf[threadIdx.x + j]);
+            for (int j = 64; j < G; j += 64) v = red_apply<T>(redop, v, xbuf[threadIdx.x + j]);
     }
     if (live && gl == 0) {
         if (a.nsplit == 1)
@@ -413,13 +430,21 @@ SMR_DEV void reduce_row_body(const RedArgs a, F f) {
             ((T*)a.partials)[o * a.nsplit + sp] = v;
     }
 }
+template <class T, class F, bool MIXED, int V>
+SMR_DEV void reduce_row_body(const RedArgs a, F f) {
+    if (a.redop == SMR_RED_ADD)
+        reduce_row_impl<T, F, MIXED, V, SMR_RED_ADD>(a, f);
+    else
+        reduce_row_impl<T, F, MIXED, V, -1>(a, f);
+}
 
 // COL: every input is unit-stride (or broadcast) along kept dim 0.  A workgroup = TX lanes along
 // dim 0 (V destination elements each, vector loads) x TY rows of the reduced space (Y0 rows along
 // the inner reduced dim x Y1 along q); the rows are folded through LDS.  sum(A; dims=2) of a
 // column-major matrix is the model case.
-template <class T, class F, bool MIXED, int V>
-SMR_DEV void reduce_col_body(const RedArgs a, F f) {
+template <class T, class F, bool MIXED, int V, int OPC>
+SMR_DEV void reduce_col_impl(const RedArgs& a, F f) {
+    const int redop = (OPC >= 0) ? OPC : a.redop;  // compile-time for the sum: no op switch inside the loops
     __shared__ T xbuf[256 * V];
     typedef RVec<T, V> VT;
     constexpr int U = 4;
@@ -443,7 +468,7 @@ SMR_DEV void reduce_col_body(const RedArgs a, F f) {
     if (a.NK > 1) decompose(a, krest, 1, a.NK, ooff);
     T acc[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = neutral<T>(a.redop);
+    for (int e = 0; e < V; ++e) acc[e] = neutral<T>(redop);
     // U loads in flight per lane: along the inner reduced dim when it is long enough, else over q
     const bool unroll_q = (jend - jbeg) <= (i64)Y0;
     auto col_step = [&](const i64 (&off)[U][MAXM], const bool (&ok)[U]) {
@@ -484,7 +509,7 @@ SMR_DEV void reduce_col_body(const RedArgs a, F f) {
                         arg[k] = T{};
                         if (k < nin) arg[k] = in[u][k].v[e];
                     }
-                    acc[e] = red_apply<T>(a.redop, acc[e], f(arg));
+                    acc[e] = red_apply<T>(redop, acc[e], f(arg));
                 }
             }
         }
@@ -535,7 +560,7 @@ SMR_DEV void reduce_col_body(const RedArgs a, F f) {
         if (ty < h) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                acc[e] = red_apply<T>(a.redop, acc[e], xbuf[(threadIdx.x + h * TX) * V + e]);
+                acc[e] = red_apply<T>(redop, acc[e], xbuf[(threadIdx.x + h * TX) * V + e]);
                 xbuf[threadIdx.x * V + e] = acc[e];
             }
         }
@@ -552,6 +577,13 @@ SMR_DEV void reduce_col_body(const RedArgs a, F f) {
             }
         }
     }
+}
+template <class T, class F, bool MIXED, int V>
+SMR_DEV void reduce_col_body(const RedArgs a, F f) {
+    if (a.redop == SMR_RED_ADD)
+        reduce_col_impl<T, F, MIXED, V, SMR_RED_ADD>(a, f);
+    else
+        reduce_col_impl<T, F, MIXED, V, -1>(a, f);
 }
 
 // second pass of a split partial reduction: LPO = 2^lpolog consecutive lanes fold the nsplit partials
