@@ -284,7 +284,11 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * "tiled_vec", "max_lds_bytes", "tile_order" (orbit-major tile order on/off),
  * "tiled_persist" / "tiled_persist_wpc" / "tiled_persist_min" (persistent pipelined form),
  * "reduce_blocks", "reduce_part_kind" (-1 auto, 0 general, 1 row, 2 col), "reduce_col_txlog",
- * "reduce_part_wgs", "jit" (runtime compilation of f on/off).  Read-only counters through
+ * "reduce_part_wgs", "jit" (runtime compilation of f on/off), "orbit" (ORBIT family on/off),
+ * "orbit_lg" / "orbit_min" / "orbit_few" (orbit tile edge and thresholds), "orbit_pipe" (persistent
+ * pipelined orbits: -1 auto, 0, 1), "nt_store" (non-temporal stores: -1 auto, 0 never, 1 always),
+ * "nt_stream_min", "nt_load" (non-temporal loads of complete reductions: -1 auto, 0, 1).  Experiment
+ * switches: "stream_u", "orbit_lds_min".  Read-only counters through
  * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms".             */
 int smr_set_option(const char* name, int64_t value);
 int64_t smr_get_option(const char* name);
