@@ -491,7 +491,17 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     if (opt.orbit_lds_min > 0) lds = std::max(lds, (size_t)opt.orbit_lds_min);  // experiment: fewer resident workgroups per CU
     a.nlist = (int32_t)o.list.size();
     unsigned grid = (unsigned)o.list.size();
-    if (PIPE) grid = std::min<unsigned>(grid, 256u * (unsigned)std::max<size_t>(1, (160 * 1024) / lds));
+    if (PIPE) {
+        // as many workgroups as the machine holds at once, a multiple of 8 so that a workgroup stays on its XCD's run
+        static const int ncu = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            (void)hipGetLastError();
+            return n;
+        }();
+        const unsigned cap = (unsigned)ncu * (unsigned)std::max<size_t>(1, (160 * 1024) / lds) / 8u * 8u;
+        if (cap >= 8) grid = std::min<unsigned>(grid, cap);
+    }
     if constexpr (is_jit<F>::value) {
         JitLaunch l;
         l.family = "orbit";
