@@ -386,3 +386,29 @@ def test_planner_rules_for_short_dims_big_transposes_and_short_reductions():
     assert "form=col lanes_per_out=1 " in red((100, 90, 80, 7), (3,))           # 7 rows per output: one lane walks them
     assert "form=col lanes_per_out=8 " in red((512, 384, 64), (2,))             # 64 rows: shared through LDS as before
     assert "split=7 " in red((100, 90, 80, 7), (1, 3)) + " "                      # outer (7) x inner (1) cuts together
+
+
+def test_plans_of_the_baseline_configs():
+    """The five BASELINE.json configs land in the kernel family / tile the measurements were taken with."""
+    fn = S.fn
+
+    def cm(dims, dt=np.float64):
+        return S.StridedView(np.zeros(dims, dtype=dt, order="F"))
+
+    n = 32
+    A, B = cm((n,) * 4), cm((n,) * 4)
+    d = S.make_plan(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0)))).describe()            # configs[1]
+    assert "family=tiled" in d and "tile=d0:32,d3:32" in d and "grid=1024" in d, d
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    d = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, A.size, (B,) + tuple(A.permutedims(p) for p in perms)).describe()  # configs[2]
+    assert "family=orbit" in d and "f=add4" in d and "tile=d0:4,d1:4,d2:4,d3:4" in d and "orbits=1044" in d, d
+    M, N = cm((4000, 4000)), cm((4000, 4000))
+    d = S.make_plan(lambda x, y: (x + y) / 2, None, None, (4000, 4000), (N, M, M.adjoint())).describe()        # configs[0]
+    assert "family=orbit" in d and "f=sym" in d and "group=2" in d, d
+    X = S.StridedView(np.zeros(1 << 20, dtype=np.float32))
+    O = S.StridedView(np.zeros(1, dtype=np.float32), (1 << 20,), (0,), 0)
+    d = S.make_plan(fn.abs2, "+", None, (1 << 20,), (O, X)).describe()                                         # configs[3], one shard
+    assert "family=reduce_all" in d and "f=abs2" in d, d
+    E, F_ = cm((2048, 2048), np.float32), cm((2048, 2048), np.float32)
+    d = S.make_plan(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, (2048, 2048), (F_, E)).describe()  # configs[4]
+    assert "family=stream" in d and "f=expr5" in d and "vec=4" in d and "N=1" in d, d
