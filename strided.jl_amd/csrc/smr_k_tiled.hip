@@ -293,7 +293,16 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
                     if constexpr (V == 1) {
                         x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
                     } else {
-#if SMR_TILED_NTL  // experiment (A/B build): non-temporal loads
+#if SMR_TILED_NTL == 2  // experiment (A/B build): system-scope loads (sc0 sc1: served below the L2, which keeps its contents)
+                        {
+                            constexpr int NQ = (int)(sizeof(VT) / 8);
+                            uint64_t qw[NQ > 0 ? NQ : 1];
+#pragma unroll
+                            for (int w = 0; w < NQ; ++w)
+                                qw[w] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __builtin_memcpy(&x[i][r], qw, sizeof(VT));
+                        }
+#elif SMR_TILED_NTL  // experiment (A/B build): non-temporal loads
                         x[i][r] = load_vec_ct<true, VT>(p);
 #else
                         x[i][r] = *reinterpret_cast<const VT*>(p);
