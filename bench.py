@@ -10,9 +10,11 @@ Algorithmic bytes per step = 2 launches x (8 MiB read + 8 MiB written) = 33,554,
 (every distinct array counted once).
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run (one rank per GPU); every rank runs the step on its
-own arrays (independent objects, no data-path collective -> "weak" scaling) and the value is
-the whole-job aggregate.  The reduce path (C4, RCCL all-reduce of the per-shard partial) is
+N > 1: one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE set) the process is a rank;
+started plain with --gpus N > 1 it re-executes itself under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` and the N ranks rendezvous on 127.0.0.1.
+Every rank runs the step on its own arrays (independent objects, no data-path collective -> "weak"
+scaling) and the value is the whole-job aggregate.  The reduce path (C4, RCCL all-reduce of the per-shard partial) is
 reported under "extra".
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside this run) and
@@ -74,7 +76,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(S, budget_s=24.0):
+def cpu_baseline(S, budget_s=24.0, full=True):
     """The reference algorithm's CPU path (oracle: fuse/order/blocks/threaded bisection/kernel
     restated in C++) timed on this box's host cores: the headline 32^4 f64 step, and -- as bounded
     samples -- the other BASELINE.json configs and the README / benchmarks/benchtests.jl extras."""
@@ -116,10 +118,12 @@ def cpu_baseline(S, budget_s=24.0):
     # the other configs (bounded samples; algorithmic bytes = distinct operand footprints)
     configs = {}
 
-    def sample(name, what, problem, algbytes, keep):
+    def sample(name, what, problem, algbytes, keep, only=None):
+        # only=(): the big configs run at the largest thread count (a single-threaded pass over 4 GiB would eat the
+        # whole budget) -- 2 repetitions, min taken
         rows = []
-        for nt in threads:
-            b, r = best_of(problem, nt, 20, min(t_end, time.perf_counter() + budget_s / 16))
+        for nt in (threads if only is None else [threads[-1]]):
+            b, r = best_of(problem, nt, 20 if only is None else 2, min(t_end, time.perf_counter() + budget_s / 16))
             rows.append({"threads": nt, "ms": round(b * 1e3, 3), "GB/s": round(algbytes / b / 1e9, 2), "reps": r})
         configs[name] = {"sample": what, "algorithmic_bytes": algbytes, "best_GB/s": max(r["GB/s"] for r in rows), "by_threads": rows}
         del keep
@@ -138,15 +142,23 @@ def cpu_baseline(S, budget_s=24.0):
     for q, name in (((1, 2, 3, 0), "perm_2341_32^4_f64"), ((2, 3, 0, 1), "perm_3412_32^4_f64")):
         p, k = S.build_problem(lambda x: x, None, None, A.size, (B, A.permutedims(q)), stream=0)
         sample(name, "permutedims!(B, A, %s), 32^4 Float64 (benchmarks/benchtests.jl:40-42)" % (tuple(i + 1 for i in q),), p, 2 * 8 * n ** 4, k)
-    X = S.StridedView(np.asfortranarray((rng.random((4096, 4096, 2)) * 2 - 1).astype(np.float32)))
+    # configs[3] and configs[4] at FULL size; the 4 GiB input is generated slab by slab
+    nz = 64 if full else 2
+    xa = np.empty((4096, 4096, nz), dtype=np.float32, order="F")
+    for z in range(nz):
+        xa[:, :, z] = rng.random((4096, 4096), dtype=np.float32) * 2 - 1
+    X = S.StridedView(xa)
     o = S.StridedView(np.zeros(1, dtype=np.float32), X.size, (0, 0, 0), 0)
     p, k = S.build_problem(fn.abs2, "+", None, X.size, (o, X), stream=0)
-    sample("c4_mapreduce_abs2_f32", "mapreduce(abs2,+) on a 4096x4096x2 Float32 slab (1/32 of configs[3])", p, 4 * 4096 * 4096 * 2 + 4, k)
-    del X
-    Y = S.StridedView(np.asfortranarray(rng.random((8192, 1024)).astype(np.float32)))
+    sample("c4_mapreduce_abs2_f32", "mapreduce(abs2,+) on 4096x4096x%d Float32 (%s configs[3])" % (nz, "full" if full else "1/32 of"),
+           p, 4 * 4096 * 4096 * nz + 4, k, only=() if full else None)
+    del X, xa
+    ny = 8192 if full else 1024
+    Y = S.StridedView(np.asfortranarray(rng.random((8192, ny), dtype=np.float32)))
     Z = Y.similar()
     p, k = S.build_problem(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, Y.size, (Z, Y), stream=0)
-    sample("c5_expr_f32", "B .= A.*exp.(-2A) .+ sin.(A.*A) on 8192x1024 Float32 (1/8 of configs[4])", p, 2 * 4 * 8192 * 1024, k)
+    sample("c5_expr_f32", "B .= A.*exp.(-2A) .+ sin.(A.*A) on 8192x%d Float32 (%s configs[4])" % (ny, "full" if full else "1/8 of"),
+           p, 2 * 4 * 8192 * ny, k, only=() if full else None)
     return {
         "value": round(best["gbs"], 3), "unit": "GB/s", "cores": best["threads"], "kind": "port",
         "cpu_model": _cpu_model(), "host_cores": cores,
@@ -158,6 +170,43 @@ def cpu_baseline(S, budget_s=24.0):
     }
 
 
+def relaunch_as_ranks(ngpus):
+    """`python bench.py --gpus N` started without a launcher: become the launcher (one rank per GPU)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """--dry: no GPU.  The ranks rendezvous over gloo, agree on the world size and rank 0 prints the line's
+    launch-related fields (CPU test of the `--gpus N` path)."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([1.0, float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        seen, ranksum = int(t[0].item()), int(t[1].item())
+    else:
+        seen, ranksum = 1, 0
+    assert seen == world and ranksum == world * (world - 1) // 2
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": seen, "requested_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "backend": "gloo" if world > 1 else "none"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,15 +215,23 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--dry", action="store_true", help="rendezvous only (gloo, no GPU): checks that --gpus N yields N ranks")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch_as_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.dry:
+        return dry_run(args, world, rank)
 
     import numpy as np
     import torch
     import strided_jl_amd as S
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -394,6 +451,8 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
         uid = [D.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         D.comm_init(world, rank, uid[0])
+        rccl_rank, rccl_ranks = D.comm_rank()
+        assert (rccl_rank, rccl_ranks) == (rank, world), "RCCL communicator disagrees with the launcher"
 
         def c4():
             out.zero_()
@@ -426,7 +485,8 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
         "us": round(ms * 1e3, 2), "GB/s_total": round(b / (ms * 1e-3) / 1e9, 1), "shards": world if sharded else 1,
         "frac_of_8TBs_per_gpu": round(b / (world if sharded else 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "rel_err_vs_f64": abs(got - truth) / truth, "plan": desc,
-        "collective": "RCCL ncclAllReduce(1 x f32) issued by libstrided_hip (smr_comm.cpp)" if sharded else "none"}
+        "collective": "RCCL ncclAllReduce(1 x f32) issued by libstrided_hip (smr_comm.cpp)" if sharded else "none",
+        "rccl_ranks": rccl_ranks if sharded else 1}
     return res
 
 

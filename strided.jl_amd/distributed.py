@@ -147,6 +147,13 @@ def comm_init(nranks: int, rank: int, unique_id: bytes | None = None):
         L.check(L.load().smr_comm_init(int(nranks), int(rank), buf, 128))
 
 
+def comm_rank():
+    """(rank, nranks) as the library's RCCL communicator reports them (smr_comm_rank)."""
+    r, n = C.c_int(-1), C.c_int(0)
+    L.check(L.load().smr_comm_rank(C.byref(r), C.byref(n)))
+    return int(r.value), int(n.value)
+
+
 def comm_destroy():
     L.check(L.load().smr_comm_destroy())
 

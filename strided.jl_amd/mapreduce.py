@@ -84,9 +84,24 @@ def _current_stream() -> int:
 _FPROG_CACHE: dict = {}
 
 
+_SCALARS = (int, float, complex, bool, np.generic, type(None))
+
+
+def _code_names(code):
+    """Global / attribute names read by a code object and by every code object nested in it."""
+    names = set(code.co_names)
+    for c in code.co_consts:
+        if hasattr(c, "co_names"):
+            names |= _code_names(c)
+    return names
+
+
 def _closure_key(f):
-    """Hashable identity of a plain Python function INCLUDING the values it closes over (a lambda capturing a
-    scalar that changes between calls must not hit a stale entry); None when that cannot be established."""
+    """Hashable identity of a plain Python function INCLUDING every value it can read: closure cells, defaults
+    and the module globals its code names.  A key is only produced when all of them are immutable scalars (or
+    this package's own function table `fn`); a captured callable, object or container can change behind an
+    unchanged id() -- `lambda x: g(x) + 1` with a fresh `g` per loop trip, `lambda x: x * cfg.alpha` -- so such
+    closures are re-traced on every call (None = do not cache)."""
     code = getattr(f, "__code__", None)
     if code is None or getattr(f, "__self__", None) is not None:
         return None
@@ -96,12 +111,20 @@ def _closure_key(f):
             cells = tuple(c.cell_contents for c in f.__closure__)
         except ValueError:
             return None
-        if not all(isinstance(v, (int, float, complex, bool, np.generic, type(None))) or callable(v) for v in cells):
+        from . import fn as _fn0
+        if not all(isinstance(v, _SCALARS) or v is _fn0 for v in cells):
             return None
-        cells = tuple((type(v).__name__, v if not callable(v) else id(v)) for v in cells)
-    if code.co_names and any(isinstance(f.__globals__.get(n, None), (int, float, complex, np.generic)) for n in code.co_names):
-        return None  # reads a module-level scalar that may change
-    return (code, cells, f.__defaults__)
+        cells = tuple((type(v).__name__, "fn" if v is _fn0 else v) for v in cells)
+    defaults = f.__defaults__ or ()
+    kwdefaults = tuple(sorted((f.__kwdefaults__ or {}).items()))
+    if not all(isinstance(v, _SCALARS) for v in defaults) or not all(isinstance(v, _SCALARS) for _, v in kwdefaults):
+        return None
+    from . import fn as _fn
+    g = f.__globals__
+    for n in _code_names(code):
+        if n in g and g[n] is not _fn:
+            return None  # a module-level scalar, object or function the closure reads: may change between calls
+    return (code, cells, tuple((type(v).__name__, v) for v in defaults), kwdefaults)
 
 
 def _serialized(f, M, dts):
@@ -113,7 +136,10 @@ def _serialized(f, M, dts):
         ck = _closure_key(f)
         if ck is not None:
             key = (ck, M, dts)
-            hit = _FPROG_CACHE.get(key)
+            try:
+                hit = _FPROG_CACHE.get(key)
+            except TypeError:  # an unhashable value slipped into the key
+                key, hit = None, None
             if hit is not None:
                 return hit
     e = E.trace(f, M - 1)

@@ -140,3 +140,27 @@ def test_two_rank_gloo_sharding_and_allreduce():
         assert abs(r["sum"] - r["sum_ref"]) <= 1e-10 * abs(r["sum_ref"])
         assert r["max"] == r["max_ref"]
         assert np.allclose(r["part_all"], r["part_all_ref"], rtol=1e-12)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus N` alone must produce an N-rank job.  --dry stops after the
+    rendezvous (gloo, no GPU) and reports what the ranks agreed on."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "1", "--dry"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["requested_gpus"] == 2 and out["steps"] == 7 and out["warmup"] == 1
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent 1-GPU run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,
+                       timeout=120, env=env2, cwd=root)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)

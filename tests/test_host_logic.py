@@ -202,3 +202,43 @@ def test_plain_array_rule_is_opt_in_and_returns_a_plain_array(monkeypatch):
         set_plain_array_rule(old)
     with pytest.raises(ValueError):
         set_plain_array_rule("cpu")
+
+
+def test_fprog_cache_never_serves_a_stale_program():
+    """the cache keyed captured callables by id() and ignored attributes of global objects.
+    A closure is cached only when everything it can read is an immutable scalar."""
+    import importlib
+    import types
+    MR = importlib.import_module("strided_jl_amd.mapreduce")
+    a = S.StridedView(np.zeros((8, 8), order="F"))
+    b = a.similar()
+
+    def consts_of(f):
+        p, keep = S.build_problem(f, None, None, a.size, (b, a), stream=0)
+        return [p.fconsts[2 * i] for i in range(p.nconsts)]
+
+    def make(alpha):
+        g = lambda x: x * alpha  # noqa: E731
+        return lambda x: g(x) + 1
+
+    got = [consts_of(make(al)) for al in (2.0, 3.0, 5.0)]   # fresh inner function per trip, ids may be reused
+    assert [c[0] for c in got] == [2.0, 3.0, 5.0]
+    cfg = types.SimpleNamespace(alpha=2.0)
+    f = lambda x: x * cfg.alpha  # noqa: E731
+    assert consts_of(f) == [2.0]
+    cfg.alpha = 7.0
+    assert consts_of(f) == [7.0]
+    assert MR._closure_key(f) is None and MR._closure_key(make(1.0)) is None
+    # unhashable / non-scalar defaults: not cached, no TypeError
+    h = lambda x, w=[3.0]: x * w[0]  # noqa: E731
+    assert MR._closure_key(h) is None
+    # module-level scalar read by the closure
+    globals()["_SCALE_FOR_TEST"] = 2.0
+    k = lambda x: x * _SCALE_FOR_TEST  # noqa: E731,F821
+    assert consts_of(k) == [2.0]
+    globals()["_SCALE_FOR_TEST"] = 4.0
+    assert consts_of(k) == [4.0]
+    # the package's own function table is fine (bench / README expressions), nested lambdas are scanned
+    fn = S.fn
+    assert MR._closure_key(lambda x: x * fn.exp(-2 * x)) is not None
+    assert MR._closure_key(lambda x: (lambda y: y * _SCALE_FOR_TEST)(x)) is None  # noqa: F821
