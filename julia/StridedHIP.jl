@@ -19,6 +19,14 @@ import Strided: _mapreduce_fuse!
 const lib = get(ENV, "STRIDED_HIP_LIB", "libstrided_hip.so")
 const MAXN, MAXM = 8, 8
 
+# The reference is synchronous (tasks are `wait`ed, src/mapreduce.jl:214-223), so by default every funnel call ends
+# with a stream synchronisation -- which costs more than a 3 us kernel.  `StridedHIP.async!(true)` drops it: calls
+# are then only ORDERED on the library's stream (results are complete once `synchronize()` returns; `download` /
+# `copyto!(::Array, ::HipBuffer)` always synchronise, so reading a result back is safe either way).
+const ASYNC = Ref(false)
+async!(on::Bool=true) = (ASYNC[] = on; nothing)
+synchronize() = check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))
+
 struct Unsupported <: Exception
     msg::String
 end
@@ -202,7 +210,7 @@ function _mapreduce_fuse!(f, op, initop, dims::Dims, arrays::Tuple{HipView,Varar
             # ranks and all-reduces a split reduced dim; with a single rank it is plain smr_mapreduce.  An `f`
             # without a precompiled functor is compiled for gfx950 on first use (library-side, cached).
             check(ccall((:smr_mapreduce_sharded, lib), Cint, (Ptr{SmrProblem},), p))
-            check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))   # the reference is synchronous
+            ASYNC[] || synchronize()          # the reference is synchronous; async!(true): ordered on the stream only
         end
     catch e
         e isa Unsupported || rethrow()

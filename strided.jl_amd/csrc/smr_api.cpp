@@ -60,6 +60,14 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
     return set_error(SMR_EINVAL, "plan has no kernel family");
 }
 
+unsigned long long* stamp_next(size_t waves) {
+    Options& o = options();
+    if (!o.stamp_base || o.stamp_used + (i64)(2 * waves) > o.stamp_cap) return nullptr;
+    unsigned long long* p = reinterpret_cast<unsigned long long*>((uintptr_t)o.stamp_base) + o.stamp_used;
+    o.stamp_used += (i64)(2 * waves);
+    return p;
+}
+
 static bool g_device_checked = false;
 static int ensure_device() {
     if (g_device_checked) return SMR_OK;
@@ -172,6 +180,16 @@ std::string signature(const smr_problem* p) {
                 break;
             }
         const uint32_t align = (uint32_t)((uintptr_t)p->ops[k].base & 255u);
+        // address class = first operand whose FIRST ELEMENT sits at the same address: the ORBIT / tile-order planners
+        // recognise "views of one buffer" by that address, whatever the base pointers are
+        int32_t acls = k;
+        const char* ak = (const char*)p->ops[k].base + p->ops[k].offset * (int64_t)dtype_size(p->ops[k].dtype);
+        for (int j = 0; j < k; ++j)
+            if ((const char*)p->ops[j].base + p->ops[j].offset * (int64_t)dtype_size(p->ops[j].dtype) == ak) {
+                acls = j;
+                break;
+            }
+        put(&acls, sizeof acls);
         put(&cls, sizeof cls);
         put(&align, sizeof align);
         put(&p->ops[k].offset, sizeof(int64_t));
@@ -492,6 +510,11 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "orbit_few") o.orbit_few = value;
     else if (n == "orbit_pipe") o.orbit_pipe = value;
     else if (n == "orbit_lds_min") o.orbit_lds_min = value;
+    else if (n == "orbit_group") o.orbit_group = value;
+    else if (n == "stamp_base" || n == "stamp_cap" || n == "stamp_used") {  // no plan depends on these: keep the cache
+        (n == "stamp_base" ? o.stamp_base : (n == "stamp_cap" ? o.stamp_cap : o.stamp_used)) = value;
+        return SMR_OK;
+    }
     else if (n == "orbit_lg") o.orbit_lg = value;
     else if (n == "orbit") o.orbit = value;
     else if (n == "max_lds_bytes") o.max_lds_bytes = value;
@@ -536,6 +559,11 @@ int64_t smr_get_option(const char* name) {
     if (n == "orbit_few") return o.orbit_few;
     if (n == "orbit_pipe") return o.orbit_pipe;
     if (n == "orbit_lds_min") return o.orbit_lds_min;
+    if (n == "orbit_group") return o.orbit_group;
+    if (n == "stamp_base") return o.stamp_base;
+    if (n == "stamp_cap") return o.stamp_cap;
+    if (n == "stamp_used") return o.stamp_used;
+    if (n == "stamp_build") return SMR_STAMP;
     if (n == "orbit_lg") return o.orbit_lg;
     if (n == "orbit") return o.orbit;
     if (n == "max_lds_bytes") return o.max_lds_bytes;

@@ -16,6 +16,38 @@ namespace smr {
 
 #define SMR_DEV __device__ __forceinline__
 
+// ---- device-side wall-clock stamps (debug build: make stamp -> libstrided_hip_stamp.so, -DSMR_STAMP=1) --------
+// Profiler-independent timing of a launch: every wave records s_memrealtime (100 MHz, one clock for the whole
+// device) at entry and after its last store has been acknowledged, into its own 16-byte slot of the region the
+// launcher reserved for this launch (smr_set_option "stamp_base" / "stamp_cap" / "stamp_used"; tools/device_span.py
+// turns the slots into first-start, last-end, cadence and inter-launch gap).  The product build compiles none of it.
+#ifndef SMR_STAMP
+#define SMR_STAMP 0
+#endif
+#if SMR_STAMP && !defined(SMR_JIT)
+#define SMR_STAMP_PARAM , unsigned long long* smr_stamps
+#define SMR_STAMP_ARG(grid, block) , ::smr::stamp_next((size_t)(grid) * (((size_t)(block) + 63) / 64))
+#define SMR_STAMP_BEGIN const unsigned long long smr_t0 = (unsigned long long)wall_clock64();
+#define SMR_STAMP_END ::smr::stamp_end(smr_stamps, smr_t0);
+#else
+#define SMR_STAMP_PARAM
+#define SMR_STAMP_ARG(grid, block)
+#define SMR_STAMP_BEGIN
+#define SMR_STAMP_END
+#endif
+#if SMR_STAMP && !defined(SMR_JIT)
+__device__ __forceinline__ void stamp_end(unsigned long long* stamps, unsigned long long t0) {
+    if (!stamps) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = (unsigned long long)wall_clock64();
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6)) * 2;
+        o[0] = t0;
+        o[1] = t1;
+    }
+}
+#endif
+
 template <class R>
 struct alignas(2 * sizeof(R)) cplx {
     R re, im;

@@ -207,9 +207,12 @@ struct Options {
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
     i64 orbit_min = 150;     // pick the largest tile edge that still yields this many orbits (measured: tools/orbit_sweep.py)
     i64 orbit_pipe = -1;     // persistent pipelined ORBIT form: 0 never, 1 whenever there are more orbits than CUs, -1 = when LDS leaves one workgroup per CU
+    i64 orbit_group = 2;     // super-cell edge (tiles per tiled dim) of the ORBIT work list: the orbits of one super-cell run
+                             // next to each other on one XCD
+    i64 stamp_base = 0, stamp_cap = 0, stamp_used = 0;  // SMR_STAMP builds: device buffer of 8-byte words for wave stamps
     i64 orbit_lds_min = 0;   // experiment: request at least this much LDS per ORBIT workgroup (limits residency)
     i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
-    i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes and
+    i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes (default 0: all) and
                              // TILED tiles that write whole 128-byte lines (profiles/r02_nt_store_ab.txt: configs[4]
                              // 91.8 -> 80.2 us, 32^4 permutedims! 3.36 -> 2.76 us); ORBIT's 32-byte runs get slower (4.8 -> 6.3 us)
     i64 nt_stream_min = 0;
@@ -218,6 +221,9 @@ struct Options {
     i64 tile_lg[MAXN] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per canonical dim log2 tile extent override
 };
 Options& options();
+
+// SMR_STAMP builds: the region (2 words per wave) of the next launch, or nullptr when no buffer is set / it is full
+unsigned long long* stamp_next(size_t waves);
 
 int canonicalise(const smr_problem* p, Canon& c);
 int make_plan(const smr_problem* p, Plan& plan);

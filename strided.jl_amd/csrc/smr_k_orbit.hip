@@ -310,8 +310,10 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
 
 #ifndef SMR_JIT
 template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE>
-__global__ void __launch_bounds__(1024) k_orbit_map(const OrbitArgs a, F f) {
+__global__ void __launch_bounds__(1024) k_orbit_map(const OrbitArgs a, F f SMR_STAMP_PARAM) {
+    SMR_STAMP_BEGIN
     orbit_map_body<T, F, V, NREP, NG, OWN0, PIPE>(a, f);
+    SMR_STAMP_END
 }
 
 // XOR-fold swizzle l ^ (((l >> s1) ^ (l >> s2)) & mask): parameters picked per plan by counting the
@@ -523,7 +525,7 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a, f);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a, f SMR_STAMP_ARG(grid, block));
         return check_launch("k_orbit_map");
     }
 }

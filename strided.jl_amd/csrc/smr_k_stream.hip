@@ -142,8 +142,10 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
 
 #ifndef SMR_JIT
 template <class T, class F, bool MIXED, int V, int U, bool FLAT>
-__global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f) {
+__global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f SMR_STAMP_PARAM) {
+    SMR_STAMP_BEGIN
     stream_map_body<T, F, MIXED, V, U, FLAT>(a, f);
+    SMR_STAMP_END
 }
 
 template <class T, class F, bool MIXED, int V, int UOVR = 0>
@@ -162,8 +164,11 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.M = c.M;
     a.n0v = c.dims[0] / V;
     {
-        // Streaming outputs of at least half the Infinity Cache (256 MiB) bypass it: caching them would only evict the
-        // inputs.  Measured on configs[4] (8192^2 f32, 256 MiB in / out, tools/c5_proto.hip): 91 -> 74 us.
+        // Vector stores of this family are non-temporal at EVERY size (nt_stream_min = 0).  Measured
+        // (profiles/r02_nt_store_ab.txt): configs[4] 8192^2 f32 91.8 -> 80.2 us, 2048^2 copy 5.38 -> 3.88 us, and a
+        // non-temporal producer never slowed the kernel that reads its output (producer -> consumer pairs at 32^4,
+        // 64^4, 2048^2: 9.88 / 101.9 / 12.7 -> 9.55 / 91.5 / 10.6 us) -- the dirty lines leave during the kernel
+        // instead of at its end.  "nt_stream_min" raises the threshold for callers who want small outputs cached.
         const Options& o = options();
         const i64 outbytes = c.nout * (i64)c.esize[0];
         a.nts = (o.nt_store > 0 || (o.nt_store < 0 && outbytes >= o.nt_stream_min)) ? 1 : 0;
@@ -199,9 +204,9 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
         if (a.txlog == 8)
-            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, true>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
+            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, true>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
         else
-            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, false>), dim3((unsigned)grid), dim3(256), 0, s, a, f);
+            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, false>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
         return check_launch("k_stream_map");
     }
 }

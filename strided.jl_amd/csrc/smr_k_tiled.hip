@@ -599,13 +599,17 @@ SMR_DEV void tiled_map_pipe_body(const TiledArgs<WIDE> a, F f) {
 
 #ifndef SMR_JIT
 template <class T, class F, bool MIXED, bool WIDE, int V, int MODE, int THRLOG>
-__global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE> a, F f) {
+__global__ void __launch_bounds__(1 << THRLOG) k_tiled_map(const TiledArgs<WIDE> a, F f SMR_STAMP_PARAM) {
+    SMR_STAMP_BEGIN
     tiled_map_body<T, F, MIXED, WIDE, V, MODE, THRLOG>(a, f);
+    SMR_STAMP_END
 }
 
 template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
-__global__ void __launch_bounds__(1 << THRLOG) k_tiled_map_pipe(const TiledArgs<WIDE> a, F f) {
+__global__ void __launch_bounds__(1 << THRLOG) k_tiled_map_pipe(const TiledArgs<WIDE> a, F f SMR_STAMP_PARAM) {
+    SMR_STAMP_BEGIN
     tiled_map_pipe_body<T, F, MIXED, WIDE, V, THRLOG>(a, f);
+    SMR_STAMP_END
 }
 
 // ---- LDS swizzle ------------------------------------------------------------------------------------
@@ -748,7 +752,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                         if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
                     }
-                    hipLaunchKernelGGL(kern, dim3(pgrid), dim3(1u << THRLOG), lds, s, ka, f);
+                    hipLaunchKernelGGL(kern, dim3(pgrid), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(pgrid, 1u << THRLOG));
                     return check_launch("k_tiled_map_pipe");
                 }
             }
@@ -757,7 +761,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
             }
-            hipLaunchKernelGGL(kern, dim3(grid_), dim3(1u << THRLOG), lds, s, ka, f);
+            hipLaunchKernelGGL(kern, dim3(grid_), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(grid_, 1u << THRLOG));
             return check_launch("k_tiled_map");
         }
     };

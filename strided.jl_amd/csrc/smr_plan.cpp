@@ -599,7 +599,9 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
     int best = -1;
     for (int l = maxbits / nu; l >= 1; --l) {
         if (n0 & (((i64)1 << l) - 1)) continue;
-        if ((size_t)o.ng * ((size_t)es << (l * nu)) > (size_t)128 * 1024) continue;
+        // LDS: the launch pads a group of order 3 to four slots; "max_lds_bytes" can raise (never lower) the 128 KiB cap
+        const size_t slots = o.ng == 3 ? 4 : (size_t)o.ng;
+        if (slots * ((size_t)es << (l * nu)) > std::min<size_t>((size_t)160 * 1024, std::max<size_t>((size_t)opt.max_lds_bytes, (size_t)128 * 1024))) continue;
         if (((i64)es << l) < 32 || l < vlog) continue;  // runs of at least 32 bytes
         if (l * nu < 8) continue;                        // at least 256 elements per tile (128 lanes x 16 B)
         if (opt.orbit_lg >= 0) {
@@ -631,7 +633,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
     if (o.ntiles_total > ((i64)1 << 22)) return false;
     // 16-byte accesses: every non-unit stride a multiple of the vector (alignment is re-checked at launch)
     o.vec = vec_ok ? vmax : 1;
-    o.lds_bytes = (size_t)o.ng * ((size_t)es << o.tilelog);
+    o.lds_bytes = (o.ng == 3 ? 4 : (size_t)o.ng) * ((size_t)es << o.tilelog);
     {  // 32-bit byte offsets inside a tile
         long double span = 0;
         for (int d = 0; d < c.N; ++d) span += (long double)(((i64)1 << o.lg[d]) - 1) * (long double)s[d] * es;
@@ -654,7 +656,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
     i64 ncell[MAXN], cells = 1;
     int sub[MAXN];
     for (int d = 0; d < c.N; ++d) {
-        sub[d] = (o.lg[d] > 0 && o.ntiles[d] > 1) ? 2 : 1;
+        sub[d] = (o.lg[d] > 0 && o.ntiles[d] > 1) ? (int)std::max<i64>(1, std::min<i64>(opt.orbit_group, o.ntiles[d])) : 1;
         ncell[d] = (o.ntiles[d] + sub[d] - 1) / sub[d];
         cells *= ncell[d];
     }

@@ -7,6 +7,48 @@ import sqlite3
 import sys
 
 
+def summarise_by_grid(path):
+    """Per (kernel, grid size): dispatch count and durations; PMC values per dispatch, and -- for counters that are
+    reported per hardware instance (no _sum suffix: one row per XCD / channel) -- the spread over the instances."""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    print(f"== {path}")
+    q = f"""select s.kernel_name, d.grid_size_x, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.workgroup_size_x)
+            from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name, d.grid_size_x order by sum(d.end-d.start) desc"""
+    print(f"{'calls':>6} {'avg_ns':>12} {'min_ns':>12} {'grid':>11} {'wg':>5}  kernel")
+    for r in cur.execute(q):
+        print(f"{r[2]:6d} {r[3]:12.0f} {r[4]:12d} {r[1]:11d} {r[5]:5d}  {r[0][:90]}")
+    pm = [t for t in tabs if t.startswith("rocpd_pmc_event")]
+    pi = [t for t in tabs if t.startswith("rocpd_info_pmc")]
+    if not (pm and pi):
+        return
+    q = f"""select s.kernel_name, d.grid_size_x, p.name, e.event_id, e.value
+            from {pm[0]} e join {pi[0]} p on e.pmc_id = p.id
+            join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id"""
+    acc = {}
+    try:
+        for name, grid, pname, ev, val in cur.execute(q):
+            acc.setdefault((name, grid, pname), {}).setdefault(ev, []).append(val)
+    except sqlite3.Error as e:
+        print("   (pmc query failed:", e, ")")
+        return
+    print("-- PMC per dispatch (mean over the dispatches); instance spread for per-instance counters")
+    for (name, grid, pname), evs in sorted(acc.items()):
+        if grid < 1024:
+            continue
+        totals = [sum(v) for v in evs.values()]
+        line = f"   grid {grid:10d} {pname:44s} {sum(totals) / len(totals):18.1f}"
+        inst = max(len(v) for v in evs.values())
+        if inst > 1:
+            v = sorted(list(evs.values())[-1])
+            mean = sum(v) / len(v)
+            line += f"   [{inst} instances: min {v[0]:.0f} median {v[len(v) // 2]:.0f} max {v[-1]:.0f}, max/mean {v[-1] / mean if mean else 0:.2f}]"
+        print(line + f"   {name[:40]}")
+
+
 def summarise(path):
     con = sqlite3.connect(path)
     cur = con.cursor()
@@ -74,7 +116,11 @@ def histogram(path):
 
 args = sys.argv[1:]
 hist = "--hist" in args
-for p in [a for a in args if a != "--hist"]:
+bygrid = "--by-grid" in args
+for p in [a for a in args if a not in ("--hist", "--by-grid")]:
+    if bygrid:
+        summarise_by_grid(p)
+        continue
     summarise(p)
     if hist:
         histogram(p)
