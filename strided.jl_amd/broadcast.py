@@ -51,14 +51,15 @@ class Ref:
 
 # StridedArrayStyle x DefaultArrayStyle -> DefaultArrayStyle (src/broadcast.jl:11-18): a broadcast that mixes a
 # StridedView with a plain array leaves the strided path in the reference -- Base broadcasts it on the CPU and the
-# result is a plain Array (test/othertests.jl:64).  There is no CPU path here.  The default is to refuse; the
-# opt-in "upload" copies the plain array to the views' memory space, computes there and hands an out-of-place
-# result back as a plain host array (same values, same result type as the reference).
-_PLAIN_RULE = "error"
+# result is a plain Array (test/othertests.jl:64) -- it never throws.  There is no CPU path here, so the default
+# rule "upload" copies the plain array to the views' memory space, computes there and hands an out-of-place
+# result back as a plain host array (same values, same result type as the reference; round 3: this became the
+# default, rounds 1-2 raised).  "error" is the strict mode for callers who want to see accidental host arrays.
+_PLAIN_RULE = "upload"
 
 
 def set_plain_array_rule(rule: str) -> str:
-    """'error' (default) or 'upload'.  Returns the previous rule."""
+    """'upload' (default) or 'error'.  Returns the previous rule."""
     global _PLAIN_RULE
     if rule not in ("error", "upload"):
         raise ValueError("plain-array rule must be 'error' or 'upload'")
@@ -78,9 +79,8 @@ def _check_leaf(a):
     if _is_plain(a):
         if _PLAIN_RULE == "upload":
             return
-        raise TypeError("broadcast mixes a StridedView with a plain array; the reference would fall back to "
-                        "Base broadcasting on the CPU -- wrap the array in StridedView, or opt in to "
-                        "set_plain_array_rule('upload')")
+        raise TypeError("broadcast mixes a StridedView with a plain array (strict mode: set_plain_array_rule('error') "
+                        "is active); wrap the array in StridedView or return to set_plain_array_rule('upload')")
     raise TypeError(f"cannot broadcast over {type(a)}")
 
 

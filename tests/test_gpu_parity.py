@@ -364,7 +364,7 @@ def test_every_kernel_family_is_exercised():
 
 
 def test_plain_array_rule_upload_on_the_device():
-    """a5 opt-in: a broadcast that mixes device views with a plain host array uploads the array, runs on the GPU and
+    """a5 (default rule 'upload'): a broadcast that mixes device views with a plain host array uploads the array, runs on the GPU and
     hands the out-of-place result back as a plain array (src/broadcast.jl:11-18, test/othertests.jl:64)."""
     import torch
     from strided_jl_amd.broadcast import set_plain_array_rule
@@ -376,8 +376,12 @@ def test_plain_array_rule_upload_on_the_device():
         B2 = S.StridedView(torch.from_numpy(R2).cuda()).permutedims((1, 0))
         B3 = S.StridedView(torch.from_numpy(R3).cuda()).permutedims((2, 0, 1))
         A3 = B3.toarray()
-        with pytest.raises(TypeError):
-            B2.adjoint() * A3
+        old = set_plain_array_rule("error")
+        try:
+            with pytest.raises(TypeError):
+                B2.adjoint() * A3
+        finally:
+            set_plain_array_rule(old)
         old = set_plain_array_rule("upload")
         try:
             got = (B2.adjoint() * A3 - fn.max(fn.abs(B1), fn.real(B3))).materialize()

@@ -114,8 +114,9 @@ def test_errors_are_raised_before_the_funnel():
         S.mul_(F(np.zeros((3, 3))), a, a)
     with pytest.raises(ValueError, match="unknown reduction"):
         S.mapreduce(lambda x: x, (lambda p, q: p - q), a)
+    assert (a + np.zeros((3, 4))) is not None   # StridedArrayStyle x DefaultArrayStyle: no error (rule 'upload', a5)
     with pytest.raises(TypeError):
-        a + np.zeros((3, 4))   # StridedArrayStyle x DefaultArrayStyle has no device path
+        a + [1, 2, 3]                           # not broadcastable at all
     # zero-size map! returns the destination untouched without touching the engine
     z = F(np.zeros((0, 4)))
     assert S.map_(lambda x: x, z, z) is z
@@ -164,10 +165,11 @@ def test_traced_f_programs_are_cached_per_closure_including_captured_values():
     assert len(MR._FPROG_CACHE) == n + 1
 
 
-def test_plain_array_rule_is_opt_in_and_returns_a_plain_array(monkeypatch):
+def test_plain_array_rule_uploads_by_default_and_returns_a_plain_array(monkeypatch):
     """a5 (src/broadcast.jl:11-18, test/othertests.jl:64): Strided x plain Array leaves the strided path in the
-    reference and yields a plain Array.  Default here: TypeError; opt-in 'upload': computed on the views' memory
-    space, out-of-place result handed back as a plain host array, in-place destination stays a StridedView."""
+    reference and yields a plain Array, never an error.  Default here ('upload'): computed on the views' memory
+    space, out-of-place result handed back as a plain host array, in-place destination stays a StridedView;
+    strict mode 'error' raises TypeError."""
     import sys
 
     import oraclelib
@@ -183,12 +185,16 @@ def test_plain_array_rule_is_opt_in_and_returns_a_plain_array(monkeypatch):
     R1, R2, R3 = rng.random(10), rng.random((10, 10)), rng.random((10, 10, 10))
     B1, B2, B3 = F(R1), F(R2).permutedims((1, 0)), F(R3).permutedims((2, 0, 1))
     A3 = B3.toarray()
-    with pytest.raises(TypeError, match="set_plain_array_rule"):
-        B2.adjoint() * A3
     from strided_jl_amd.broadcast import set_plain_array_rule
+    old = set_plain_array_rule("error")
+    try:
+        assert old == "upload"                                 # the default follows the reference: no error
+        with pytest.raises(TypeError, match="set_plain_array_rule"):
+            B2.adjoint() * A3
+    finally:
+        set_plain_array_rule(old)
     old = set_plain_array_rule("upload")
     try:
-        assert old == "error"
         got = (B2.adjoint() * A3 - fn.max(fn.abs(B1), fn.real(B3))).materialize()
         assert isinstance(got, np.ndarray)                     # "isa Array"
         a1, a2 = B1.toarray(), B2.toarray()
