@@ -493,6 +493,7 @@ int smr_set_option(const char* name, int64_t value) {
     if (n == "force_family") o.force_family = value;
     else if (n == "tile_log2") o.tile_log2 = value;
     else if (n == "tile_order") o.tile_order = value;
+    else if (n == "tile_block") o.tile_block = value;
     else if (n == "reduce_blocks") o.reduce_blocks = value;
     else if (n == "jit") o.jit = value;
     else if (n == "tiled_persist") o.tiled_persist = value;
@@ -511,6 +512,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "orbit_pipe") o.orbit_pipe = value;
     else if (n == "orbit_lds_min") o.orbit_lds_min = value;
     else if (n == "orbit_group") o.orbit_group = value;
+    else if (n == "orbit_wgs") o.orbit_wgs = value;
     else if (n == "stamp_base" || n == "stamp_cap" || n == "stamp_used") {  // no plan depends on these: keep the cache
         (n == "stamp_base" ? o.stamp_base : (n == "stamp_cap" ? o.stamp_cap : o.stamp_used)) = value;
         return SMR_OK;
@@ -538,6 +540,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "force_family") return o.force_family;
     if (n == "tile_log2") return o.tile_log2;
     if (n == "tile_order") return o.tile_order;
+    if (n == "tile_block") return o.tile_block;
     if (n == "reduce_blocks") return o.reduce_blocks;
     if (n == "jit") return o.jit;
     if (n == "tiled_persist") return o.tiled_persist;
@@ -560,6 +563,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "orbit_pipe") return o.orbit_pipe;
     if (n == "orbit_lds_min") return o.orbit_lds_min;
     if (n == "orbit_group") return o.orbit_group;
+    if (n == "orbit_wgs") return o.orbit_wgs;
     if (n == "stamp_base") return o.stamp_base;
     if (n == "stamp_cap") return o.stamp_cap;
     if (n == "stamp_used") return o.stamp_used;

@@ -192,6 +192,7 @@ struct Options {
     i64 force_family = 0;
     i64 tile_log2 = 0;       // 0 = planner default
     i64 tile_order = 1;      // orbit-major tile order for inputs that are permuted views of one buffer
+    i64 tile_block = 0;      // distinct arrays with >= 3 unit axes: tiles in compact blocks of this many per dim (0 = natural order)
     i64 jit = 1;             // compile unrecognised f-programs with hiprtc (0 = always interpret)
     i64 reduce_col_txlog = 5;   // COL form: log2 of the lanes along kept dim 0 (cap)
     i64 reduce_part_wgs = 4096; // partial reductions with few outputs are split until about this many workgroups run
@@ -210,6 +211,7 @@ struct Options {
     i64 orbit_group = 2;     // super-cell edge (tiles per tiled dim) of the ORBIT work list: the orbits of one super-cell run
                              // next to each other on one XCD
     i64 stamp_base = 0, stamp_cap = 0, stamp_used = 0;  // SMR_STAMP builds: device buffer of 8-byte words for wave stamps
+    i64 orbit_wgs = 0;       // persistent ORBIT form: cap on the number of workgroups (0 = as many as the machine holds at once)
     i64 orbit_lds_min = 0;   // experiment: request at least this much LDS per ORBIT workgroup (limits residency)
     i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
     i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes (default 0: all) and

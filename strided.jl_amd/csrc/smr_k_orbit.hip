@@ -195,6 +195,16 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
             for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(goff[r]));
             asm volatile("" : "+v"(tidp));
         }
+        // the NEXT orbit's origin row is requested before the slots are parked (unconditionally, on a clamped index:
+        // no branch in front of the LDS stores), so that it has arrived when the barrier opens and the next loads
+        // leave right behind it
+        i64 norg[NG];
+        bool nlive = false, more = false;
+        if constexpr (PIPE) {
+            wg += gridDim.x;
+            more = wg < (uint32_t)a.nlist;
+            load_row(more ? wg : (uint32_t)a.nlist - 1u, norg, nlive);
+        }
         // ---- park the slots in LDS ---------------------------------------------------------------------------
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -207,14 +217,9 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
             }
         }
         __syncthreads();
-        i64 norg[NG];
-        bool nlive = false, more = false;
         VT xn[NG][NREP];
         if constexpr (PIPE) {
-            wg += gridDim.x;
-            more = wg < (uint32_t)a.nlist;
             if (more) {
-                load_row(wg, norg, nlive);
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -225,7 +230,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
         // ---- outputs of every slot: all LDS reads of a repeat are issued before the first use ----------------
         // (the one-shot form batches the reads of all slots: one LDS latency per repeat; the persistent form has the
         // next orbit's loads in registers as well and batches per slot)
-        constexpr int GB = PIPE ? 1 : NG;
+        constexpr int GB = (PIPE && NREP > 1) ? 1 : NG;
 #pragma unroll
         for (int r = 0; r < NREP; ++r) {
 #pragma unroll
@@ -503,6 +508,7 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         }();
         const unsigned cap = (unsigned)ncu * (unsigned)std::max<size_t>(1, (160 * 1024) / lds) / 8u * 8u;
         if (cap >= 8) grid = std::min<unsigned>(grid, cap);
+        if (opt.orbit_wgs >= 8) grid = std::min<unsigned>(grid, (unsigned)opt.orbit_wgs / 8u * 8u);
     }
     if constexpr (is_jit<F>::value) {
         JitLaunch l;

@@ -503,6 +503,49 @@ static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
 }
 
 
+// Block order for inputs that are DISTINCT arrays with different unit axes (no orbit structure to exploit): the
+// tiles that run at the same time form compact blocks (blk tiles along every tiled dim) instead of a slab that is
+// long along dim 0 only, so that every operand -- whatever its unit axis -- has its 32-/64-byte runs completed to
+// longer contiguous pieces by tiles that are in flight together (DRAM row locality; option "tile_block").
+static void plan_block_order(const Canon& c, TilePlan& t, const int* lg, int blk) {
+    if (blk < 2 || t.grid < 64 || t.grid > ((i64)1 << 22)) return;
+    i64 nb[MAXN], blocks = 1, tmul[MAXN], acc = 1;
+    int tiled[MAXN], ntd = 0;
+    for (int d = 0; d < c.N; ++d) {
+        tmul[d] = acc;
+        acc *= t.ntiles[d];
+        const bool is_tiled = lg[d] > 0 || true;  // untiled dims (tile extent 1) are blocked as well: their tiles are adjacent rows
+        if (is_tiled) tiled[ntd++] = d;
+        nb[d] = (t.ntiles[d] + blk - 1) / blk;
+        blocks *= nb[d];
+    }
+    (void)tiled;
+    std::vector<uint32_t> list;
+    list.reserve((size_t)t.grid);
+    for (i64 b = 0; b < blocks; ++b) {
+        i64 bc[MAXN], r = b, lo[MAXN], n[MAXN], cnt = 1;
+        for (int d = 0; d < c.N; ++d) {
+            bc[d] = r % nb[d];
+            r /= nb[d];
+            lo[d] = bc[d] * blk;
+            n[d] = std::min<i64>(blk, t.ntiles[d] - lo[d]);
+            cnt *= n[d];
+        }
+        for (i64 q = 0; q < cnt; ++q) {
+            i64 rr = q, id = 0;
+            for (int d = 0; d < c.N; ++d) {
+                id += (lo[d] + rr % n[d]) * tmul[d];
+                rr /= n[d];
+            }
+            list.push_back((uint32_t)id);
+        }
+    }
+    if ((i64)list.size() != t.grid) return;
+    while (list.size() % 8) list.push_back(0xffffffffu);
+    t.ord = std::move(list);
+    t.ord_groups = (int)blocks;
+}
+
 // ---- orbit planning (FAM_ORBIT) ----------------------------------------------------------------------
 // B .= (A .+ A')./2, the 4-way permuted sum, ... : every input is a permuted view of ONE buffer.  The
 // classic tiled kernel reads that buffer once per view (through L1: 4 x 8 MiB for the 4-way sum at 32^4);
@@ -883,6 +926,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     t.ord.clear();
     t.ord_groups = 0;
     if (o.tile_order) plan_tile_order(c, t, lg);
+    if (t.ord.empty() && o.tile_block >= 2 && na >= 3) plan_block_order(c, t, lg, (int)o.tile_block);
     return true;
 }
 

@@ -74,7 +74,7 @@ __device__ __forceinline__ void stamp_end(u64* stamps, u64 t0, int waves) {
 // ---- orbit kernel: MODE 0 sum; 4: loads + exchange + adds, stores only of impossible values (read side);
 // 5: stores only (write side, values from the lane id) -------------------------------------------------------
 template <int L0, int L1, int L2, int L3, int NTLOG, int SWZ, bool NTS, int MODE, int Q, bool ST>
-__global__ void __launch_bounds__(Q << NTLOG) k_orb(const double* __restrict__ A, double* __restrict__ B, int nlog, const uint32_t* __restrict__ boxes,
+__global__ void __launch_bounds__(Q << NTLOG) k_orb(const double* __restrict__ A, double* __restrict__ B, int n, const uint32_t* __restrict__ boxes,
                                                    u64* __restrict__ stamps) {
     constexpr int LG[4] = {L0, L1, L2, L3};
     constexpr int TL = L0 + L1 + L2 + L3;
@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(Q << NTLOG) k_orb(const double* __restrict__ A
     static_assert(NREP >= 1, "box too small for the workgroup");
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const u64 t0 = ST ? (u64)wall_clock64() : 0;
+    const uint32_t st[4] = {1u, (uint32_t)n, (uint32_t)n * (uint32_t)n, (uint32_t)n * (uint32_t)n * (uint32_t)n};
     const uint32_t tid = threadIdx.x & (NT - 1);
     const uint32_t sub = threadIdx.x >> NTLOG;
     double* lds = lds_all + ((size_t)sub << (TL + 2));
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(Q << NTLOG) k_orb(const double* __restrict__ A
             for (int d = 0; d < 4; ++d) {
                 const int sl = LG[(d - k) & 3];
                 const uint32_t j = (e >> sh) & ((1u << sl) - 1u);
-                off += (o[(d - k) & 3] + j) << (nlog * d);
+                off += (o[(d - k) & 3] + j) * st[d];
                 sh += sl;
             }
             goff[k][r] = off;
@@ -249,6 +250,7 @@ struct Ctx {
     int reps;
     u64* dstamps;
     size_t stamp_cap;  // u64 words
+    bool verify = true;
 };
 
 // Launch `reps` times inside one graph (each launch gets its own stamp region when `stamped`), replay, time with
@@ -346,6 +348,7 @@ static void print_span(const char* what, const SpanStats& plain, const SpanStats
 // Work list: roots = coarse cubes (edge 2^ml) whose coordinate is the lexicographically smallest of its rotations,
 // visited super-cell by super-cell (gs coarse cubes per dim); every root contributes all its sub-boxes one after
 // the other; the list is cut into 8 contiguous runs, run x executed by the workgroups b = 8 * slot + x (XCD x).
+static int g_order = 0;  // 0: super-cell grouped, one contiguous run per XCD; 1: the same list dealt round-robin to the XCDs; 2: shuffled, runs per XCD
 static std::vector<uint32_t> grouped_boxes(int n, const int* lg, int group_log, int Q) {
     const int ml = *std::max_element(lg, lg + 4);
     const int nc = n >> ml;
@@ -383,8 +386,19 @@ static std::vector<uint32_t> grouped_boxes(int n, const int* lg, int group_log, 
                                         list.push_back(p);
                                     }
                     }
+    if (g_order == 2) {
+        uint64_t rs = 88172645463325252ull;
+        for (size_t i = list.size(); i > 1; --i) {
+            rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+            std::swap(list[i - 1], list[rs % i]);
+        }
+    }
     // Q consecutive entries form one workgroup
     while (list.size() % Q) list.push_back(0xffffffffu);
+    if (g_order == 1) {
+        while (list.size() % (8 * Q)) list.push_back(0xffffffffu);
+        return list;
+    }
     const size_t nwg = list.size() / Q;
     const size_t cs = (nwg + 7) / 8;
     std::vector<uint32_t> out(cs * 8 * Q, 0xffffffffu);
@@ -423,21 +437,21 @@ static void run_orb(Ctx& c, bool stamps = false) {
         CK(hipFuncSetAttribute((const void*)kern_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     CK(hipMemsetAsync(c.dB, 0xff, c.N * 8, c.st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Q << NTLOG), lds, c.st, c.dA, c.dB, c.nlog, db, (u64*)nullptr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Q << NTLOG), lds, c.st, c.dA, c.dB, c.n, db, (u64*)nullptr);
     CK(hipGetLastError());
     CK(hipStreamSynchronize(c.st));
     bool ok = true;
-    if (MODE == 0) ok = check(c, "orbit");
+    if (MODE == 0 && c.verify) ok = check(c, "orbit");
     const unsigned waves = grid * ((Q << NTLOG) >> 6);
-    const SpanStats p = time_graph(c, c.reps, waves, false, [&](u64* s) { hipLaunchKernelGGL(kern, dim3(grid), dim3(Q << NTLOG), lds, c.st, c.dA, c.dB, c.nlog, db, s); });
+    const SpanStats p = time_graph(c, c.reps, waves, false, [&](u64* s) { hipLaunchKernelGGL(kern, dim3(grid), dim3(Q << NTLOG), lds, c.st, c.dA, c.dB, c.n, db, s); });
     static const char* mn[] = {"orbit", "?", "?", "?", "orbit-readside", "orbit-writeside"};
     char what[160];
-    snprintf(what, sizeof what, "%-15s box %2dx%2dx%2dx%2d Q %d grp %d lanes %4d swz %d nts %d wgs %6u lds %6zu", mn[MODE], 1 << L0, 1 << L1, 1 << L2, 1 << L3, Q, 1 << GROUP,
+    snprintf(what, sizeof what, "%-15s ord %d box %2dx%2dx%2dx%2d Q %d grp %d lanes %4d swz %d nts %d wgs %6u lds %6zu", mn[MODE], g_order, 1 << L0, 1 << L1, 1 << L2, 1 << L3, Q, 1 << GROUP,
              Q << NTLOG, SWZ, (int)NTS, grid, lds);
     printf("n=%3d %s : %9.2f us  %7.1f GB/s  (%.1f %% of 8 TB/s) %s\n", c.n, what, p.us_events, 2.0 * c.N * 8 / p.us_events * 1e-3, 2.0 * c.N * 8 / p.us_events * 1e-3 / 80.0,
            ok ? "ok" : "WRONG");
     if (stamps) {
-        const SpanStats s = time_graph(c, c.reps, waves, true, [&](u64* sp) { hipLaunchKernelGGL(kern_st, dim3(grid), dim3(Q << NTLOG), lds, c.st, c.dA, c.dB, c.nlog, db, sp); });
+        const SpanStats s = time_graph(c, c.reps, waves, true, [&](u64* sp) { hipLaunchKernelGGL(kern_st, dim3(grid), dim3(Q << NTLOG), lds, c.st, c.dA, c.dB, c.n, db, sp); });
         print_span(mn[MODE], p, s);
     }
     fflush(stdout);
@@ -478,12 +492,12 @@ static void run_forkjoin(Ctx& c) {
         for (int i = 0; i < reps; ++i) {
             if (variant == 0) {  // in order on one stream
                 hipLaunchKernelGGL(k_perm4321<true>, dim3(gperm), dim3(256), 0, c.st, c.dA, c.dC, c.nlog, (u64*)nullptr);
-                hipLaunchKernelGGL(korb, dim3(gorb), dim3(128), lds, c.st, c.dA, c.dB, c.nlog, db, (u64*)nullptr);
+                hipLaunchKernelGGL(korb, dim3(gorb), dim3(128), lds, c.st, c.dA, c.dB, c.n, db, (u64*)nullptr);
             } else if (variant == 1) {  // fork / join every step
                 CK(hipEventRecord(fork, c.st));
                 CK(hipStreamWaitEvent(c.st2, fork, 0));
                 hipLaunchKernelGGL(k_perm4321<true>, dim3(gperm), dim3(256), 0, c.st, c.dA, c.dC, c.nlog, (u64*)nullptr);
-                hipLaunchKernelGGL(korb, dim3(gorb), dim3(128), lds, c.st2, c.dA, c.dB, c.nlog, db, (u64*)nullptr);
+                hipLaunchKernelGGL(korb, dim3(gorb), dim3(128), lds, c.st2, c.dA, c.dB, c.n, db, (u64*)nullptr);
                 CK(hipEventRecord(join, c.st2));
                 CK(hipStreamWaitEvent(c.st, join, 0));
             } else {  // two independent chains, joined once at the end (each output has its own stream order)
@@ -492,7 +506,7 @@ static void run_forkjoin(Ctx& c) {
                     CK(hipStreamWaitEvent(c.st2, fork, 0));
                 }
                 hipLaunchKernelGGL(k_perm4321<true>, dim3(gperm), dim3(256), 0, c.st, c.dA, c.dC, c.nlog, (u64*)nullptr);
-                hipLaunchKernelGGL(korb, dim3(gorb), dim3(128), lds, c.st2, c.dA, c.dB, c.nlog, db, (u64*)nullptr);
+                hipLaunchKernelGGL(korb, dim3(gorb), dim3(128), lds, c.st2, c.dA, c.dB, c.n, db, (u64*)nullptr);
                 if (i == reps - 1) {
                     CK(hipEventRecord(join, c.st2));
                     CK(hipStreamWaitEvent(c.st, join, 0));
@@ -542,7 +556,11 @@ static void run_forkjoin(Ctx& c) {
 
 int main(int argc, char** argv) {
     std::vector<int> sizes;
-    for (int i = 1; i < argc; ++i) sizes.push_back(atoi(argv[i]));
+    bool sweep = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "sweep")) sweep = true;
+        else sizes.push_back(atoi(argv[i]));
+    }
     if (sizes.empty()) sizes = {32, 64, 128};
     {
         int dev = 0, khz = 0;
@@ -561,6 +579,33 @@ int main(int argc, char** argv) {
         CK(hipStreamCreate(&c.st2));
         c.stamp_cap = (size_t)16 << 20;  // 128 MiB of stamps
         CK(hipMalloc(&c.dstamps, c.stamp_cap * 8));
+        c.verify = !sweep;
+        if (sweep) {
+            // the size sweep (any multiple of 8): timing only -- read side, write side and the whole orbit kernel on 8^4
+            // cubes, with the work list grouped / dealt round-robin / shuffled
+            CK(hipMalloc(&c.dA, c.N * 8));
+            CK(hipMalloc(&c.dB, c.N * 8));
+            CK(hipMemset(c.dA, 0, c.N * 8));
+            c.reps = n <= 64 ? 20 : 3;
+            run_copy<false, 0>(c, "copy", false);
+            run_copy<false, 4>(c, "linear read only", false);
+            run_copy<false, 5>(c, "linear write only", false);
+            for (int ord = 0; ord < 3; ++ord) {
+                g_order = ord;
+                run_orb<3, 3, 3, 3, 10, 3, false, 0, 1>(c);
+                run_orb<3, 3, 3, 3, 10, 3, false, 4, 1>(c);
+                run_orb<3, 3, 3, 3, 10, 3, false, 5, 1>(c);
+            }
+            g_order = 0;
+            run_orb<3, 3, 3, 3, 10, 3, true, 5, 1>(c);
+            run_orb<3, 3, 3, 3, 10, 3, false, 5, 1, 2>(c);
+            CK(hipFree(c.dA));
+            CK(hipFree(c.dB));
+            CK(hipFree(c.dstamps));
+            CK(hipStreamDestroy(c.st));
+            CK(hipStreamDestroy(c.st2));
+            continue;
+        }
         c.hA.resize(c.N);
         c.want.resize(c.N);
         c.got.resize(c.N);

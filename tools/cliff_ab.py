@@ -38,9 +38,11 @@ def setopt(**kw):
 perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
 sizes = [int(a) for a in sys.argv[1:]] or [32, 48, 64, 96, 128]
 variants = [("default", {}), ("small tiles", dict(tile_log2=10)), ("big tiles", dict(tile_log2=12)),
-            ("big, never persistent", dict(tile_log2=12, tiled_persist=0)), ("small, persistent from 8 rounds", dict(tile_log2=10, tiled_persist_min=8)),
-            ("big, persistent from 2 rounds", dict(tile_log2=12, tiled_persist_min=2))]
-defaults = dict(tile_log2=0, tiled_persist=1, tiled_persist_min=32)
+            ("big, never persistent", dict(tile_log2=12, tiled_persist=0)),
+            ("big, blocks of 2", dict(tile_log2=12, tile_block=2)), ("big, blocks of 4", dict(tile_log2=12, tile_block=4)),
+            ("big, blocks of 4, never persistent", dict(tile_log2=12, tile_block=4, tiled_persist=0)),
+            ("big, blocks of 8", dict(tile_log2=12, tile_block=8)), ("small, blocks of 4", dict(tile_log2=10, tile_block=4))]
+defaults = dict(tile_log2=0, tiled_persist=1, tiled_persist_min=32, tile_block=0)
 for n in sizes:
     dt = torch.float64
     ts = [torch.randn(n ** 4, dtype=dt, device="cuda") for _ in range(4)]
