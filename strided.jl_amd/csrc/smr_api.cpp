@@ -494,6 +494,8 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "tile_log2") o.tile_log2 = value;
     else if (n == "tile_order") o.tile_order = value;
     else if (n == "tile_block") o.tile_block = value;
+    else if (n == "tile_block_xcd") o.tile_block_xcd = value;
+    else if (n == "tile_block_min_axes") o.tile_block_min_axes = value;
     else if (n == "reduce_blocks") o.reduce_blocks = value;
     else if (n == "jit") o.jit = value;
     else if (n == "tiled_persist") o.tiled_persist = value;
@@ -541,6 +543,8 @@ int64_t smr_get_option(const char* name) {
     if (n == "tile_log2") return o.tile_log2;
     if (n == "tile_order") return o.tile_order;
     if (n == "tile_block") return o.tile_block;
+    if (n == "tile_block_xcd") return o.tile_block_xcd;
+    if (n == "tile_block_min_axes") return o.tile_block_min_axes;
     if (n == "reduce_blocks") return o.reduce_blocks;
     if (n == "jit") return o.jit;
     if (n == "tiled_persist") return o.tiled_persist;

@@ -134,6 +134,7 @@ struct TilePlan {
     // locality-aware execution order (empty = natural): workgroup b runs tile ord[b], 0xffffffff = idle
     std::vector<uint32_t> ord;
     int ord_groups = 0;
+    bool no_persist = false;  // block-ordered lists run in the one-shot form
 };
 
 // Description for FAM_ORBIT (smr_k_orbit.hip).  Every input k is a view of one buffer whose strides are
@@ -192,7 +193,10 @@ struct Options {
     i64 force_family = 0;
     i64 tile_log2 = 0;       // 0 = planner default
     i64 tile_order = 1;      // orbit-major tile order for inputs that are permuted views of one buffer
-    i64 tile_block = 0;      // distinct arrays with >= 3 unit axes: tiles in compact blocks of this many per dim (0 = natural order)
+    i64 tile_block = -1;     // distinct arrays with >= 3 unit axes: tiles in compact blocks of this many per dim (0 = natural
+                             // order, -1 = blocks of 4 for grids of >= 1024 tiles)
+    i64 tile_block_min_axes = 3;  // experiment: 2 = block order for plain transposes as well
+    i64 tile_block_xcd = -1; // block-ordered list in one contiguous run per XCD: 0 never, 1 always, -1 = while the operands fit the Infinity Cache
     i64 jit = 1;             // compile unrecognised f-programs with hiprtc (0 = always interpret)
     i64 reduce_col_txlog = 5;   // COL form: log2 of the lanes along kept dim 0 (cap)
     i64 reduce_part_wgs = 4096; // partial reductions with few outputs are split until about this many workgroups run

@@ -709,7 +709,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     unsigned pgrid = 0;
     if constexpr (!EDGE) {
         const Options& o = options();
-        if (o.tiled_persist) {
+        if (o.tiled_persist && !t.no_persist) {
             static const int ncu = [] {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;

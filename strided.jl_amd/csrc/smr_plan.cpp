@@ -507,7 +507,7 @@ static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
 // tiles that run at the same time form compact blocks (blk tiles along every tiled dim) instead of a slab that is
 // long along dim 0 only, so that every operand -- whatever its unit axis -- has its 32-/64-byte runs completed to
 // longer contiguous pieces by tiles that are in flight together (DRAM row locality; option "tile_block").
-static void plan_block_order(const Canon& c, TilePlan& t, const int* lg, int blk) {
+static void plan_block_order(const Canon& c, TilePlan& t, const int* lg, int blk, bool xcd_runs) {
     if (blk < 2 || t.grid < 64 || t.grid > ((i64)1 << 22)) return;
     i64 nb[MAXN], blocks = 1, tmul[MAXN], acc = 1;
     int tiled[MAXN], ntd = 0;
@@ -541,8 +541,16 @@ static void plan_block_order(const Canon& c, TilePlan& t, const int* lg, int blk
         }
     }
     if ((i64)list.size() != t.grid) return;
-    while (list.size() % 8) list.push_back(0xffffffffu);
-    t.ord = std::move(list);
+    if (xcd_runs) {  // experiment: one contiguous run of the list per XCD (a block then meets in ONE L2)
+        const i64 cs = (t.grid + 7) / 8;
+        t.ord.assign((size_t)(cs * 8), 0xffffffffu);
+        for (i64 x = 0; x < 8; ++x)
+            for (i64 slot = 0; slot < cs; ++slot)
+                if (x * cs + slot < t.grid) t.ord[(size_t)(slot * 8 + x)] = list[(size_t)(x * cs + slot)];
+    } else {
+        while (list.size() % 8) list.push_back(0xffffffffu);
+        t.ord = std::move(list);
+    }
     t.ord_groups = (int)blocks;
 }
 
@@ -807,9 +815,14 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     // 16384^2 840 / 778 / 719 us, 8192^2 270 (218 persistent) / 215 / 206 us; sizes that are not powers of two
     // (4000^2, 12000^2) tie.  Float32 stays with 32 x 32 (128^4: 451 vs 480 / 535 us)
     else if (o.tile_log2 == 0 && na == 2 && nst == 1 && es >= 8 && (long double)c.total * es * 2 >= 1073741824.0L) {
-        tl_cap = 12;
-        runbytes = 32 * es;
-        big_transpose = true;
+        // ... only when the 128 x 32 tile is (nearly) filled: on 96^4 / 144^4 the 128-wide tile idles 25 / 44 % of its
+        // lanes (round 3: 144^4 3.47 TB/s with it)
+        auto util = [&](int d, i64 e) { return (long double)c.dims[d] / (long double)(((c.dims[d] + e - 1) / e) * e); };
+        if (util(axes[0], 128) * util(axes[1], 32) >= 0.9L) {
+            tl_cap = 12;
+            runbytes = 32 * es;
+            big_transpose = true;
+        }
     }
     else if (o.tile_log2 == 0 && na >= 3 && (size_t)nst * 4096 * es <= (size_t)128 * 1024 && c.total >= (i64)4096 * 256) {
         bool fits = true;  // every axis must be able to reach its share of the 12 bits
@@ -820,7 +833,19 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
         // in between (measured 48^4: 25.8 vs 32.0 us, 64^4: 73.5 vs 83.3 us) several small workgroups per
         // CU overlap better than a few rounds of one big workgroup per CU
         const i64 nbig = c.total >> 12;
-        if (nbig > 256 && nbig < 8192) fits = false;
+        // ... when the inputs are views of ONE buffer (they hit in L2).  DISTINCT arrays stream from HBM / the
+        // Infinity Cache and want the longer runs of the big tiles much earlier (round 3, tools/cliff_ab.py, Float64:
+        // A .+ perm(C) .* perm'(D) 48^4 35.7 -> 26.6 us, 64^4 117.8 -> 105.5 us; four arrays with four unit axes:
+        // 64^4 177 -> 157 us, 96^4 888 -> 755 us together with the block order below, 48^4 stays with small tiles)
+        bool one_buffer = false;
+        for (int j = 1; j < c.M; ++j)
+            for (int k = j + 1; k < c.M; ++k)
+                if ((char*)c.base[j] + c.offsets[j] * c.esize[j] == (char*)c.base[k] + c.offsets[k] * c.esize[k]) one_buffer = true;
+        if (one_buffer) {
+            if (nbig > 256 && nbig < 8192) fits = false;
+        } else if (nbig > 256 && nbig < (na >= 4 ? 2048 : 257)) {
+            fits = false;
+        }
         if (fits) tl_cap = 12;
     }
     if ((size_t)nst * ((size_t)1 << tl_cap) * es > std::max<size_t>((size_t)o.max_lds_bytes, tl_cap == 12 ? (size_t)128 * 1024 : 0)) return false;
@@ -926,7 +951,16 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     t.ord.clear();
     t.ord_groups = 0;
     if (o.tile_order) plan_tile_order(c, t, lg);
-    if (t.ord.empty() && o.tile_block >= 2 && na >= 3) plan_block_order(c, t, lg, (int)o.tile_block);
+    // 128 x 32 transposing tiles run one-shot: measured round 3 (tools/perm_block_ab.py, Float64) permutedims! 128^4
+    // 826 -> 791 us, (2,3,4,1) 866 -> 745 us, (3,4,1,2) 801 -> 699 us, transpose 16384^2 859 -> 719 us, 8192^2 / 12000^2 tie
+    t.no_persist = big_transpose;
+    if (t.ord.empty() && (na >= 3 || (o.tile_block_min_axes <= 2 && na >= 2)) && o.tile_block != 0 && (o.tile_block > 0 || t.grid >= 1024)) {
+        // one contiguous run of the list per XCD while the operands fit the Infinity Cache (a block's partner pieces meet in ONE
+        // L2: 48^4 45.0 -> 38.5 us); round-robin once they stream from HBM (64^4: 157 vs 175 us)
+        const bool xcd_runs = o.tile_block_xcd > 0 || (o.tile_block_xcd < 0 && c.algbytes <= ((i64)256 << 20));
+        plan_block_order(c, t, lg, o.tile_block > 0 ? (int)o.tile_block : 4, xcd_runs);
+        t.no_persist = t.no_persist || !t.ord.empty();  // measured: the one-shot form wins on block-ordered lists (128^4: 2715 vs 2773 us)
+    }
     return true;
 }
 

@@ -649,6 +649,13 @@ int main(int argc, char** argv) {
             run_orb<2, 2, 2, 2, 7, 3, false, 4, 1>(c, true);
             run_orb<2, 2, 2, 2, 7, 3, false, 5, 1>(c, true);
             run_orb<2, 2, 2, 2, 7, 3, false, 0, 2>(c, true);
+            run_orb<2, 2, 2, 2, 6, 3, false, 0, 1>(c, true);   // one wave per orbit
+            run_orb<2, 2, 2, 2, 6, 3, false, 0, 2>(c, true);
+            run_orb<2, 2, 2, 2, 6, 3, false, 0, 4>(c);
+            run_orb<3, 2, 2, 2, 7, 1, false, 0, 1>(c);
+            run_orb<3, 2, 2, 2, 7, 3, false, 0, 1>(c);
+            run_orb<3, 2, 2, 2, 8, 3, false, 0, 1>(c);
+            run_orb<3, 2, 2, 2, 8, 2, false, 0, 1>(c);
             run_orb<2, 2, 2, 2, 7, 3, false, 0, 4>(c, true);
             run_orb<3, 2, 2, 2, 8, 1, false, 0, 1>(c, true);
             run_orb<3, 2, 2, 2, 8, 1, false, 0, 2>(c);

@@ -37,12 +37,15 @@ def setopt(**kw):
 
 perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
 sizes = [int(a) for a in sys.argv[1:]] or [32, 48, 64, 96, 128]
-variants = [("default", {}), ("small tiles", dict(tile_log2=10)), ("big tiles", dict(tile_log2=12)),
-            ("big, never persistent", dict(tile_log2=12, tiled_persist=0)),
-            ("big, blocks of 2", dict(tile_log2=12, tile_block=2)), ("big, blocks of 4", dict(tile_log2=12, tile_block=4)),
-            ("big, blocks of 4, never persistent", dict(tile_log2=12, tile_block=4, tiled_persist=0)),
-            ("big, blocks of 8", dict(tile_log2=12, tile_block=8)), ("small, blocks of 4", dict(tile_log2=10, tile_block=4))]
-defaults = dict(tile_log2=0, tiled_persist=1, tiled_persist_min=32, tile_block=0)
+variants = [("default (auto)", {}), ("round 2 (natural order)", dict(tile_block=0)),
+            ("small, natural", dict(tile_log2=10, tile_block=0)), ("big, natural", dict(tile_log2=12, tile_block=0)),
+            ("big, blocks of 3", dict(tile_log2=12, tile_block=3)), ("big, blocks of 4", dict(tile_log2=12, tile_block=4)),
+            ("big, blocks of 6", dict(tile_log2=12, tile_block=6)),
+            ("big, blocks of 4, XCD runs", dict(tile_log2=12, tile_block=4, tile_block_xcd=1)),
+            ("big, blocks of 2, XCD runs", dict(tile_log2=12, tile_block=2, tile_block_xcd=1)),
+            ("small, blocks of 4", dict(tile_log2=10, tile_block=4)), ("small, blocks of 6", dict(tile_log2=10, tile_block=6)),
+            ("small, blocks of 4, XCD runs", dict(tile_log2=10, tile_block=4, tile_block_xcd=1))]
+defaults = dict(tile_log2=0, tiled_persist=1, tiled_persist_min=32, tile_block=-1, tile_block_xcd=0)
 for n in sizes:
     dt = torch.float64
     ts = [torch.randn(n ** 4, dtype=dt, device="cuda") for _ in range(4)]
