@@ -65,8 +65,15 @@ typedef enum {
 } smr_status;
 
 /* Element types.  Arithmetic is done in one of the four float classes every reference
- * test-set iterates over (test/othertests.jl:2); integer types are bit-moved by
- * copy!/permutedims! and may be the destination of counting reductions.              */
+ * test-set iterates over (test/othertests.jl:2), or -- round 3 -- in the INTEGER class: when every
+ * operand (destination included) has an integer eltype and f uses only integer-closed operations
+ * (+ - * neg abs abs2 min max comparisons select, integer-valued constants; reductions + * min max & |),
+ * the call computes in wrapping 64-bit two's-complement arithmetic like Julia's Int64 (sum of an Int64
+ * view above 2^53, overflow wrap-around) and truncates on store to a narrower destination type (= the
+ * wrapped result of Julia's arithmetic in that type for + - * chains).  UInt64 operands take part in ring
+ * operations only (no order: min / max / < / abs are refused with SMR_EUNSUPPORTED, as is any 64-bit integer
+ * input that meets floating-point arithmetic).  Pure moves (copy!/permutedims!) of any integer width are
+ * bit copies; integers mixed with floats compute in Float64.                                             */
 typedef enum {
     SMR_F32 = 0,
     SMR_F64 = 1,

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -66,6 +67,16 @@ template <> struct traits<float> { typedef float real; static constexpr bool is_
 template <> struct traits<double> { typedef double real; static constexpr bool is_cx = false; };
 template <> struct traits<cx<float>> { typedef float real; static constexpr bool is_cx = true; };
 template <> struct traits<cx<double>> { typedef double real; static constexpr bool is_cx = true; };
+// the integer class: Julia's Int64 arithmetic (wrapping two's complement; built with -fwrapv).  Selected when every
+// operand has an integer eltype and f stays inside the integers -- src/mapreduce.jl:55-72 takes typeof(op(...)) as the
+// accumulator type, and `+`/`*` of Int64 wrap in Julia.
+typedef long long ix64;
+template <> struct traits<ix64> { typedef ix64 real; static constexpr bool is_cx = false; };
+// double -> real type of a class (saturating for the integer class: the +-Inf seeds of min / max become typemax / typemin)
+template <class R> inline R rcast(double d) { return R(d); }
+template <> inline ix64 rcast<ix64>(double d) {
+    return d >= 9223372036854775807.0 ? 9223372036854775807LL : (d <= -9223372036854775808.0 ? (-9223372036854775807LL - 1) : (ix64)d);
+}
 
 template <class R> inline R re_of(R x) { return x; }
 template <class R> inline R re_of(cx<R> x) { return x.re; }
@@ -76,6 +87,7 @@ template <> inline float make<float>(float re, float) { return re; }
 template <> inline double make<double>(double re, double) { return re; }
 template <> inline cx<float> make<cx<float>>(float re, float im) { return {re, im}; }
 template <> inline cx<double> make<cx<double>>(double re, double im) { return {re, im}; }
+template <> inline ix64 make<ix64>(ix64 re, ix64) { return re; }
 
 template <class R> inline cx<R> operator+(cx<R> a, cx<R> b) { return {a.re + b.re, a.im + b.im}; }
 template <class R> inline cx<R> operator-(cx<R> a, cx<R> b) { return {a.re - b.re, a.im - b.im}; }
@@ -147,6 +159,35 @@ struct real_ops {
     }
     static bool truthy(T a) { return a != R(0); }
 };
+template <> struct ops<ix64> {
+    typedef unsigned long long U;
+    static ix64 un(int op, ix64 a) {
+        switch (op) {
+            case SMR_OP_NEG: return (ix64)(U(0) - (U)a);
+            case SMR_OP_ABS: return a < 0 ? (ix64)(U(0) - (U)a) : a;  // abs(typemin(Int64)) == typemin(Int64) in Julia
+            case SMR_OP_ABS2: return (ix64)((U)a * (U)a);
+            case SMR_OP_IMAG: return 0;
+        }
+        return a;
+    }
+    static ix64 bin(int op, ix64 a, ix64 b) {
+        switch (op) {
+            case SMR_OP_ADD: return (ix64)((U)a + (U)b);
+            case SMR_OP_SUB: return (ix64)((U)a - (U)b);
+            case SMR_OP_MUL: return (ix64)((U)a * (U)b);
+            case SMR_OP_MIN: return b < a ? b : a;
+            case SMR_OP_MAX: return a < b ? b : a;
+            case SMR_OP_LT: return a < b ? 1 : 0;
+            case SMR_OP_LE: return a <= b ? 1 : 0;
+            case SMR_OP_GT: return a > b ? 1 : 0;
+            case SMR_OP_GE: return a >= b ? 1 : 0;
+            case SMR_OP_EQ: return a == b ? 1 : 0;
+            case SMR_OP_NE: return a != b ? 1 : 0;
+        }
+        return a;
+    }
+    static bool truthy(ix64 a) { return a != 0; }
+};
 template <> struct ops<float> : real_ops<float> {};
 template <> struct ops<double> : real_ops<double> {};
 
@@ -207,7 +248,7 @@ inline T eval_prog(const Prog& p, const T* args /* args[k] = value of input k (1
         if (op == SMR_OP_ARG) {
             st[sp++] = args[imm];
         } else if (op == SMR_OP_CONST) {
-            st[sp++] = make<T>(R(p.consts[2 * imm]), R(p.consts[2 * imm + 1]));
+            st[sp++] = make<T>(rcast<R>(p.consts[2 * imm]), rcast<R>(p.consts[2 * imm + 1]));
         } else if (op < 32) {
             st[sp - 1] = ops<T>::un(op, st[sp - 1]);
         } else if (op < 64) {
@@ -256,6 +297,19 @@ int check_prog(const Prog& p, int M) {
 template <class T>
 inline T load_as(const void* base, i64 idx, int dt) {
     typedef typename traits<T>::real R;
+    if constexpr (std::is_same<T, ix64>::value) {  // sign / zero extension
+        switch (dt) {
+            case SMR_I8: return ((const int8_t*)base)[idx];
+            case SMR_U8: return ((const uint8_t*)base)[idx];
+            case SMR_I16: return ((const int16_t*)base)[idx];
+            case SMR_U16: return ((const uint16_t*)base)[idx];
+            case SMR_I32: return ((const int32_t*)base)[idx];
+            case SMR_U32: return ((const uint32_t*)base)[idx];
+            case SMR_I64: return ((const long long*)base)[idx];
+            case SMR_U64: return (ix64)((const unsigned long long*)base)[idx];
+        }
+        return 0;
+    } else
     switch (dt) {
         case SMR_F32: return make<T>(R(((const float*)base)[idx]), R(0));
         case SMR_F64: return make<T>(R(((const double*)base)[idx]), R(0));
@@ -274,6 +328,15 @@ inline T load_as(const void* base, i64 idx, int dt) {
 }
 template <class T>
 inline void store_as(void* base, i64 idx, int dt, T v) {
+    if constexpr (std::is_same<T, ix64>::value) {  // truncation = the wrapped value in the narrower type
+        switch (dt) {
+            case SMR_I8: case SMR_U8: ((uint8_t*)base)[idx] = (uint8_t)v; break;
+            case SMR_I16: case SMR_U16: ((uint16_t*)base)[idx] = (uint16_t)v; break;
+            case SMR_I32: case SMR_U32: ((uint32_t*)base)[idx] = (uint32_t)v; break;
+            case SMR_I64: case SMR_U64: ((long long*)base)[idx] = v; break;
+        }
+        return;
+    } else {
     auto re = re_of(v);
     auto im = im_of(v);
     switch (dt) {
@@ -289,6 +352,7 @@ inline void store_as(void* base, i64 idx, int dt, T v) {
         case SMR_U32: ((uint32_t*)base)[idx] = (uint32_t)std::llrint((double)re); break;
         case SMR_I64: ((int64_t*)base)[idx] = (int64_t)std::llrint((double)re); break;
         case SMR_U64: ((uint64_t*)base)[idx] = (uint64_t)std::llrint((double)re); break;
+    }
     }
 }
 
@@ -797,6 +861,7 @@ template <> struct dtype_of<float> { static constexpr int v = SMR_F32; };
 template <> struct dtype_of<double> { static constexpr int v = SMR_F64; };
 template <> struct dtype_of<cx<float>> { static constexpr int v = SMR_C32; };
 template <> struct dtype_of<cx<double>> { static constexpr int v = SMR_C64; };
+template <> struct dtype_of<ix64> { static constexpr int v = SMR_I64; };
 
 template <class T>
 int run_typed(const smr_problem* p, const Lowered& L, const Prog& prog, int nthreads) {
@@ -811,7 +876,7 @@ int run_typed(const smr_problem* p, const Lowered& L, const Prog& prog, int nthr
         A.esize[k] = L.esize[k];
         if (A.dtype[k] != dtype_of<T>::v) uniform = false;
     }
-    T beta = make<T>(R(p->initarg[0]), R(p->initarg[1]));
+    T beta = make<T>(rcast<R>(p->initarg[0]), rcast<R>(p->initarg[1]));
     FSpec fs = classify(prog);
     auto make_kernel = [&](const Operands& ops_) {
         Kernel<T> K{L, ops_, prog, fs, p->redop, p->initop, beta, uniform};
@@ -874,6 +939,36 @@ int run_typed(const smr_problem* p, const Lowered& L, const Prog& prog, int nthr
     };
     threaded(L, L.dims, L.offsets, costs, nthreads, 0, 1, leaf, true);
     return SMR_OK;
+}
+
+// the integer class applies when every operand is an integer type and f is closed over the integers (the same rule as
+// the device planner, csrc/smr_plan.cpp: canonicalise)
+bool integer_class(const smr_problem* p, const Prog& prog) {
+    bool has_u64 = false;
+    for (int k = 0; k < p->M; ++k) {
+        if (p->ops[k].dtype < SMR_I8) return false;
+        if (p->ops[k].dtype == SMR_U64) has_u64 = true;
+    }
+    bool ordered = p->redop == SMR_RED_MIN || p->redop == SMR_RED_MAX;
+    for (int pc = 0; pc < prog.len; ++pc) {
+        const int op = prog.code[2 * pc];
+        switch (op) {
+            case SMR_OP_ARG: case SMR_OP_NEG: case SMR_OP_ABS2: case SMR_OP_CONJ: case SMR_OP_REAL: case SMR_OP_IMAG:
+            case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_EQ: case SMR_OP_NE: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
+            case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: ordered = true; break;
+            case SMR_OP_CONST: {
+                const double re = prog.consts[2 * prog.code[2 * pc + 1]], im = prog.consts[2 * prog.code[2 * pc + 1] + 1];
+                if (im != 0.0 || !(re == std::floor(re) || std::isinf(re)) || (std::fabs(re) > 9223372036854775808.0 && !std::isinf(re))) return false;
+                break;
+            }
+            default: return false;
+        }
+    }
+    if (p->initop == SMR_INIT_SCALE || p->initop == SMR_INIT_CONST) {
+        const double re = p->initarg[0], im = p->initarg[1];
+        if (im != 0.0 || re != std::floor(re) || std::fabs(re) > 9223372036854775808.0) return false;
+    }
+    return !(has_u64 && ordered);
 }
 
 int compute_class(const smr_problem* p) {
@@ -961,6 +1056,7 @@ int oracle_mapreduce(const smr_problem* p, int nthreads) {
     if (anyint && p->redop == SMR_RED_NONE && p->M == 2 && p->ops[0].dtype == p->ops[1].dtype &&
         prog.len == 1 && prog.code[0] == SMR_OP_ARG)
         return run_bitcopy(p, L);
+    if (integer_class(p, prog)) return run_typed<ix64>(p, L, prog, nthreads);
     switch (compute_class(p)) {
         case SMR_F32: return run_typed<float>(p, L, prog, nthreads);
         case SMR_F64: return run_typed<double>(p, L, prog, nthreads);

@@ -32,6 +32,7 @@ int hip_error(hipError_t e, const char* what) {
         case SMR_F64: return fn##_ct<SMR_F64>(plan, bases, s);                \
         case SMR_C32: return fn##_ct<SMR_C32>(plan, bases, s);                \
         case SMR_C64: return fn##_ct<SMR_C64>(plan, bases, s);                \
+        case SMR_I64: return fn##_ct<SMR_I64>(plan, bases, s);                \
     }                                                                         \
     return set_error(SMR_EINVAL, "bad compute class");
 
@@ -354,7 +355,7 @@ int smr_plan_jit_source(const smr_plan* plan, char* buf, size_t buflen) {
     if (!plan || !buf || buflen == 0) return set_error(SMR_EINVAL, "null argument");
     static const char* names[] = {"float", "double", "smr::c32", "smr::c64"};
     const Canon& c = plan->plan.c;
-    std::snprintf(buf, buflen, "%s", jit_functor_source(c, names[c.ct & 3]).c_str());
+    std::snprintf(buf, buflen, "%s", jit_functor_source(c, c.ct == SMR_I64 ? "smr::ix64" : names[c.ct & 3]).c_str());
     return SMR_OK;
 }
 

@@ -113,6 +113,14 @@ int fill_neutral(const smr_problem* p) {
     if (p->redop == SMR_RED_MUL || p->redop == SMR_RED_AND) c[0] = 1;
     if (p->redop == SMR_RED_MIN) c[0] = __builtin_huge_val();
     if (p->redop == SMR_RED_MAX) c[0] = -__builtin_huge_val();
+    const int dt = p->ops[0].dtype;
+    if (dt >= SMR_I8 && (p->redop == SMR_RED_MIN || p->redop == SMR_RED_MAX)) {
+        // integer destination: typemax / typemin of ITS type (the integer class saturates +-Inf to the Int64 limits;
+        // -1 stored into a UInt64 is all ones)
+        static const double imax[8] = {127., 32767., 2147483647., __builtin_huge_val(), 255., 65535., 4294967295., -1.};
+        static const double imin[8] = {-128., -32768., -2147483648., -__builtin_huge_val(), 0., 0., 0., 0.};
+        c[0] = p->redop == SMR_RED_MIN ? imax[dt - SMR_I8] : imin[dt - SMR_I8];
+    }
     f.fprog = code;
     f.fprog_len = 1;
     f.fconsts = c;

@@ -68,6 +68,9 @@ template <> struct tr<float> { typedef float real; static constexpr bool cx = fa
 template <> struct tr<double> { typedef double real; static constexpr bool cx = false; static constexpr bool arith = true; static constexpr int dt = SMR_F64; };
 template <> struct tr<c32> { typedef float real; static constexpr bool cx = true; static constexpr bool arith = true; static constexpr int dt = SMR_C32; };
 template <> struct tr<c64> { typedef double real; static constexpr bool cx = true; static constexpr bool arith = true; static constexpr int dt = SMR_C64; };
+// the integer compute class: 64-bit two's-complement, wrapping (Julia's Int64 arithmetic); compiled with -fwrapv
+typedef long long ix64;
+template <> struct tr<ix64> { typedef ix64 real; static constexpr bool cx = false; static constexpr bool arith = true; static constexpr int dt = SMR_I64; };
 template <> struct tr<b8> { typedef float real; static constexpr bool cx = false; static constexpr bool arith = false; static constexpr int dt = SMR_U8; };
 template <> struct tr<b16> { typedef float real; static constexpr bool cx = false; static constexpr bool arith = false; static constexpr int dt = SMR_U16; };
 
@@ -121,7 +124,16 @@ SMR_DEV void store_vec(char* p, const VT& v, int nts) {
     }
 }
 
+template <class T> struct is_int_class { static constexpr bool value = false; };
+template <> struct is_int_class<ix64> { static constexpr bool value = true; };
+// double -> the real type of a compute class; saturating for the integer class (the +-Inf seeds of min / max
+// reductions become typemax / typemin, as _init_reduction! would give them)
+template <class R> SMR_DEV R rcast(double d) { return R(d); }
+template <> SMR_DEV ix64 rcast<ix64>(double d) {
+    return d >= 9223372036854775807.0 ? 9223372036854775807LL : (d <= -9223372036854775808.0 ? (-9223372036854775807LL - 1) : (ix64)d);
+}
 template <class T> SMR_DEV T mk(typename tr<T>::real re, typename tr<T>::real im);
+template <> SMR_DEV ix64 mk<ix64>(ix64 re, ix64) { return re; }
 template <> SMR_DEV float mk<float>(float re, float) { return re; }
 template <> SMR_DEV double mk<double>(double re, double) { return re; }
 template <> SMR_DEV c32 mk<c32>(float re, float im) { return c32{re, im}; }
@@ -130,6 +142,9 @@ template <> SMR_DEV c64 mk<c64>(double re, double im) { return c64{re, im}; }
 SMR_DEV float re_(float x) { return x; }
 SMR_DEV double re_(double x) { return x; }
 template <class R> SMR_DEV R re_(cplx<R> x) { return x.re; }
+SMR_DEV ix64 re_(ix64 x) { return x; }
+SMR_DEV ix64 im_(ix64) { return 0; }
+SMR_DEV ix64 cj(ix64 x) { return x; }
 SMR_DEV float im_(float) { return 0.f; }
 SMR_DEV double im_(double) { return 0.; }
 template <class R> SMR_DEV R im_(cplx<R> x) { return x.im; }
@@ -203,6 +218,39 @@ struct mathx_real {
 };
 template <> struct mathx<float> : mathx_real<float> {};
 template <> struct mathx<double> : mathx_real<double> {};
+
+// integer class: every operation is closed over Int64 and wraps (unsigned arithmetic underneath: no UB);
+// the planner admits only these opcodes (csrc/smr_plan.cpp: canonicalise)
+template <> struct mathx<ix64> {
+    typedef unsigned long long U;
+    static SMR_DEV ix64 un(int op, ix64 a) {
+        switch (op) {
+            case SMR_OP_NEG: return (ix64)(U(0) - (U)a);
+            case SMR_OP_ABS: return a < 0 ? (ix64)(U(0) - (U)a) : a;  // abs(typemin) = typemin, like Julia
+            case SMR_OP_ABS2: return (ix64)((U)a * (U)a);
+            case SMR_OP_IMAG: return 0;
+        }
+        return a;  // conj, real, round32 / widen (never emitted for integers)
+    }
+    static SMR_DEV ix64 bin(int op, ix64 a, ix64 b) {
+        switch (op) {
+            case SMR_OP_ADD: return (ix64)((U)a + (U)b);
+            case SMR_OP_SUB: return (ix64)((U)a - (U)b);
+            case SMR_OP_MUL: return (ix64)((U)a * (U)b);
+            case SMR_OP_DIV: return b == 0 ? 0 : ((a == (-9223372036854775807LL - 1) && b == -1) ? a : a / b);  // not admitted by the planner (Julia's `/` leaves the integers)
+            case SMR_OP_MIN: return b < a ? b : a;
+            case SMR_OP_MAX: return a < b ? b : a;
+            case SMR_OP_LT: return a < b ? 1 : 0;
+            case SMR_OP_LE: return a <= b ? 1 : 0;
+            case SMR_OP_GT: return a > b ? 1 : 0;
+            case SMR_OP_GE: return a >= b ? 1 : 0;
+            case SMR_OP_EQ: return a == b ? 1 : 0;
+            case SMR_OP_NE: return a != b ? 1 : 0;
+        }
+        return a;
+    }
+    static SMR_DEV bool truthy(ix64 a) { return a != 0; }
+};
 
 template <class R>
 struct mathx_cx {
@@ -279,6 +327,19 @@ SMR_DEV void st(void* base, i64 idx, T v) {
 template <class T>
 SMR_DEV T ld_as(const void* base, i64 idx, int dt) {
     typedef typename tr<T>::real R;
+    if constexpr (is_int_class<T>::value) {  // sign / zero extension; floating operands never reach this class
+        switch (dt) {
+            case SMR_I8: return ((const int8_t*)base)[idx];
+            case SMR_U8: return ((const uint8_t*)base)[idx];
+            case SMR_I16: return ((const int16_t*)base)[idx];
+            case SMR_U16: return ((const uint16_t*)base)[idx];
+            case SMR_I32: return ((const int32_t*)base)[idx];
+            case SMR_U32: return ((const uint32_t*)base)[idx];
+            case SMR_I64: return ((const long long*)base)[idx];
+            case SMR_U64: return (ix64)((const unsigned long long*)base)[idx];
+        }
+        return 0;
+    } else
     switch (dt) {
         case SMR_F32: return mk<T>(R(((const float*)base)[idx]), R(0));
         case SMR_F64: return mk<T>(R(((const double*)base)[idx]), R(0));
@@ -297,6 +358,15 @@ SMR_DEV T ld_as(const void* base, i64 idx, int dt) {
 }
 template <class T>
 SMR_DEV void st_as(void* base, i64 idx, int dt, T v) {
+    if constexpr (is_int_class<T>::value) {  // truncation = the wrapped value in the narrower type
+        switch (dt) {
+            case SMR_I8: case SMR_U8: ((uint8_t*)base)[idx] = (uint8_t)v; break;
+            case SMR_I16: case SMR_U16: ((uint16_t*)base)[idx] = (uint16_t)v; break;
+            case SMR_I32: case SMR_U32: ((uint32_t*)base)[idx] = (uint32_t)v; break;
+            case SMR_I64: case SMR_U64: ((long long*)base)[idx] = v; break;
+        }
+        return;
+    } else {
     auto re = re_(v);
     auto im = im_(v);
     switch (dt) {
@@ -318,6 +388,7 @@ SMR_DEV void st_as(void* base, i64 idx, int dt, T v) {
                                                                           : (unsigned long long)llrint(d);
             break;
         }
+    }
     }
 }
 
@@ -377,7 +448,7 @@ template <class T> struct FScale {
 template <class T> struct FSym {
     static constexpr int NIN = 2;
     T c;
-    SMR_DEV T operator()(const T* a) const { return (a[0] + a[1]) / c; }
+    SMR_DEV T operator()(const T* a) const { return mathx<T>::bin(SMR_OP_DIV, a[0] + a[1], c); }
 };
 template <class T> struct FAxpy {
     static constexpr int NIN = 2;
@@ -402,7 +473,8 @@ template <class T> struct FExpr5 {  // a*exp(c*a) + sin(a*a), real types only
     T c;
     SMR_DEV T operator()(const T* a) const {
         T x = a[0];
-        return x * exp(c * x) + sin(x * x);
+        if constexpr (is_int_class<T>::value) return x;  // never selected for the integer class
+        else return x * exp(c * x) + sin(x * x);
     }
 };
 
@@ -426,7 +498,7 @@ template <class T> struct FProg {
                     for (int k = 1; k < MAXIN; ++k)
                         if (imm == k + 1) v = a[k];
                 } else {
-                    v = mk<T>(R(p.consts[2 * imm]), R(p.consts[2 * imm + 1]));
+                    v = mk<T>(rcast<R>(p.consts[2 * imm]), rcast<R>(p.consts[2 * imm + 1]));
                 }
                 s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
             } else if (op < 32) {

@@ -1,7 +1,7 @@
 // smr_dispatch.h -- compile-time dispatch helpers shared by the kernel translation units.
 //
 // Every kernel family is a template over <compute type T, functor F, MIXED>.  Each family's
-// .hip file is compiled once per compute type (-DSMR_CT=0..3) so the instantiation matrix
+// .hip file is compiled once per compute type (-DSMR_CT=0..3 and 7 = the integer class) so the instantiation matrix
 // builds in parallel; the per-type entry points are the explicit specialisations of
 // launch_<family>_ct<CT>.
 #pragma once
@@ -20,6 +20,7 @@ template <> struct ct_type<SMR_F32> { typedef float type; };
 template <> struct ct_type<SMR_F64> { typedef double type; };
 template <> struct ct_type<SMR_C32> { typedef c32 type; };
 template <> struct ct_type<SMR_C64> { typedef c64 type; };
+template <> struct ct_type<SMR_I64> { typedef ix64 type; };  // the integer class (smr_device.h)
 
 #ifndef SMR_JIT
 template <class T> inline T hostmk(double re, double im);
@@ -27,6 +28,9 @@ template <> inline float hostmk<float>(double re, double) { return (float)re; }
 template <> inline double hostmk<double>(double re, double) { return re; }
 template <> inline c32 hostmk<c32>(double re, double im) { return c32{(float)re, (float)im}; }
 template <> inline c64 hostmk<c64>(double re, double im) { return c64{re, im}; }
+template <> inline ix64 hostmk<ix64>(double re, double) {
+    return re >= 9223372036854775807.0 ? 9223372036854775807LL : (re <= -9223372036854775808.0 ? (-9223372036854775807LL - 1) : (ix64)re);
+}
 
 // Host-side stand-in for the functor that smr_jit.cpp generates from the f-program: selects the
 // jit_launch() path inside the launchers (no device code is instantiated for it).
@@ -44,6 +48,7 @@ template <> inline const char* tname<float>() { return "float"; }
 template <> inline const char* tname<double>() { return "double"; }
 template <> inline const char* tname<c32>() { return "smr::c32"; }
 template <> inline const char* tname<c64>() { return "smr::c64"; }
+template <> inline const char* tname<ix64>() { return "smr::ix64"; }
 template <> inline const char* tname<b8>() { return "smr::b8"; }
 template <> inline const char* tname<b16>() { return "smr::b16"; }
 
@@ -72,13 +77,15 @@ int with_functor(const Canon& c, unsigned mask, Fn&& fn) {
         case FK_ADD3: return fn(FAdd3<T>{});
         case FK_ADD4: return fn(FAdd4<T>{});
         case FK_SCALE: return fn(FScale<T>{hostmk<T>(c.fc[0], c.fc[1])});
-        case FK_SYM: return fn(FSym<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_SYM:
+            if constexpr (!is_int_class<T>::value) return fn(FSym<T>{hostmk<T>(c.fc[0], c.fc[1])});
+            break;
         case FK_AXPY: return fn(FAxpy<T>{hostmk<T>(c.fc[0], c.fc[1])});
         case FK_AXPBY: return fn(FAxpby<T>{hostmk<T>(c.fc[0], c.fc[1]), hostmk<T>(c.fc[2], c.fc[3])});
         case FK_ABS2: return fn(FAbs2<T>{});
         case FK_MUL2: return fn(FMul2<T>{});
         case FK_EXPR5:
-            if constexpr (!tr<T>::cx) return fn(FExpr5<T>{hostmk<T>(c.fc[0], 0)});
+            if constexpr (!tr<T>::cx && !is_int_class<T>::value) return fn(FExpr5<T>{hostmk<T>(c.fc[0], 0)});
             break;
         default: break;
     }

@@ -37,8 +37,9 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "smr_jitc: hiprtcCreateProgram failed\n");
         return 1;
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    // -fwrapv: the integer compute class wraps like Julia's Int64 (no effect on the floating classes)
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fwrapv"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);

@@ -6,7 +6,7 @@
 #include "smr_dispatch.h"
 
 #ifndef SMR_CT
-#error "compile with -DSMR_CT=0..3"
+#error "compile with -DSMR_CT=0..3 or 7"
 #endif
 
 namespace smr {

@@ -29,7 +29,7 @@
 #include "smr_dispatch.h"
 
 #ifndef SMR_CT
-#error "compile with -DSMR_CT=0..3"
+#error "compile with -DSMR_CT=0..3 or 7"
 #endif
 
 // 1: the per-lane offsets (byte offset in a tile + one LDS read index per permuted view) come from a small

@@ -13,7 +13,7 @@
 #include "smr_dispatch.h"
 
 #ifndef SMR_CT
-#error "compile with -DSMR_CT=0..3"
+#error "compile with -DSMR_CT=0..3 or 7"
 #endif
 
 namespace smr {
@@ -42,8 +42,8 @@ SMR_DEV T neutral(int op) {
     switch (op) {
         case SMR_RED_MUL: return mk<T>(R(1), R(0));
         case SMR_RED_AND: return mk<T>(R(1), R(0));
-        case SMR_RED_MIN: return mk<T>(R(__builtin_huge_val()), R(0));
-        case SMR_RED_MAX: return mk<T>(R(-__builtin_huge_val()), R(0));
+        case SMR_RED_MIN: return mk<T>(rcast<R>(__builtin_huge_val()), R(0));   // integer class: typemax / typemin
+        case SMR_RED_MAX: return mk<T>(rcast<R>(-__builtin_huge_val()), R(0));
     }
     return mk<T>(R(0), R(0));
 }
@@ -59,7 +59,7 @@ template <class T, bool MIXED>
 SMR_DEV void epilogue(const RedArgs& a, i64 off0, T acc) {
     typedef typename tr<T>::real R;
     T old = load_op<T, MIXED>(a.ops, 0, off0);
-    if (a.initop != SMR_INIT_NONE) old = init_apply<T>(a.initop, old, mk<T>(R(a.beta[0]), R(a.beta[1])));
+    if (a.initop != SMR_INIT_NONE) old = init_apply<T>(a.initop, old, mk<T>(rcast<R>(a.beta[0]), rcast<R>(a.beta[1])));
     store_op<T, MIXED>(a.ops, off0, red_apply<T>(a.redop, old, acc));
 }
 

@@ -45,7 +45,7 @@
 #include "smr_dispatch.h"
 
 #ifndef SMR_CT
-#error "compile with -DSMR_CT=0..3"
+#error "compile with -DSMR_CT=0..3 or 7"
 #endif
 // 1: compute the per-lane rows (bit slices of the lane id, fold swizzle) instead of loading them from the
 // device table.  Measured on MI355X (tools/perm_ab.py, round 2): SLOWER where it was meant to help -- permutedims!

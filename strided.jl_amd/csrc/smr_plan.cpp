@@ -13,6 +13,7 @@
 // lives in oracle/ as test infrastructure.
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -162,12 +163,48 @@ int canonicalise(const smr_problem* p, Canon& c) {
     for (int pc = 0; pc < prog.len; ++pc)
         if (prog.code[2 * pc] == SMR_OP_WIDEN) dbl = true;  // a 64-bit scalar takes part (strided_hip.h)
     c.ct = cplx ? (dbl ? SMR_C64 : SMR_C32) : (dbl ? SMR_F64 : SMR_F32);
+    // The integer class (round 3): every operand has an integer eltype and f stays inside the integers -> wrapping
+    // 64-bit arithmetic like Julia's (typeof(op(...)) is the accumulator type, src/mapreduce.jl:55-72); narrower
+    // destinations truncate on store.  UInt64 takes part in ring operations only (no order on the device).
+    {
+        bool allint = true, has_u64 = false;
+        for (int k = 0; k < M0; ++k) {
+            if (p->ops[k].dtype < SMR_I8) allint = false;
+            if (p->ops[k].dtype == SMR_U64) has_u64 = true;
+        }
+        bool closed = true, ordered = p->redop == SMR_RED_MIN || p->redop == SMR_RED_MAX;
+        for (int pc = 0; pc < prog.len && closed; ++pc) {
+            const int op = prog.code[2 * pc];
+            switch (op) {
+                case SMR_OP_ARG: case SMR_OP_NEG: case SMR_OP_ABS2: case SMR_OP_CONJ: case SMR_OP_REAL: case SMR_OP_IMAG:
+                case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_EQ: case SMR_OP_NE: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
+                case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: ordered = true; break;
+                case SMR_OP_CONST: {
+                    const double re = prog.consts[2 * prog.code[2 * pc + 1]], im = prog.consts[2 * prog.code[2 * pc + 1] + 1];
+                    // integer-valued (or a +-Inf seed of a min / max reduction, which saturates to typemax / typemin)
+                    if (im != 0.0 || !(re == std::floor(re) || std::isinf(re)) || (std::fabs(re) > 9223372036854775808.0 && !std::isinf(re))) closed = false;
+                    break;
+                }
+                default: closed = false;
+            }
+        }
+        if (p->initop == SMR_INIT_SCALE || p->initop == SMR_INIT_CONST) {
+            const double re = p->initarg[0], im = p->initarg[1];
+            if (im != 0.0 || re != std::floor(re) || std::fabs(re) > 9223372036854775808.0) closed = false;
+        }
+        if (allint && closed && !(has_u64 && ordered)) c.ct = SMR_I64;
+    }
     c.redop = p->redop;
     c.initop = p->initop;
     c.initarg[0] = p->initarg[0];
     c.initarg[1] = p->initarg[1];
     c.bitcopy = false;
-    if (anyint) {
+    if (anyint && c.ct == SMR_I64 && p->redop == SMR_RED_NONE && M0 == 2 && p->ops[0].dtype == p->ops[1].dtype && prog.len == 1 &&
+        prog.code[0] == SMR_OP_ARG) {
+        c.bitcopy = true;  // a pure move stays a bit copy of opaque elements (any width, vectorised)
+        c.ct = SMR_F64;
+    }
+    if (anyint && c.ct != SMR_I64 && !c.bitcopy) {
         bool pure = p->redop == SMR_RED_NONE && M0 == 2 && p->ops[0].dtype == p->ops[1].dtype && prog.len == 1 &&
                     prog.code[0] == SMR_OP_ARG;
         if (pure) c.bitcopy = true;
@@ -180,8 +217,8 @@ int canonicalise(const smr_problem* p, Canon& c) {
             for (int k = 1; k < M0; ++k)
                 if (p->ops[k].dtype == SMR_I64 || p->ops[k].dtype == SMR_U64)
                     return set_error(SMR_EUNSUPPORTED,
-                                     "64-bit integer inputs are supported as pure moves only (copy!/permutedims!): arithmetic on them would run in Float64, "
-                                     "which is exact only below 2^53");
+                                     "64-bit integer inputs outside the integer class (all operands integer, f built from + - * neg abs abs2 min max "
+                                     "comparisons select and integer constants): the arithmetic would run in Float64, which is exact only below 2^53");
     }
 
     // working copies
@@ -1165,7 +1202,7 @@ void describe(Plan& plan) {
     static const char* fk[] = {"prog", "ident", "add2", "add3", "add4", "scale", "sym", "axpy", "axpby", "abs2", "mul2", "expr5"};
     static const char* ct[] = {"f32", "f64", "c32", "c64"};
     char buf[1024];
-    int n = std::snprintf(buf, sizeof buf, "family=%s ct=%s%s f=%s N=%d M=%d dims=", fam[plan.family], ct[c.ct],
+    int n = std::snprintf(buf, sizeof buf, "family=%s ct=%s%s f=%s N=%d M=%d dims=", fam[plan.family], c.ct == SMR_I64 ? "i64" : ct[c.ct & 3],
                           c.bitcopy ? "(bitcopy)" : (c.mixed ? "(mixed)" : ""), fk[c.fkind], c.N, c.M);
     for (int i = 0; i < c.N; ++i) n += std::snprintf(buf + n, sizeof buf - n, "%s%lld", i ? "x" : "", (long long)c.dims[i]);
     if (plan.family == FAM_TILED) {

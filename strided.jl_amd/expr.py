@@ -79,6 +79,11 @@ class Const(Expr):
             self.dtype = None                  # weak (Julia Bool/Int do not widen floats)
         elif isinstance(value, numbers.Integral):
             self.dtype = None
+            # constants travel as Float64: an integer beyond 2^53 must survive that exactly -- or be one of the type
+            # limits the integer class saturates to (typemax(Int64) / typemin(Int64), the seeds of min / max)
+            iv = int(value)
+            if abs(iv) > 2 ** 53 and int(float(iv)) != iv and iv not in (2 ** 63 - 1, -2 ** 63):
+                raise OverflowError(f"integer constant {iv} is not representable in the f-program (Float64 constants)")
         elif isinstance(value, numbers.Rational):
             self.dtype = None                  # Fraction ~ Julia Rational: takes the array's float type
             value = value.numerator / value.denominator

@@ -318,22 +318,30 @@ def test_shard_ex_local_operands_and_reported_slab():
             assert out2.ops[1].offset == 30 * lo.value  # replicated operand: shifted inside the whole parent
 
 
-def test_64bit_integer_inputs_are_moves_only():
-    """integer arithmetic runs in Float64 (exact below 2^53); 64-bit integer inputs could hold more,
-    so anything but a pure move of them is SMR_EUNSUPPORTED (the Julia shim falls back to the CPU method)."""
+def test_64bit_integer_inputs_compute_in_the_integer_class_or_are_refused():
+    """Round 3: integer operands + integer-closed f run in the wrapping Int64 class (tests/test_integer_class.py); a 64-bit
+    integer input that meets floating-point arithmetic would run in Float64 (exact only below 2^53) and stays
+    SMR_EUNSUPPORTED (the Julia shim falls back to the CPU method)."""
     lib = L.load()
     h = C.c_void_p()
     a, b = _views((16, 16), [(1, 16), (16, 1)], np.int64)
-    p, keep = S.build_problem(lambda v: v, None, None, (16, 16), (a, b), stream=0)     # permutedims! of Int64: fine
+    p, keep = S.build_problem(lambda v: v, None, None, (16, 16), (a, b), stream=0)     # permutedims! of Int64: a bit copy
     assert lib.smr_plan_create(C.byref(p), C.byref(h)) == 0
     lib.smr_plan_destroy(h)
-    p, keep = S.build_problem(lambda v: v + 1, None, None, (16, 16), (a, b), stream=0)
+    p, keep = S.build_problem(lambda v: v + 1, None, None, (16, 16), (a, b), stream=0)   # integer class
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == 0
+    lib.smr_plan_destroy(h)
+    p, keep = S.build_problem(lambda v: v / 2, None, None, (16, 16), (a, b), stream=0)   # `/` leaves the integers
     assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EUNSUPPORTED and b"2^53" in lib.smr_last_error()
-    o = S.StridedView(np.zeros(1, dtype=np.int64), (16, 16), (0, 0), 0)
-    p, keep = S.build_problem(lambda v: v, "+", None, (16, 16), (o, b), stream=0)       # sum of Int64
+    f, = _views((16, 16), [(1, 16)], np.float64)
+    p, keep = S.build_problem(lambda v, w: v + w, None, None, (16, 16), (f, b, f), stream=0)   # Int64 + Float64
     assert lib.smr_plan_create(C.byref(p), C.byref(h)) == L.SMR_EUNSUPPORTED
+    o = S.StridedView(np.zeros(1, dtype=np.int64), (16, 16), (0, 0), 0)
+    p, keep = S.build_problem(lambda v: v, "+", None, (16, 16), (o, b), stream=0)       # sum of Int64: integer class
+    assert lib.smr_plan_create(C.byref(p), C.byref(h)) == 0
+    lib.smr_plan_destroy(h)
     c32, = _views((16, 16), [(1, 16)], np.int32)
-    p, keep = S.build_problem(lambda v: v, "+", None, (16, 16), (o, c32), stream=0)     # Int32 -> Int64 sum: allowed
+    p, keep = S.build_problem(lambda v: v, "+", None, (16, 16), (o, c32), stream=0)     # Int32 -> Int64 sum
     assert lib.smr_plan_create(C.byref(p), C.byref(h)) == 0
     lib.smr_plan_destroy(h)
 
