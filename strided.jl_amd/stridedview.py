@@ -47,6 +47,9 @@ def _torch_np_dtype(t):
         torch.complex128: np.complex128, torch.int8: np.int8, torch.int16: np.int16,
         torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8, torch.bool: np.bool_,
     }
+    for name, npdt in (("uint16", np.uint16), ("uint32", np.uint32), ("uint64", np.uint64)):  # torch >= 2.3
+        if hasattr(torch, name):
+            table[getattr(torch, name)] = npdt
     if t.dtype not in table:
         raise TypeError(f"torch dtype {t.dtype} is not supported")
     return np.dtype(table[t.dtype])
@@ -60,6 +63,9 @@ def _np_torch_dtype(dt):
         np.dtype(np.int8): torch.int8, np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32,
         np.dtype(np.int64): torch.int64, np.dtype(np.uint8): torch.uint8, np.dtype(np.bool_): torch.bool,
     }
+    for name, npdt in (("uint16", np.uint16), ("uint32", np.uint32), ("uint64", np.uint64)):
+        if hasattr(torch, name):
+            table[np.dtype(npdt)] = getattr(torch, name)
     return table[np.dtype(dt)]
 
 
@@ -283,7 +289,12 @@ class StridedView:
                 shp = [1] * self.ndim
                 shp[d] = n
                 idx = idx + (np.arange(n, dtype=np.int64) * s).reshape(shp)
-            out = flat_t[torch.from_numpy(np.ascontiguousarray(idx)).to(p.device)].cpu().numpy()
+            if self.dtype.kind == "u" and self.dtype.itemsize > 1:
+                # torch has no gather for the wide unsigned types: index the same bits as signed integers
+                sdt = {2: torch.int16, 4: torch.int32, 8: torch.int64}[self.dtype.itemsize]
+                out = flat_t.view(sdt)[torch.from_numpy(np.ascontiguousarray(idx)).to(p.device)].cpu().numpy().view(self.dtype)
+            else:
+                out = flat_t[torch.from_numpy(np.ascontiguousarray(idx)).to(p.device)].cpu().numpy()
             if self.op == "conj":
                 out = np.conj(out)
             return np.asarray(out)
