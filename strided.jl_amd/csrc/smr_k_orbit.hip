@@ -544,7 +544,9 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     const i64 want = options().orbit_pipe;
     bool pipe = false;
     if constexpr (V * sizeof(T) == 16) {
-        pipe = want > 0 ? o.list.size() > 256 : (want < 0 && lds > 80 * 1024 && o.list.size() >= 4 * 256);
+        // at least 8 orbits per CU: with 4 (64^4) the pipelined ComplexF32 kernel -- 128 VGPRs, 20 bytes of scratch -- loses
+        // (68.4 vs 47.6 us) and the Float64 one ties; from 80^4 on it gains 2-4 % (tools/orbit_cplx.py)
+        pipe = want > 0 ? o.list.size() > 256 : (want < 0 && lds > 80 * 1024 && o.list.size() >= 8 * 256);
         if (pipe) return go4<T, F, V, NREP, NG, OWN0, true>(plan, s, f, tab);
     }
     return go4<T, F, V, NREP, NG, OWN0, false>(plan, s, f, tab);

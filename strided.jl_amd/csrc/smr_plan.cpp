@@ -690,7 +690,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
         // LDS: the launch pads a group of order 3 to four slots; "max_lds_bytes" can raise (never lower) the 128 KiB cap
         const size_t slots = o.ng == 3 ? 4 : (size_t)o.ng;
         if (slots * ((size_t)es << (l * nu)) > std::min<size_t>((size_t)160 * 1024, std::max<size_t>((size_t)opt.max_lds_bytes, (size_t)128 * 1024))) continue;
-        if (((i64)es << l) < 32 || l < vlog) continue;  // runs of at least 32 bytes
+        if (((i64)es << l) < opt.orbit_minrun || l < vlog) continue;  // runs of at least 32 bytes (option orbit_minrun)
         if (l * nu < 8) continue;                        // at least 256 elements per tile (128 lanes x 16 B)
         if (opt.orbit_lg >= 0) {
             if (l == opt.orbit_lg) best = l;
@@ -702,7 +702,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
         if (tiles / o.ng >= opt.orbit_min) break;
         // a handful of big workgroups loses against the classic kernel's many small ones (measured: 24^4 f32,
         // 20 orbits of 8^4: 3.96 vs 3.38 us)
-        if (l == 1 || (((i64)es << (l - 1)) < 32) || l - 1 < vlog || (l - 1) * nu < 8)
+        if (l == 1 || (((i64)es << (l - 1)) < opt.orbit_minrun) || l - 1 < vlog || (l - 1) * nu < 8)
             if (tiles / o.ng < opt.orbit_few) best = -1;
     }
     if (best < 0) return false;
