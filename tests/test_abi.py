@@ -184,6 +184,44 @@ def test_tile_order_four_way_permuted_sum_and_opt_out(classic_tiled):
         S.set_option("tile_order", 1)
 
 
+def test_block_tile_order_for_distinct_arrays_with_several_unit_axes():
+    """Round 3: inputs that are DISTINCT arrays with different unit axes have no orbit structure; their
+    tiles are visited in compact blocks (4 tiles per dim) so that tiles in flight together complete each other's short
+    runs.  Every tile exactly once; a block's tiles are adjacent in the list; round-robin over the XCDs once the
+    operands exceed the Infinity Cache, one contiguous run per XCD below it; opt-out with tile_block=0."""
+    n = 64
+    xs = [S.StridedView(np.zeros((n,) * 4, order="F")) for _ in range(4)]
+    y = xs[0].similar()
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    plan = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, y.size, (y, *[x.permutedims(q) for x, q in zip(xs, perms)]))
+    d = plan.describe()
+    assert "family=tiled" in d and "tile=d0:16,d1:8,d2:8,d3:4" in d and "order=orbits:" in d    # big tiles + block order
+    ord_ = np.array(plan.tile_order(), dtype=np.int64)
+    nt = (4, 8, 8, 16)
+    assert sorted(ord_[ord_ != 0xFFFFFFFF]) == list(range(4 * 8 * 8 * 16))
+    first = ord_[:256]                                        # one block = 4 x 4 x 4 x 4 tiles
+    co = np.stack(np.unravel_index(first, nt, order="F"))
+    assert all(co[k].max() - co[k].min() <= 3 for k in range(4))
+    S.set_option("tile_block", 0)
+    try:
+        assert S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, y.size, (y, *[x.permutedims(q) for x, q in zip(xs, perms)])).tile_order() == []
+    finally:
+        S.set_option("tile_block", -1)
+    # cache-resident operands (5 x 21 MiB): one contiguous run of the list per XCD (workgroup b -> XCD b mod 8)
+    m = 40
+    xs = [S.StridedView(np.zeros((m,) * 4, order="F")) for _ in range(4)]
+    y = xs[0].similar()
+    plan = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, y.size, (y, *[x.permutedims(q) for x, q in zip(xs, perms)]))
+    ord_ = np.array(plan.tile_order(), dtype=np.int64)
+    real = ord_[ord_ != 0xFFFFFFFF]
+    assert len(real) == len(set(real.tolist())) and "order=orbits:" in plan.describe()
+    run0 = ord_[0::8][:16]                                    # what XCD 0 executes first: consecutive members of one block
+    nt = tuple(int(v) for v in plan.describe().split("grid=")[0].split("tile=")[1].replace("d0:", "").replace("d1:", "").replace("d2:", "").replace("d3:", "").split()[0].split(","))
+    tiles = tuple(-(-m // e) for e in nt)
+    co = np.stack(np.unravel_index(run0, tiles, order="F"))
+    assert all(co[k].max() - co[k].min() <= 3 for k in range(4))
+
+
 def test_invalid_problems_return_einval():
     x, y = _views((8, 8), [(1, 8), (1, 8)])
     p, keep = S.build_problem(lambda v: v, None, None, (8, 8), (x, y), stream=0)

@@ -79,6 +79,13 @@ def recipe(name, seed, T):
         f, nin, exact = EXPRS[4] if rng0.integers(0, 2) else EXPRS[3]
         dims = pick([(32, 32, 32, 32), (64, 16, 32, 40), (48, 48, 24, 24)])
         mkview = None  # distinct arrays, cyclically permuted: three or more unit axes
+    elif name == "tiled_blocks":
+        # round 3: distinct arrays with three or four different unit axes, the tiles visited in compact blocks
+        # (forced block edge / XCD runs / tile size; VERDICT r2 item 4: `add4 of 4 distinct arrays`, a 3-array map)
+        f, nin, exact = EXPRS[4] if rng0.integers(0, 2) else EXPRS[3]
+        dims = pick([(40, 40, 40, 40), (64, 16, 32, 40), (24, 20, 36, 28), (48, 48, 24, 24), (96, 33, 50)])
+        opts = {"tile_block": int(pick([2, 3, 4, -1])), "tile_block_xcd": int(pick([0, 1])), "tile_log2": int(pick([10, 12, 0]))}
+        mkview = None
     elif name in ("orbit", "aliased_classic", "orbit_pipe"):
         dims = pick([(256, 256), (1024, 1024), (96, 96, 24), (32, 32, 32, 32), (16, 16, 16, 16), (64, 8, 64, 8)])
         if name == "orbit_pipe":  # persistent pipelined form: needs more orbits than CUs
@@ -114,7 +121,7 @@ def recipe(name, seed, T):
     def run(mk, describe=None):
         rng = np.random.default_rng(vseed)
         data = _data(rng, T)
-        if name == "tiled_big":
+        if name in ("tiled_big", "tiled_blocks"):
             ins = [mk(data(dims)).permutedims(tuple((d + k) % N for d in range(N))) if len(set(dims)) == 1
                    else _perm_view(rng, mk, data, dims) for k in range(nin)]
         elif name in ("orbit", "aliased_classic", "orbit_pipe"):
@@ -157,7 +164,7 @@ def _initop_fn(i):
 
 
 RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_short0", "tiled_big", "orbit", "orbit_pipe", "aliased_classic", "generic",
-           "reduce_all", "reduce_part"]
+           "reduce_all", "reduce_part", "tiled_blocks"]
 
 SEED_OFFSET = int(os.environ.get("SMR_FUZZ_SEED_OFFSET", "0"))  # other seeds for longer campaigns on a GPU box
 
@@ -171,7 +178,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
         oraclelib.mapreduce(p, 4)
         return arrays[0]
 
-    n = {"tiled_big": 40, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
+    n = {"tiled_big": 40, "tiled_blocks": 30, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:
@@ -188,14 +195,14 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
                 torch.cuda.synchronize()
             finally:
                 for k in opts:
-                    S.set_option(k, {"tiled_persist_min": 32, "orbit": 1, "orbit_pipe": -1}[k])
+                    S.set_option(k, {"tiled_persist_min": 32, "orbit": 1, "orbit_pipe": -1, "tile_block": -1, "tile_block_xcd": -1, "tile_log2": 0}[k])
             d = desc[0]
             key = d[d.find("family=") + 7:d.find(" ct=")]
             if key == "reduce_part":
                 key += ":" + d[d.find("form=") + 5:].split()[0]
             if key == "tiled":
                 key += ":4096" if "threads=1024" in d else ":1024"
-                key += "+orbit-order" if "order=orbits" in d else ""
+                key += "+order" if "order=orbits" in d else ""
             fam[key] += 1
             msg = f"seed {seed} {np.dtype(T).name} {info} | {d}"
             assert got.shape == want.shape, msg
