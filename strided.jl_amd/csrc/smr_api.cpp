@@ -517,6 +517,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "orbit_group") o.orbit_group = value;
     else if (n == "orbit_wgs") o.orbit_wgs = value;
     else if (n == "orbit_minrun") o.orbit_minrun = value;
+    else if (n == "orbit_skew") o.orbit_skew = value;
     else if (n == "stamp_base" || n == "stamp_cap" || n == "stamp_used") {  // no plan depends on these: keep the cache
         (n == "stamp_base" ? o.stamp_base : (n == "stamp_cap" ? o.stamp_cap : o.stamp_used)) = value;
         return SMR_OK;
@@ -571,6 +572,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "orbit_group") return o.orbit_group;
     if (n == "orbit_wgs") return o.orbit_wgs;
     if (n == "orbit_minrun") return o.orbit_minrun;
+    if (n == "orbit_skew") return o.orbit_skew;
     if (n == "stamp_base") return o.stamp_base;
     if (n == "stamp_cap") return o.stamp_cap;
     if (n == "stamp_used") return o.stamp_used;

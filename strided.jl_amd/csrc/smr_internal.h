@@ -215,6 +215,7 @@ struct Options {
     i64 orbit_group = 2;     // super-cell edge (tiles per tiled dim) of the ORBIT work list: the orbits of one super-cell run
                              // next to each other on one XCD
     i64 stamp_base = 0, stamp_cap = 0, stamp_used = 0;  // SMR_STAMP builds: device buffer of 8-byte words for wave stamps
+    i64 orbit_skew = 0;      // experiment: diagonal enumeration of the ORBIT super-cells (step per super-cell along the other dims)
     i64 orbit_minrun = 16;   // shortest contiguous run (bytes) an ORBIT tile edge may have (round 3: 16 -- Float32 4^4 cubes at 32^4:
                              // 5.60 -> 4.61 us, 24^4 3.41 -> 3.01 us; larger sizes keep the 8^4 cubes)
     i64 orbit_wgs = 0;       // persistent ORBIT form: cap on the number of workgroups (0 = as many as the machine holds at once)

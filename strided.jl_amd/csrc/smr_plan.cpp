@@ -756,6 +756,17 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
             cc[d] = r % ncell[d];
             r /= ncell[d];
         }
+        // skewed enumeration (option orbit_skew): consecutive super-cells step along the DIAGONAL of the tiled dims, so
+        // that the orbits in flight together differ in every coordinate -- at power-of-two sizes the lines of one cube
+        // share a handful of L2 sets (strides 1 KiB / 128 KiB / 16 MiB), and neighbours along one dim share them too
+        if (opt.orbit_skew) {
+            int first = -1;
+            for (int d = 0; d < c.N; ++d)
+                if (sub[d] > 1 || o.lg[d] > 0) {
+                    if (first < 0) first = d;
+                    else cc[d] = (cc[d] + cc[first] * opt.orbit_skew) % ncell[d];
+                }
+        }
         for (int q = 0; q < nsub; ++q) {
             i64 t[MAXN];
             int qq = q;
