@@ -544,19 +544,38 @@ static void plan_tile_order(const Canon& c, TilePlan& t, const int* lg) {
 // tiles that run at the same time form compact blocks (blk tiles along every tiled dim) instead of a slab that is
 // long along dim 0 only, so that every operand -- whatever its unit axis -- has its 32-/64-byte runs completed to
 // longer contiguous pieces by tiles that are in flight together (DRAM row locality; option "tile_block").
+// blk < 0: run-balanced blocks -- along every dim the block is as many tiles long as it takes for the operand whose unit
+// axis that dim is to see ~256 contiguous bytes (a 16 x 8 x 8 x 4 Float64 tile: 2 x 4 x 4 x 8 tiles), about 256 tiles in all.
 static void plan_block_order(const Canon& c, TilePlan& t, const int* lg, int blk, bool xcd_runs) {
-    if (blk < 2 || t.grid < 64 || t.grid > ((i64)1 << 22)) return;
-    i64 nb[MAXN], blocks = 1, tmul[MAXN], acc = 1;
-    int tiled[MAXN], ntd = 0;
+    if (blk == 0 || blk == 1 || t.grid < 64 || t.grid > ((i64)1 << 22)) return;
+    i64 nb[MAXN], blocks = 1, tmul[MAXN], acc = 1, bd[MAXN];
+    const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+    for (int d = 0; d < c.N; ++d) bd[d] = blk > 0 ? blk : 1;
+    if (blk < 0) {
+        i64 prod = 1;
+        for (int d = 0; d < c.N; ++d) {
+            bool unit = false;
+            for (int k = 0; k < c.M; ++k)
+                if (c.strides[k][d] == 1 || c.strides[k][d] == -1) unit = true;
+            if (unit) bd[d] = std::max<i64>(1, 256 / (((i64)es) << lg[d]));
+            bd[d] = std::min<i64>(bd[d], t.ntiles[d]);
+            prod *= bd[d];
+        }
+        for (int guard = 0; prod < 192 && guard < 32; ++guard) {  // fill up to about 256 tiles: grow the shortest extents first
+            int best = -1;
+            for (int d = 0; d < c.N; ++d)
+                if (bd[d] < t.ntiles[d] && (best < 0 || (bd[d] << lg[d]) < (bd[best] << lg[best]))) best = d;
+            if (best < 0) break;
+            prod = prod / bd[best] * std::min<i64>(bd[best] * 2, t.ntiles[best]);
+            bd[best] = std::min<i64>(bd[best] * 2, t.ntiles[best]);
+        }
+    }
     for (int d = 0; d < c.N; ++d) {
         tmul[d] = acc;
         acc *= t.ntiles[d];
-        const bool is_tiled = lg[d] > 0 || true;  // untiled dims (tile extent 1) are blocked as well: their tiles are adjacent rows
-        if (is_tiled) tiled[ntd++] = d;
-        nb[d] = (t.ntiles[d] + blk - 1) / blk;
+        nb[d] = (t.ntiles[d] + bd[d] - 1) / bd[d];
         blocks *= nb[d];
     }
-    (void)tiled;
     std::vector<uint32_t> list;
     list.reserve((size_t)t.grid);
     for (i64 b = 0; b < blocks; ++b) {
@@ -564,8 +583,8 @@ static void plan_block_order(const Canon& c, TilePlan& t, const int* lg, int blk
         for (int d = 0; d < c.N; ++d) {
             bc[d] = r % nb[d];
             r /= nb[d];
-            lo[d] = bc[d] * blk;
-            n[d] = std::min<i64>(blk, t.ntiles[d] - lo[d]);
+            lo[d] = bc[d] * bd[d];
+            n[d] = std::min<i64>(bd[d], t.ntiles[d] - lo[d]);
             cnt *= n[d];
         }
         for (i64 q = 0; q < cnt; ++q) {
@@ -1002,11 +1021,11 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     // 128 x 32 transposing tiles run one-shot: measured round 3 (tools/perm_block_ab.py, Float64) permutedims! 128^4
     // 826 -> 791 us, (2,3,4,1) 866 -> 745 us, (3,4,1,2) 801 -> 699 us, transpose 16384^2 859 -> 719 us, 8192^2 / 12000^2 tie
     t.no_persist = big_transpose;
-    if (t.ord.empty() && (na >= 3 || (o.tile_block_min_axes <= 2 && na >= 2)) && o.tile_block != 0 && (o.tile_block > 0 || t.grid >= 1024)) {
+    if (t.ord.empty() && (na >= 3 || (o.tile_block_min_axes <= 2 && na >= 2)) && o.tile_block != 0 && (o.tile_block > 0 || o.tile_block == -2 || t.grid >= 1024)) {
         // one contiguous run of the list per XCD while the operands fit the Infinity Cache (a block's partner pieces meet in ONE
         // L2: 48^4 45.0 -> 38.5 us); round-robin once they stream from HBM (64^4: 157 vs 175 us)
         const bool xcd_runs = o.tile_block_xcd > 0 || (o.tile_block_xcd < 0 && c.algbytes <= ((i64)256 << 20));
-        plan_block_order(c, t, lg, o.tile_block > 0 ? (int)o.tile_block : 4, xcd_runs);
+        plan_block_order(c, t, lg, o.tile_block > 0 ? (int)o.tile_block : (o.tile_block == -2 ? -1 : 4), xcd_runs);
         t.no_persist = t.no_persist || !t.ord.empty();  // measured: the one-shot form wins on block-ordered lists (128^4: 2715 vs 2773 us)
     }
     return true;

@@ -40,7 +40,8 @@ sizes = [int(a) for a in sys.argv[1:]] or [32, 48, 64, 96, 128]
 variants = [("default (auto)", {}), ("round 2 (natural order)", dict(tile_block=0)),
             ("small, natural", dict(tile_log2=10, tile_block=0)), ("big, natural", dict(tile_log2=12, tile_block=0)),
             ("big, blocks of 3", dict(tile_log2=12, tile_block=3)), ("big, blocks of 4", dict(tile_log2=12, tile_block=4)),
-            ("big, blocks of 6", dict(tile_log2=12, tile_block=6)),
+            ("big, blocks of 6", dict(tile_log2=12, tile_block=6)), ("big, run-balanced blocks", dict(tile_log2=12, tile_block=-2)),
+            ("big, run-balanced, XCD runs", dict(tile_log2=12, tile_block=-2, tile_block_xcd=1)), ("small, run-balanced blocks", dict(tile_log2=10, tile_block=-2)),
             ("big, blocks of 4, XCD runs", dict(tile_log2=12, tile_block=4, tile_block_xcd=1)),
             ("big, blocks of 2, XCD runs", dict(tile_log2=12, tile_block=2, tile_block_xcd=1)),
             ("small, blocks of 4", dict(tile_log2=10, tile_block=4)), ("small, blocks of 6", dict(tile_log2=10, tile_block=6)),

@@ -36,6 +36,7 @@ variants = [("natural", dict(tile_block=0)), ("blocks 2", dict(tile_block=2, til
             ("blocks 4", dict(tile_block=4, tile_block_min_axes=2, tile_block_xcd=0)), ("blocks 8", dict(tile_block=8, tile_block_min_axes=2, tile_block_xcd=0)),
             ("blocks 4, XCD runs", dict(tile_block=4, tile_block_min_axes=2, tile_block_xcd=1)),
             ("natural, never persistent", dict(tile_block=0, tiled_persist=0))]
+DT = {"f64": torch.float64, "f32": torch.float32, "c64": torch.complex64, "c128": torch.complex128}[os.environ.get("DT", "f64")]
 cases = []
 for n in (96, 128, 144):
     cases.append(("permutedims!(4,3,2,1) %d^4" % n, (n,) * 4, (3, 2, 1, 0)))
@@ -45,7 +46,7 @@ for name, shape, q in cases:
     N = 1
     for d in shape:
         N *= d
-    tA = torch.randn(N, dtype=torch.float64, device="cuda")
+    tA = torch.randn(N, dtype=DT, device="cuda")
     tB = torch.empty_like(tA)
     A, B = colmajor_view(S, tA, shape), colmajor_view(S, tB, shape)
     row = []
@@ -54,10 +55,10 @@ for name, shape, q in cases:
         setopt(**kw)
         plan = S.make_plan(lambda x: x, None, None, tuple(shape[i] for i in q), (colmajor_view(S, tB, tuple(shape[i] for i in q)), A.permutedims(q)))
         us = time_plan(plan, 5)
-        row.append("%s %8.1f us %6.0f GB/s" % (vn, us, 16 * N / us / 1e3))
+        row.append("%s %8.1f us %6.0f GB/s" % (vn, us, 2 * tA.element_size() * N / us / 1e3))
     setopt(tile_block=-1, tile_block_min_axes=3, tile_block_xcd=-1, tiled_persist=1)
     d = plan.describe()
-    print("%-30s | " % name + " | ".join(row) + " | " + d[d.find("tile="):d.find(" algb")])
+    print("%-30s %-5s | " % (name, os.environ.get("DT", "f64")) + " | ".join(row) + " | " + d[d.find("tile="):d.find(" algb")])
     sys.stdout.flush()
     del tA, tB, A, B
     torch.cuda.empty_cache()
