@@ -42,6 +42,7 @@ int launch_tiled_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_
 int launch_reduce_all(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_reduce_all) }
 int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_reduce_part) }
 int launch_orbit_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_orbit_map) }
+int launch_flat_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_flat_map) }
 
 static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
     switch (plan.family) {
@@ -55,6 +56,7 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
             std::lock_guard<std::mutex> g(*plan.build_mu);
             return launch_orbit_map(plan, bases, s);
         }
+        case FAM_FLAT: return launch_flat_map(plan, bases, s);
         case FAM_REDUCE_ALL: return launch_reduce_all(plan, bases, s);
         case FAM_REDUCE_PART: return launch_reduce_part(plan, bases, s);
     }
@@ -518,6 +520,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "orbit_wgs") o.orbit_wgs = value;
     else if (n == "orbit_minrun") o.orbit_minrun = value;
     else if (n == "orbit_skew") o.orbit_skew = value;
+    else if (n == "flat") o.flat = value;
     else if (n == "stamp_base" || n == "stamp_cap" || n == "stamp_used") {  // no plan depends on these: keep the cache
         (n == "stamp_base" ? o.stamp_base : (n == "stamp_cap" ? o.stamp_cap : o.stamp_used)) = value;
         return SMR_OK;
@@ -573,6 +576,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "orbit_wgs") return o.orbit_wgs;
     if (n == "orbit_minrun") return o.orbit_minrun;
     if (n == "orbit_skew") return o.orbit_skew;
+    if (n == "flat") return o.flat;
     if (n == "stamp_base") return o.stamp_base;
     if (n == "stamp_cap") return o.stamp_cap;
     if (n == "stamp_used") return o.stamp_used;

@@ -99,6 +99,7 @@ template <int CT> int launch_tiled_map_ct(const Plan&, void* const*, hipStream_t
 template <int CT> int launch_reduce_all_ct(const Plan&, void* const*, hipStream_t);
 template <int CT> int launch_reduce_part_ct(const Plan&, void* const*, hipStream_t);
 template <int CT> int launch_orbit_map_ct(const Plan&, void* const*, hipStream_t);
+template <int CT> int launch_flat_map_ct(const Plan&, void* const*, hipStream_t);
 
 // Fills the kernel operand table: base pointers with the element offset folded in.
 inline OpTab make_optab(const Canon& c, void* const* bases) {

@@ -87,7 +87,8 @@ enum Family : int {
     FAM_TILED = 3,    // LDS-staged: operands with different unit-stride axes
     FAM_REDUCE_ALL = 4,
     FAM_REDUCE_PART = 5,
-    FAM_ORBIT = 6     // LDS-staged: every input is a differently permuted view of ONE buffer
+    FAM_ORBIT = 6,    // LDS-staged: every input is a differently permuted view of ONE buffer
+    FAM_FLAT = 7      // unary transposing map whose short leading dims (extents not powers of two) are addressed as one flat run
 };
 
 #ifndef SMR_JIT
@@ -158,11 +159,23 @@ struct OrbitPlan {
     size_t lds_bytes = 0;
 };
 
+// Description for FAM_FLAT (smr_k_flat.hip): one side ("flat": dir 0 = destination, 1 = the input) is contiguous over a
+// group of leading dims taken whole (extents multiply to R <= 64) and a power-of-two tile of the next contiguous dim p;
+// the other side ("line") is unit-stride along dim q.
+struct FlatPlan {
+    int dir = 0, R = 1, tplog = 0, tqlog = 5;
+    int p = -1, q = -1;
+    bool fuse = false;  // the flat side's run continues along q itself (planar <-> interleaved): the R x TQ tile is one run
+    bool ingroup[MAXN] = {false, false, false, false, false, false, false, false};
+    int32_t roff[64];  // line-side element offset of the leading index r
+};
+
 struct Plan {
     Canon c;
     int family = FAM_GENERIC;
     TilePlan tile;
     OrbitPlan orbit;
+    FlatPlan flat;
     // STREAM
     int vec = 1;        // elements per vector access
     // reductions
@@ -215,6 +228,7 @@ struct Options {
     i64 orbit_group = 2;     // super-cell edge (tiles per tiled dim) of the ORBIT work list: the orbits of one super-cell run
                              // next to each other on one XCD
     i64 stamp_base = 0, stamp_cap = 0, stamp_used = 0;  // SMR_STAMP builds: device buffer of 8-byte words for wave stamps
+    i64 flat = 1;            // FAM_FLAT for transposing unary maps with short non-power-of-two leading dims (0 = TILED as in round 2)
     i64 orbit_skew = 0;      // experiment: diagonal enumeration of the ORBIT super-cells (step per super-cell along the other dims)
     i64 orbit_minrun = 16;   // shortest contiguous run (bytes) an ORBIT tile edge may have (round 3: 16 -- Float32 4^4 cubes at 32^4:
                              // 5.60 -> 4.61 us, 24^4 3.41 -> 3.01 us; larger sizes keep the 8^4 cubes)
@@ -279,6 +293,7 @@ int launch_tiled_map(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_reduce_all(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s);
 int launch_orbit_map(const Plan& plan, void* const* bases, hipStream_t s);
+int launch_flat_map(const Plan& plan, void* const* bases, hipStream_t s);
 
 #endif  // !SMR_JIT
 

@@ -1,0 +1,341 @@
+// smr_k_flat.hip -- family FLAT (round 3): transposing unary maps in which ONE side's contiguous memory run is a short group of
+// leading dims whose extents are not powers of two -- permutedims (640,480,3) <-> (3,480,640) (image planes <-> interleaved
+// channels), tensor-network shapes with physical dims of 3 (100,3,100,3,10), ... -- while the other side is unit-stride along a
+// long dim.  The power-of-two tiles of the TILED family idle a quarter of their lanes on an extent of 3 and fall back to 8-byte
+// accesses (1.1-2.0 TB/s, profiles/r02_perf_sanity.txt).  Here the flat side is addressed through its FLATTENED run: the leading
+// dims d_0..d_{g-1} (extents multiply to R) are taken whole, the next contiguous dim p contributes a power-of-two tile TP, and
+// j = r + R * jp enumerates L = R * TP consecutive elements of memory (16-byte vectors whenever L * sizeof(T) allows); the line
+// side walks its own unit axis q in 16-byte vectors (tile TQ).  The L x TQ tile crosses LDS once (row pitch padded by one vector).
+// DIR 0: the destination is the flat side; DIR 1: the input is.  Reference semantics: a pure map! with one input
+// (src/mapreduce.jl:38-53 -> _mapreduce_kernel! :229-349), any unary f.
+#ifndef SMR_JIT
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+#include "smr_dispatch.h"
+
+#ifndef SMR_CT
+#error "compile with -DSMR_CT=0..3 or 7"
+#endif
+
+namespace smr {
+
+constexpr int FLAT_MAXR = 64;
+
+struct FlatArgs {
+    OpTab ops;
+    int32_t N, dir, R, TPlog, TQ, L;      // L = R << TPlog; TQ: tile of the line side (a vector multiple, not necessarily a power of two)
+    int32_t p, q;                         // tiled group dim of the flat side (-1: none), unit axis of the line side
+    int32_t nouter, conjv;                // dims handled by the block index besides p and q; conjv: any conj flag set
+    int32_t fuse, pad0;                   // fuse: the flat side continues along q itself (stride of q = R): the whole R x TQ tile is ONE run
+    uint32_t ntp, ntq;                    // tiles along p / q
+    uint32_t magicR, magicLv, magicXV, pad1;  // floor(2^32 / d) + 1 for d = R, L / VF, TQ / VL
+    i64 dimp, dimq;                       // extents of p (1 when p < 0) and q
+    i64 sfq, slp;                         // flat-side stride of q, line-side stride of p
+    i64 sfp;                              // flat-side stride of p (= R)
+    int32_t roff[FLAT_MAXR];              // line-side element offset of the leading index r
+    int32_t odim[MAXN];                   // outer dims (neither in the group nor p nor q)
+    i64 oext[MAXN], osf[MAXN], osl[MAXN]; // their extents and flat- / line-side strides
+};
+
+template <class T, int V>
+struct alignas(sizeof(T) * V) FVec {
+    T v[V];
+};
+
+// n / d for n < 65536, d < 65536 with magic = floor(2^32 / d) + 1
+SMR_DEV uint32_t fdiv16(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
+
+// VL / VF: elements per access on the line / flat side (1 or 16 bytes' worth)
+template <class T, class F, int DIR, int VL, int VF>
+SMR_DEV void flat_map_body(const FlatArgs a, F f) {
+    constexpr int PAD = (16 / (int)sizeof(T)) > 0 ? (16 / (int)sizeof(T)) : 1;
+    const int TQ = a.TQ;                   // tile of the line side (runtime: ~32 / 64 elements, up to 512 in the fused form)
+    const int PITCH = TQ + PAD;
+    const int XV = TQ / VL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_flat[];
+    T* lds = reinterpret_cast<T*>(smem_flat);
+    const uint32_t tid = threadIdx.x;
+    // ---- tile origin: block -> (tq, tp, outer index) -------------------------------------------------------------
+    uint32_t b = blockIdx.x;
+    const uint32_t tq = b % a.ntq;
+    b /= a.ntq;
+    const uint32_t tp = b % a.ntp;
+    b /= a.ntp;
+    i64 bf = 0, bl = 0;  // element offsets of the tile origin on the flat / line side
+    for (int i = 0; i < a.nouter; ++i) {
+        const uint32_t e = (uint32_t)a.oext[i];
+        const uint32_t c = b % e;
+        b /= e;
+        bf += (i64)c * a.osf[i];
+        bl += (i64)c * a.osl[i];
+    }
+    const i64 q0 = (i64)tq * TQ, p0 = (i64)tp << a.TPlog;
+    bf += q0 * a.sfq + p0 * a.sfp;
+    bl += q0 + p0 * a.slp;
+    const int nq = (int)((a.dimq - q0 < TQ) ? (a.dimq - q0) : TQ);                       // valid columns
+    const i64 vp = (a.dimp - p0 < ((i64)1 << a.TPlog)) ? (a.dimp - p0) : ((i64)1 << a.TPlog);
+    const int nj = (int)(vp * a.R);                                                        // valid flat run (a contiguous prefix)
+    const T* src = (const T*)a.ops.base[1];
+    T* dst = (T*)a.ops.base[0];
+    const bool cin = a.conjv && a.ops.conj[1], cout = a.conjv && a.ops.conj[0];
+    (void)cin;
+    (void)cout;
+
+    // ---- phase 1: global -> LDS[j][x] --------------------------------------------------------------------------------
+    if constexpr (DIR == 0) {
+        // the input is the line side: 16-byte vectors along q
+        const int nvec = a.L * XV;
+        for (int v = (int)tid; v < nvec; v += 256) {
+            const int j = (int)fdiv16((uint32_t)v, a.magicXV), x = (v - j * XV) * VL;
+            if (j < nj && x < nq) {
+                const uint32_t jp = fdiv16((uint32_t)j, a.magicR);
+                const int r = j - (int)jp * a.R;
+                const FVec<T, VL> t = *reinterpret_cast<const FVec<T, VL>*>(src + bl + a.roff[r] + (i64)jp * a.slp + x);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) lds[j * PITCH + x + e] = t.v[e];
+            }
+        }
+    } else {
+        // the input is the flat side: 16-byte vectors along the flattened run
+        const int LV = a.L / VF;
+        const int nvec = LV * TQ;
+        if (a.fuse) {  // planar <-> interleaved: element t = x * R + r of the tile, all of it contiguous
+            const int nt = a.R * nq;
+            for (int t0 = (int)tid * VF; t0 < nt; t0 += 256 * VF) {
+                const FVec<T, VF> t = *reinterpret_cast<const FVec<T, VF>*>(src + bf + t0);
+#pragma unroll
+                for (int e = 0; e < VF; ++e) {
+                    const int x = (int)fdiv16((uint32_t)(t0 + e), a.magicR), r = t0 + e - x * a.R;
+                    lds[r * PITCH + x] = t.v[e];
+                }
+            }
+        } else
+        for (int v = (int)tid; v < nvec; v += 256) {
+            const int x = (int)fdiv16((uint32_t)v, a.magicLv), j = (v - x * LV) * VF;
+            if (j < nj && x < nq) {
+                const FVec<T, VF> t = *reinterpret_cast<const FVec<T, VF>*>(src + bf + (i64)x * a.sfq + j);
+#pragma unroll
+                for (int e = 0; e < VF; ++e) lds[(j + e) * PITCH + x] = t.v[e];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: LDS -> f -> global ------------------------------------------------------------------------------------
+    if constexpr (DIR == 0) {
+        const int LV = a.L / VF;
+        const int nvec = LV * TQ;
+        if (a.fuse) {
+            const int nt = a.R * nq;
+            for (int t0 = (int)tid * VF; t0 < nt; t0 += 256 * VF) {
+                FVec<T, VF> o;
+#pragma unroll
+                for (int e = 0; e < VF; ++e) {
+                    const int x = (int)fdiv16((uint32_t)(t0 + e), a.magicR), r = t0 + e - x * a.R;
+                    T arg[MAXIN];
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
+                    T t = lds[r * PITCH + x];
+                    if constexpr (tr<T>::cx) {
+                        if (cin) t = cj(t);
+                    }
+                    arg[0] = t;
+                    T rr = f(arg);
+                    if constexpr (tr<T>::cx) {
+                        if (cout) rr = cj(rr);
+                    }
+                    o.v[e] = rr;
+                }
+                *reinterpret_cast<FVec<T, VF>*>(dst + bf + t0) = o;
+            }
+        } else
+        for (int v = (int)tid; v < nvec; v += 256) {
+            const int x = (int)fdiv16((uint32_t)v, a.magicLv), j = (v - x * LV) * VF;
+            if (j < nj && x < nq) {
+                FVec<T, VF> o;
+#pragma unroll
+                for (int e = 0; e < VF; ++e) {
+                    T arg[MAXIN];
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
+                    T t = lds[(j + e) * PITCH + x];
+                    if constexpr (tr<T>::cx) {
+                        if (cin) t = cj(t);
+                    }
+                    arg[0] = t;
+                    T r = f(arg);
+                    if constexpr (tr<T>::cx) {
+                        if (cout) r = cj(r);
+                    }
+                    o.v[e] = r;
+                }
+                *reinterpret_cast<FVec<T, VF>*>(dst + bf + (i64)x * a.sfq + j) = o;
+            }
+        }
+    } else {
+        const int nvec = a.L * XV;
+        for (int v = (int)tid; v < nvec; v += 256) {
+            const int j = (int)fdiv16((uint32_t)v, a.magicXV), x = (v - j * XV) * VL;
+            if (j < nj && x < nq) {
+                const uint32_t jp = fdiv16((uint32_t)j, a.magicR);
+                const int r = j - (int)jp * a.R;
+                FVec<T, VL> o;
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    T arg[MAXIN];
+#pragma unroll
+                    for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
+                    T t = lds[j * PITCH + x + e];
+                    if constexpr (tr<T>::cx) {
+                        if (cin) t = cj(t);
+                    }
+                    arg[0] = t;
+                    T rr = f(arg);
+                    if constexpr (tr<T>::cx) {
+                        if (cout) rr = cj(rr);
+                    }
+                    o.v[e] = rr;
+                }
+                *reinterpret_cast<FVec<T, VL>*>(dst + bl + a.roff[r] + (i64)jp * a.slp + x) = o;
+            }
+        }
+    }
+}
+
+#ifndef SMR_JIT
+template <class T, class F, int DIR, int VL, int VF>
+__global__ void __launch_bounds__(256) k_flat_map(const FlatArgs a, F f) {
+    flat_map_body<T, F, DIR, VL, VF>(a, f);
+}
+
+template <class T, class F, int DIR, int VL, int VF>
+static int go3(const Plan& plan, hipStream_t s, F f, const FlatArgs& a, size_t lds, unsigned grid) {
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "flat";
+        l.tname = tname<T>();
+        l.argtype = "smr::FlatArgs";
+        l.entry = std::string("smr::flat_map_body<") + tname<T>() + ", smr::FJit, " + std::to_string(DIR) + ", " + std::to_string(VL) + ", " +
+                  std::to_string(VF) + ">(a, smr::FJit{kc});";
+        l.grid = grid;
+        l.block = 256;
+        l.lds = lds;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(plan.c, l, s);
+    } else {
+        if (jit_no_launch()) return SMR_OK;
+        clear_sticky_error();
+        hipLaunchKernelGGL((k_flat_map<T, F, DIR, VL, VF>), dim3(grid), dim3(256), lds, s, a, f);
+        return check_launch("k_flat_map");
+    }
+}
+
+template <class T, class F>
+static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    const Canon& c = plan.c;
+    const FlatPlan& fp = plan.flat;
+    constexpr int VMAX = (16 / (int)sizeof(T)) > 1 ? (16 / (int)sizeof(T)) : 1;
+    // tile of the line side: about 1 << tqlog elements, evened out over the extent (100 -> 4 tiles of 26, not 3 of 32 + 1 of 4),
+    // a multiple of the vector width
+    int TQ = 1 << fp.tqlog;
+    {
+        const i64 nt = (c.dims[fp.q] + TQ - 1) / TQ;
+        TQ = (int)((c.dims[fp.q] + nt - 1) / nt);
+        TQ = (TQ + VMAX - 1) / VMAX * VMAX;
+    }
+    FlatArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.ops = make_optab(c, bases);
+    a.N = c.N;
+    a.dir = fp.dir;
+    a.R = fp.R;
+    a.TPlog = fp.tplog;
+    a.L = fp.R << fp.tplog;
+    a.TQ = TQ;
+    a.p = fp.p;
+    a.q = fp.q;
+    const int kf = fp.dir == 0 ? 0 : 1, kl = 1 - kf;  // operand index of the flat / line side
+    a.dimp = fp.p >= 0 ? c.dims[fp.p] : 1;
+    a.dimq = c.dims[fp.q];
+    a.sfq = c.strides[kf][fp.q];
+    a.sfp = fp.R;
+    a.slp = fp.p >= 0 ? c.strides[kl][fp.p] : 0;
+    a.ntp = (unsigned)((a.dimp + ((i64)1 << fp.tplog) - 1) >> fp.tplog);
+    a.ntq = (unsigned)((a.dimq + TQ - 1) / TQ);
+    a.conjv = (c.conj[0] || c.conj[1]) ? 1 : 0;
+    a.fuse = fp.fuse ? 1 : 0;
+    for (int r = 0; r < fp.R; ++r) a.roff[r] = fp.roff[r];
+    i64 blocks = (i64)a.ntp * a.ntq;
+    for (int d = 0; d < c.N; ++d) {
+        if (d == fp.p || d == fp.q || fp.ingroup[d]) continue;
+        a.odim[a.nouter] = d;
+        a.oext[a.nouter] = c.dims[d];
+        a.osf[a.nouter] = c.strides[kf][d];
+        a.osl[a.nouter] = c.strides[kl][d];
+        blocks *= c.dims[d];
+        ++a.nouter;
+    }
+    if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "flat plan: too many tiles");
+    // vector widths: 16 bytes where extents, strides and base addresses allow
+    int vl = VMAX, vf = VMAX;
+    auto aligned = [&](int k) { return (((uintptr_t)a.ops.base[k]) % 16) == 0; };
+    if (c.dims[fp.q] % VMAX || !aligned(kl)) vl = 1;
+    for (int d = 0; d < c.N; ++d)
+        if (d != fp.q && c.strides[kl][d] % VMAX) vl = 1;
+    if (fp.fuse) {
+        // the run is R * (valid columns): whole vectors when R * extent(q) is a vector multiple (tile origins are q0 * R)
+        if ((fp.R * c.dims[fp.q]) % VMAX || !aligned(kf)) vf = 1;
+        for (int d = 0; d < c.N; ++d)
+            if (!fp.ingroup[d] && d != fp.q && c.strides[kf][d] % VMAX) vf = 1;
+    } else {
+        if (a.L % VMAX || !aligned(kf)) vf = 1;
+        if ((fp.R * (fp.p >= 0 ? c.dims[fp.p] : 1)) % VMAX) vf = 1;  // a ragged last tile must end on a vector boundary
+        for (int d = 0; d < c.N; ++d)
+            if (!fp.ingroup[d] && d != fp.p && c.strides[kf][d] % VMAX) vf = 1;
+    }
+    a.magicR = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)fp.R + 1);
+    a.magicXV = (TQ / vl) > 1 ? (uint32_t)(((uint64_t)1 << 32) / (uint32_t)(TQ / vl) + 1) : 0u;
+    a.magicLv = (a.L / vf) > 1 ? (uint32_t)(((uint64_t)1 << 32) / (uint32_t)(a.L / vf) + 1) : 0u;  // unused in the fused form
+    constexpr int PAD = (16 / (int)sizeof(T)) > 0 ? (16 / (int)sizeof(T)) : 1;
+    const size_t lds = (size_t)a.L * (TQ + PAD) * sizeof(T);
+    const unsigned grid = (unsigned)blocks;
+    auto run = [&](auto DIRc) -> int {
+        constexpr int DIR = decltype(DIRc)::value;
+        if constexpr (VMAX > 1) {
+            if (vl > 1 && vf > 1) return go3<T, F, DIR, VMAX, VMAX>(plan, s, f, a, lds, grid);
+            if (vl > 1) return go3<T, F, DIR, VMAX, 1>(plan, s, f, a, lds, grid);
+            if (vf > 1) return go3<T, F, DIR, 1, VMAX>(plan, s, f, a, lds, grid);
+        }
+        return go3<T, F, DIR, 1, 1>(plan, s, f, a, lds, grid);
+    };
+    return fp.dir == 0 ? run(std::integral_constant<int, 0>{}) : run(std::integral_constant<int, 1>{});
+}
+
+template <>
+int launch_flat_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
+    typedef ct_type<SMR_CT>::type T;
+    const Canon& c = plan.c;
+    if (c.bitcopy) {
+#if SMR_CT == SMR_F32
+        switch (c.esize[0]) {
+            case 4: return go<float, FIdent<float>>(plan, bases, s, FIdent<float>{});
+            case 8: return go<double, FIdent<double>>(plan, bases, s, FIdent<double>{});
+            case 16: return go<c64, FIdent<c64>>(plan, bases, s, FIdent<c64>{});
+            default: return set_error(SMR_EINVAL, "flat plan: 1- / 2-byte moves take the generic family");
+        }
+#else
+        return set_error(SMR_EINVAL, "bitcopy is dispatched through the f32 object");
+#endif
+    }
+    switch (c.fkind) {
+        case FK_IDENT: return go<T, FIdent<T>>(plan, bases, s, FIdent<T>{});
+        case FK_SCALE: return go<T, FScale<T>>(plan, bases, s, FScale<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        default: break;
+    }
+    return with_prog<T>(c, [&](auto f) { return go<T, decltype(f)>(plan, bases, s, f); });
+}
+#endif  // !SMR_JIT
+
+}  // namespace smr

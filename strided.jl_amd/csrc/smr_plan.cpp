@@ -33,6 +33,8 @@ Options& options() {
     return o;
 }
 
+constexpr i64 FLAT_GROUP_MAX = 64;
+
 static int nextpow2_log(i64 v) {
     int l = 0;
     while (((i64)1 << l) < v) ++l;
@@ -1031,6 +1033,97 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     return true;
 }
 
+// ---- flat planning (FAM_FLAT) -----------------------------------------------------------------------------
+// A unary transposing map in which one side's memory run consists of short leading dims with extents that are not powers of
+// two (an image's 3 channels, a physical index of 3 in a tensor network): smr_k_flat.hip addresses that side through the
+// flattened run.  side = 0: the destination is flat, 1: the input.
+static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
+    const int kf = side == 0 ? 0 : 1, kl = 1 - kf;
+    const i64* sf = c.strides[kf];
+    const i64* sl = c.strides[kl];
+    // leading dim of the flat side
+    int lead = -1;
+    for (int d = 0; d < c.N; ++d)
+        if (sf[d] == 1 && c.dims[d] > 1) lead = d;
+    if (lead < 0) return false;
+    const i64 e0 = c.dims[lead];
+    if (e0 * es >= 128 || (e0 & (e0 - 1)) == 0) return false;  // long or power-of-two leading dims: the tiled family's ground
+    // unit axis of the line side: not the lead
+    int q = -1;
+    for (int d = 0; d < c.N; ++d)
+        if (d != lead && sl[d] == 1 && c.dims[d] >= 16) q = d;
+    if (q < 0) return false;
+    if (sl[lead] == 1 || sl[lead] == -1) return false;
+    for (int d = 0; d < MAXN; ++d) f.ingroup[d] = false;
+    f.ingroup[lead] = true;
+    i64 R = e0;
+    int p = -1;
+    // take further contiguous dims whole while the run stays short, then tile the next one
+    for (;;) {
+        int nxt = -1;
+        for (int d = 0; d < c.N; ++d)
+            if (!f.ingroup[d] && d != q && sf[d] == R && c.dims[d] > 1) nxt = d;
+        if (nxt < 0) break;
+        if (R * es < 192 && R * c.dims[nxt] <= FLAT_GROUP_MAX && R * c.dims[nxt] * es <= 512) {
+            f.ingroup[nxt] = true;
+            R *= c.dims[nxt];
+            continue;
+        }
+        p = nxt;
+        break;
+    }
+    if (R > 64) return false;
+    int tplog = 0;
+    if (p >= 0)
+        while ((R << tplog) * es < 256 && ((i64)1 << tplog) < c.dims[p] && (R << (tplog + 1)) <= 128) ++tplog;
+    const i64 L = R << tplog;
+    // planar <-> interleaved (NCHW <-> NHWC with 3 channels): the flat side continues along q ITSELF
+    f.fuse = p < 0 && sf[q] == R;
+    const int vmax = std::max(1, 16 / es);
+    if (!f.fuse) {
+        if (L * es < 96 || L > 128) return false;      // no run worth flattening
+        if (L / vmax < 2) return false;
+    }
+    f.dir = side;
+    f.R = (int)R;
+    f.tplog = tplog;
+    f.tqlog = es >= 8 ? 5 : 6;
+    if (f.fuse) {  // the whole R x TQ tile is one run: up to 2048 elements per workgroup (3 channels: 512 pixels)
+        f.tqlog = 5;
+        while (f.tqlog < 9 && (R << (f.tqlog + 1)) <= 2048 && ((i64)1 << f.tqlog) < c.dims[q]) ++f.tqlog;
+    }
+    f.p = p;
+    f.q = q;
+    // line-side offsets of the leading index r (mixed radix over the group dims in flat-side stride order)
+    std::vector<int> order;
+    for (int d = 0; d < c.N; ++d)
+        if (f.ingroup[d]) order.push_back(d);
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return sf[x] < sf[y]; });
+    for (i64 r = 0; r < R; ++r) {
+        i64 rem = r, off = 0;
+        for (int d : order) {
+            off += (rem % c.dims[d]) * sl[d];
+            rem /= c.dims[d];
+        }
+        if (off > 2147483647LL || off < -2147483647LL) return false;
+        f.roff[r] = (int32_t)off;
+    }
+    return true;
+}
+
+static bool plan_flat(const Canon& c, FlatPlan& f) {
+    const Options& o = options();
+    if (!o.flat || c.redop != SMR_RED_NONE || c.M != 2 || c.mixed || c.N < 2) return false;
+    const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+    if (es < 4) return false;
+    if (c.prog.len > 0) {  // unary f: every ARG is input 1 (M == 2 guarantees it)
+    }
+    if (c.total < 65536) return false;  // small boxes: generic / tiled are fine and launch-bound anyway
+    for (int d = 0; d < c.N; ++d)
+        if (c.strides[0][d] <= 0) return false;
+    return plan_flat_side(c, f, 0, es) || plan_flat_side(c, f, 1, es);
+}
+
 // ---- family selection -------------------------------------------------------------------------------
 int make_plan(const smr_problem* p, Plan& plan) {
     int rc = canonicalise(p, plan.c);
@@ -1038,7 +1131,9 @@ int make_plan(const smr_problem* p, Plan& plan) {
     const Canon& c = plan.c;
     const Options& o = options();
     int fam = FAM_GENERIC;
-    if (c.redop == SMR_RED_NONE) {
+    if (c.redop == SMR_RED_NONE && o.force_family == 0 && plan_flat(c, plan.flat)) {
+        fam = FAM_FLAT;
+    } else if (c.redop == SMR_RED_NONE) {
         bool stream = true;
         for (int k = 0; k < c.M; ++k) {
             i64 s = c.strides[k][0];
@@ -1228,7 +1323,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
 
 void describe(Plan& plan) {
     const Canon& c = plan.c;
-    static const char* fam[] = {"auto", "generic", "stream", "tiled", "reduce_all", "reduce_part", "orbit"};
+    static const char* fam[] = {"auto", "generic", "stream", "tiled", "reduce_all", "reduce_part", "orbit", "flat"};
     static const char* fk[] = {"prog", "ident", "add2", "add3", "add4", "scale", "sym", "axpy", "axpby", "abs2", "mul2", "expr5"};
     static const char* ct[] = {"f32", "f64", "c32", "c64"};
     char buf[1024];
@@ -1252,6 +1347,10 @@ void describe(Plan& plan) {
                 first = false;
             }
         n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.list.size());
+    } else if (plan.family == FAM_FLAT) {
+        const FlatPlan& fp = plan.flat;
+        n += std::snprintf(buf + n, sizeof buf - n, " flat_side=%s run=%dx%d(d%d)%s line=d%d:%d", fp.dir == 0 ? "dest" : "input", fp.R, 1 << fp.tplog, fp.p,
+                           fp.fuse ? "+line" : "", fp.q, 1 << fp.tqlog);
     } else if (plan.family == FAM_STREAM) {
         n += std::snprintf(buf + n, sizeof buf - n, " vec=%d", plan.vec);
     } else if (plan.family == FAM_REDUCE_ALL) {

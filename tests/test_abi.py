@@ -418,7 +418,19 @@ def test_planner_rules_for_short_dims_big_transposes_and_short_reductions():
     # a nearly idle short-row STREAM workgroup goes elsewhere
     assert "family=stream" not in perm((4,) * 8, (0, 3, 5, 4, 2, 6, 7, 1))
     # a unit axis shorter than the run target continues into the dim whose stride equals its extent
-    assert "tile=d0:32,d1:8,d2:4" in perm((3, 1000, 700), (2, 1, 0))
+    S.set_option("flat", 0)
+    try:
+        assert "tile=d0:32,d1:8,d2:4" in perm((3, 1000, 700), (2, 1, 0))
+    finally:
+        S.set_option("flat", 1)
+    # round 3: short leading dims with extents that are not powers of two are addressed as ONE flat run (FLAT family)
+    d = perm((3, 1000, 700), (2, 1, 0))
+    assert "family=flat" in d and "flat_side=input run=3x16(d1) line=d0:32" in d, d
+    d = perm((640, 480, 3), (2, 1, 0))
+    assert "family=flat" in d and "flat_side=dest run=3x16(d1) line=d2:32" in d, d
+    d = perm((100, 3, 100, 3, 10), (4, 3, 2, 1, 0))
+    assert "family=flat" in d and "run=30x2(d2)" in d, d
+    assert "family=flat" not in perm((4, 1000, 700), (2, 1, 0))      # powers of two stay with the tiled family
     # HBM-sized transposes of 8-/16-byte elements: 128 x 32 tiles on 1024 lanes; Float32 and smaller problems: 32 x 32
     assert "tile=d0:128,d1:32" in perm((8192, 8192), (1, 0)) and "threads=1024" in perm((8192, 8192), (1, 0))
     assert "tile=d0:32,d1:32" in perm((8192, 8192), (1, 0), np.float32)
