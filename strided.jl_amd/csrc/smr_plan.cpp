@@ -1051,7 +1051,7 @@ static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
     // unit axis of the line side: not the lead
     int q = -1;
     for (int d = 0; d < c.N; ++d)
-        if (d != lead && sl[d] == 1 && c.dims[d] >= 16) q = d;
+        if (d != lead && sl[d] == 1 && c.dims[d] * es >= 64) q = d;   // line-side runs of at least 64 bytes
     if (q < 0) return false;
     if (sl[lead] == 1 || sl[lead] == -1) return false;
     for (int d = 0; d < MAXN; ++d) f.ingroup[d] = false;
