@@ -165,6 +165,7 @@ struct OrbitPlan {
 struct FlatPlan {
     int dir = 0, R = 1, tplog = 0, tqlog = 5;
     int p = -1, q = -1;
+    bool lshare = false;  // the line side is unit-stride along the SAME lead and continues along q (a transposition of R-element groups)
     bool fuse = false;  // the flat side's run continues along q itself (planar <-> interleaved): the R x TQ tile is one run
     bool ingroup[MAXN] = {false, false, false, false, false, false, false, false};
     int32_t roff[64];  // line-side element offset of the leading index r

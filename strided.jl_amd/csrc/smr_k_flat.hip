@@ -28,9 +28,11 @@ struct FlatArgs {
     int32_t N, dir, R, TPlog, TQ, L;      // L = R << TPlog; TQ: tile of the line side (a vector multiple, not necessarily a power of two)
     int32_t p, q;                         // tiled group dim of the flat side (-1: none), unit axis of the line side
     int32_t nouter, conjv;                // dims handled by the block index besides p and q; conjv: any conj flag set
-    int32_t fuse, pad0;                   // fuse: the flat side continues along q itself (stride of q = R): the whole R x TQ tile is ONE run
+    int32_t fuse, lshare;                  // fuse: the flat side continues along q itself (stride of q = R): the whole R x TQ tile is ONE run;
+                                          // lshare: the LINE side is unit-stride along the shared lead and continues along q (stride R): a
+                                          // transposition of R-element groups ((3,W,H) -> (3,H,W)); its rows are runs of R * TQ elements
     uint32_t ntp, ntq;                    // tiles along p / q
-    uint32_t magicR, magicLv, magicXV, pad1;  // floor(2^32 / d) + 1 for d = R, L / VF, TQ / VL
+    uint32_t magicR, magicLv, magicXV, magicRow;  // floor(2^32 / d) + 1 for d = R, L / VF, TQ / VL, R * TQ / VL
     i64 dimp, dimq;                       // extents of p (1 when p < 0) and q
     i64 sfq, slp;                         // flat-side stride of q, line-side stride of p
     i64 sfp;                              // flat-side stride of p (= R)
@@ -73,7 +75,7 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
     }
     const i64 q0 = (i64)tq * TQ, p0 = (i64)tp << a.TPlog;
     bf += q0 * a.sfq + p0 * a.sfp;
-    bl += q0 + p0 * a.slp;
+    bl += q0 * (a.lshare ? a.R : 1) + p0 * a.slp;
     const int nq = (int)((a.dimq - q0 < TQ) ? (a.dimq - q0) : TQ);                       // valid columns
     const i64 vp = (a.dimp - p0 < ((i64)1 << a.TPlog)) ? (a.dimp - p0) : ((i64)1 << a.TPlog);
     const int nj = (int)(vp * a.R);                                                        // valid flat run (a contiguous prefix)
@@ -87,6 +89,21 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
     if constexpr (DIR == 0) {
         // the input is the line side: 16-byte vectors along q
         const int nvec = a.L * XV;
+        if (a.lshare) {
+            // rows jp of R * nq contiguous elements t = x * R + r
+            const int rowv = (a.R * TQ) / VL, nt = a.R * nq, njp = nj / a.R;
+            for (int v = (int)tid; v < rowv * njp; v += 256) {
+                const int jp = (int)fdiv16((uint32_t)v, a.magicRow), t0 = (v - jp * rowv) * VL;
+                if (t0 < nt) {
+                    const FVec<T, VL> t = *reinterpret_cast<const FVec<T, VL>*>(src + bl + (i64)jp * a.slp + t0);
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) {
+                        const int x = (int)fdiv16((uint32_t)(t0 + e), a.magicR), r = t0 + e - x * a.R;
+                        lds[(r + a.R * jp) * PITCH + x] = t.v[e];
+                    }
+                }
+            }
+        } else
         for (int v = (int)tid; v < nvec; v += 256) {
             const int j = (int)fdiv16((uint32_t)v, a.magicXV), x = (v - j * XV) * VL;
             if (j < nj && x < nq) {
@@ -175,6 +192,33 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
         }
     } else {
         const int nvec = a.L * XV;
+        if (a.lshare) {
+            const int rowv = (a.R * TQ) / VL, nt = a.R * nq, njp = nj / a.R;
+            for (int v = (int)tid; v < rowv * njp; v += 256) {
+                const int jp = (int)fdiv16((uint32_t)v, a.magicRow), t0 = (v - jp * rowv) * VL;
+                if (t0 < nt) {
+                    FVec<T, VL> o;
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) {
+                        const int x = (int)fdiv16((uint32_t)(t0 + e), a.magicR), r = t0 + e - x * a.R;
+                        T arg[MAXIN];
+#pragma unroll
+                        for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
+                        T t = lds[(r + a.R * jp) * PITCH + x];
+                        if constexpr (tr<T>::cx) {
+                            if (cin) t = cj(t);
+                        }
+                        arg[0] = t;
+                        T rr = f(arg);
+                        if constexpr (tr<T>::cx) {
+                            if (cout) rr = cj(rr);
+                        }
+                        o.v[e] = rr;
+                    }
+                    *reinterpret_cast<FVec<T, VL>*>(dst + bl + (i64)jp * a.slp + t0) = o;
+                }
+            }
+        } else
         for (int v = (int)tid; v < nvec; v += 256) {
             const int j = (int)fdiv16((uint32_t)v, a.magicXV), x = (v - j * XV) * VL;
             if (j < nj && x < nq) {
@@ -266,6 +310,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.ntq = (unsigned)((a.dimq + TQ - 1) / TQ);
     a.conjv = (c.conj[0] || c.conj[1]) ? 1 : 0;
     a.fuse = fp.fuse ? 1 : 0;
+    a.lshare = fp.lshare ? 1 : 0;
     for (int r = 0; r < fp.R; ++r) a.roff[r] = fp.roff[r];
     i64 blocks = (i64)a.ntp * a.ntq;
     for (int d = 0; d < c.N; ++d) {
@@ -281,9 +326,16 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     // vector widths: 16 bytes where extents, strides and base addresses allow
     int vl = VMAX, vf = VMAX;
     auto aligned = [&](int k) { return (((uintptr_t)a.ops.base[k]) % 16) == 0; };
-    if (c.dims[fp.q] % VMAX || !aligned(kl)) vl = 1;
-    for (int d = 0; d < c.N; ++d)
-        if (d != fp.q && c.strides[kl][d] % VMAX) vl = 1;
+    if (fp.lshare) {
+        // line-side rows are runs of R * (valid columns) elements starting at multiples of R * TQ
+        if ((fp.R * c.dims[fp.q]) % VMAX || !aligned(kl)) vl = 1;
+        for (int d = 0; d < c.N; ++d)
+            if (d != fp.q && !fp.ingroup[d] && c.strides[kl][d] % VMAX) vl = 1;
+    } else {
+        if (c.dims[fp.q] % VMAX || !aligned(kl)) vl = 1;
+        for (int d = 0; d < c.N; ++d)
+            if (d != fp.q && c.strides[kl][d] % VMAX) vl = 1;
+    }
     if (fp.fuse) {
         // the run is R * (valid columns): whole vectors when R * extent(q) is a vector multiple (tile origins are q0 * R)
         if ((fp.R * c.dims[fp.q]) % VMAX || !aligned(kf)) vf = 1;
@@ -296,6 +348,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             if (!fp.ingroup[d] && d != fp.p && c.strides[kf][d] % VMAX) vf = 1;
     }
     a.magicR = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)fp.R + 1);
+    a.magicRow = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)((fp.R * TQ) / vl) + 1);
     a.magicXV = (TQ / vl) > 1 ? (uint32_t)(((uint64_t)1 << 32) / (uint32_t)(TQ / vl) + 1) : 0u;
     a.magicLv = (a.L / vf) > 1 ? (uint32_t)(((uint64_t)1 << 32) / (uint32_t)(a.L / vf) + 1) : 0u;  // unused in the fused form
     constexpr int PAD = (16 / (int)sizeof(T)) > 0 ? (16 / (int)sizeof(T)) : 1;

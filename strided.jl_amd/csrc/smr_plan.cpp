@@ -1048,12 +1048,19 @@ static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
     if (lead < 0) return false;
     const i64 e0 = c.dims[lead];
     if (e0 * es >= 128 || (e0 & (e0 - 1)) == 0) return false;  // long or power-of-two leading dims: the tiled family's ground
-    // unit axis of the line side: not the lead
+    // unit axis of the line side: not the lead ...
     int q = -1;
     for (int d = 0; d < c.N; ++d)
         if (d != lead && sl[d] == 1 && c.dims[d] * es >= 64) q = d;   // line-side runs of at least 64 bytes
+    // ... or the lead itself, continued by a dim of stride e0: a transposition of e0-element groups ((3,W,H) -> (3,H,W))
+    f.lshare = false;
+    if (q < 0 && sl[lead] == 1) {
+        for (int d = 0; d < c.N; ++d)
+            if (d != lead && sl[d] == e0 && sf[d] != e0 && c.dims[d] * e0 * es >= 64) q = d;
+        f.lshare = q >= 0;
+    }
     if (q < 0) return false;
-    if (sl[lead] == 1 || sl[lead] == -1) return false;
+    if (!f.lshare && (sl[lead] == 1 || sl[lead] == -1)) return false;
     for (int d = 0; d < MAXN; ++d) f.ingroup[d] = false;
     f.ingroup[lead] = true;
     i64 R = e0;
@@ -1064,7 +1071,7 @@ static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
         for (int d = 0; d < c.N; ++d)
             if (!f.ingroup[d] && d != q && sf[d] == R && c.dims[d] > 1) nxt = d;
         if (nxt < 0) break;
-        if (R * es < 192 && R * c.dims[nxt] <= FLAT_GROUP_MAX && R * c.dims[nxt] * es <= 512) {
+        if (!f.lshare && R * es < 192 && R * c.dims[nxt] <= FLAT_GROUP_MAX && R * c.dims[nxt] * es <= 512) {
             f.ingroup[nxt] = true;
             R *= c.dims[nxt];
             continue;
@@ -1078,7 +1085,8 @@ static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
         while ((R << tplog) * es < 256 && ((i64)1 << tplog) < c.dims[p] && (R << (tplog + 1)) <= 128) ++tplog;
     const i64 L = R << tplog;
     // planar <-> interleaved (NCHW <-> NHWC with 3 channels): the flat side continues along q ITSELF
-    f.fuse = p < 0 && sf[q] == R;
+    f.fuse = p < 0 && sf[q] == R && !f.lshare;
+    if (f.lshare && p < 0) return false;
     const int vmax = std::max(1, 16 / es);
     if (!f.fuse) {
         if (L * es < 96 || L > 128) return false;      // no run worth flattening
@@ -1350,7 +1358,7 @@ void describe(Plan& plan) {
     } else if (plan.family == FAM_FLAT) {
         const FlatPlan& fp = plan.flat;
         n += std::snprintf(buf + n, sizeof buf - n, " flat_side=%s run=%dx%d(d%d)%s line=d%d:%d", fp.dir == 0 ? "dest" : "input", fp.R, 1 << fp.tplog, fp.p,
-                           fp.fuse ? "+line" : "", fp.q, 1 << fp.tqlog);
+                           fp.fuse ? "+line" : (fp.lshare ? " shared-lead" : ""), fp.q, 1 << fp.tqlog);
     } else if (plan.family == FAM_STREAM) {
         n += std::snprintf(buf + n, sizeof buf - n, " vec=%d", plan.vec);
     } else if (plan.family == FAM_REDUCE_ALL) {

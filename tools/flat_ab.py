@@ -30,7 +30,7 @@ def time_plan(plan, reps):
 cases = [((640, 480, 3), (2, 1, 0)), ((640, 480, 3), (2, 0, 1)), ((3, 480, 640), (2, 1, 0)), ((3, 1000, 700), (2, 1, 0)), ((3, 1000, 700), (1, 2, 0)),
          ((100, 3, 100, 3, 10), (4, 3, 2, 1, 0)), ((100, 3, 100, 3, 10), (1, 0, 4, 3, 2)), ((100, 3, 100, 3, 10), (4, 1, 0, 2, 3)),
          ((1920, 1080, 3), (2, 0, 1)), ((3, 1920, 1080), (1, 2, 0)), ((5, 300, 300, 7), (3, 2, 1, 0)), ((12, 10, 14, 9, 11), (4, 3, 2, 1, 0)),
-         ((6, 2048, 2048), (2, 1, 0))]
+         ((6, 2048, 2048), (2, 1, 0)), ((3, 1000, 700), (0, 2, 1)), ((3, 1920, 1080), (0, 2, 1)), ((6, 100, 50, 40), (0, 3, 2, 1)), ((5, 1024, 1024), (0, 2, 1))]
 for dt in (torch.float64, torch.float32, torch.complex64):
     for shape, q in cases:
         N = 1
