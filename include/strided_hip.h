@@ -291,7 +291,10 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * "tiled_vec", "max_lds_bytes", "tile_order" (orbit-major tile order on/off),
  * "tiled_persist" / "tiled_persist_wpc" / "tiled_persist_min" (persistent pipelined form),
  * "reduce_blocks", "reduce_part_kind" (-1 auto, 0 general, 1 row, 2 col), "reduce_col_txlog",
- * "reduce_part_wgs", "jit" (runtime compilation of f on/off), "orbit" (ORBIT family on/off),
+ * "reduce_part_wgs" (partial reductions with fewer workgroups are split until about this many run), "reduce_col_narrow",
+ * "reduce_single" (split reductions of at most this many chunks fold their partials inside the same launch; 0 = always a
+ * second launch; a plan that owns partials must not run concurrently with itself on two streams),
+ * "jit" (runtime compilation of f on/off), "orbit" (ORBIT family on/off),
  * "orbit_lg" / "orbit_min" / "orbit_few" (orbit tile edge and thresholds), "orbit_pipe" (persistent
  * pipelined orbits: -1 auto, 0, 1), "nt_store" (non-temporal stores: -1 auto, 0 never, 1 always),
  * "nt_stream_min", "nt_load" (non-temporal loads of complete reductions: -1 auto, 0, 1), "flat" (FLAT family for short

@@ -121,8 +121,17 @@ static int plan_build(const smr_problem* p, smr_plan** out) {
 static int ensure_scratch(smr_plan* h) {
     std::lock_guard<std::mutex> g(*h->plan.build_mu);
     if (h->plan.scratch || h->plan.scratch_bytes == 0 || h->plan.red_blocks <= 1) return SMR_OK;
-    hipError_t e = hipMalloc(&h->plan.scratch, h->plan.scratch_bytes);
+    const size_t coff = (h->plan.scratch_bytes + 255) & ~(size_t)255;
+    void* buf = nullptr;
+    hipError_t e = hipMalloc(&buf, coff + RED_COUNTERS * sizeof(unsigned));
     if (e != hipSuccess) return hip_error(e, "hipMalloc(reduction partials)");
+    e = hipMemset((char*)buf + coff, 0, RED_COUNTERS * sizeof(unsigned));  // the kernels leave the counters at zero
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        return hip_error(e, "hipMemset(reduction counters)");
+    }
+    h->plan.counter_off = coff;
+    h->plan.scratch = buf;
     return SMR_OK;
 }
 
@@ -508,6 +517,8 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_part_kind") o.reduce_part_kind = value;
     else if (n == "reduce_col_txlog") o.reduce_col_txlog = value;
     else if (n == "reduce_part_wgs") o.reduce_part_wgs = value;
+    else if (n == "reduce_single") o.reduce_single = value;
+    else if (n == "reduce_col_narrow") o.reduce_col_narrow = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
@@ -560,6 +571,8 @@ int64_t smr_get_option(const char* name) {
     if (n == "reduce_part_kind") return o.reduce_part_kind;
     if (n == "reduce_col_txlog") return o.reduce_col_txlog;
     if (n == "reduce_part_wgs") return o.reduce_part_wgs;
+    if (n == "reduce_single") return o.reduce_single;
+    if (n == "reduce_col_narrow") return o.reduce_col_narrow;
     if (n == "jit_compiles") return jit_stats().compiles;
     if (n == "jit_hits") return jit_stats().hits;
     if (n == "jit_failures") return jit_stats().failures;

@@ -180,8 +180,9 @@ struct Plan {
     // STREAM
     int vec = 1;        // elements per vector access
     // reductions
-    void* scratch = nullptr;  // partials (owned)
+    void* scratch = nullptr;  // partials (owned), followed by RED_COUNTERS arrival counters (zero between launches)
     size_t scratch_bytes = 0;
+    size_t counter_off = 0;   // byte offset of the counters inside `scratch` (set when it is allocated)
     int red_blocks = 0;
     int part_tr = 1;    // REDUCE_PART: lanes cooperating on one output
     int part_split = 1; // REDUCE_PART: chunks of the reduced range (two-pass when > 1)
@@ -203,6 +204,7 @@ struct Plan {
 };
 
 // Options (smr_set_option)
+constexpr int RED_COUNTERS = 16384;  // arrival counters per reduction plan (one per output group of a split reduction)
 struct Options {
     i64 force_family = 0;
     i64 tile_log2 = 0;       // 0 = planner default
@@ -213,8 +215,13 @@ struct Options {
     i64 tile_block_xcd = -1; // block-ordered list in one contiguous run per XCD: 0 never, 1 always, -1 = while the operands fit the Infinity Cache
     i64 jit = 1;             // compile unrecognised f-programs with hiprtc (0 = always interpret)
     i64 reduce_col_txlog = 5;   // COL form: log2 of the lanes along kept dim 0 (cap)
-    i64 reduce_part_wgs = 4096; // partial reductions with few outputs are split until about this many workgroups run
+    i64 reduce_part_wgs = 1024; // partial reductions with fewer workgroups than this are split until about this many run (4096 until
+                                // round 3: 512-1024 is as fast or faster on every shape of tools/reduce_sweep.py, with 4x fewer partials)
+    i64 reduce_col_narrow = 1;  // COL form: narrow the row segments when that yields reduce_part_wgs workgroups without a split
     i64 reduce_part_kind = -1;  // -1 = planner's choice; 0/1/2 force general / ROW / COL when applicable
+    i64 reduce_single = 4;     // split reductions of at most this many chunks fold their partials inside the SAME launch (the workgroup
+                               // arriving last at its group's counter does it); 0 = always a second launch.  Measured: 2-4 chunks
+                               // -1.0..-1.7 us, 8 and more +0.3..+100 us (one counter serialises its arrivals at ~12 ns each)
     i64 reduce_blocks = 2048;  // cap on the workgroups (= partials) of a complete reduction
     i64 tiled_persist = 1;      // persistent + software-pipelined tiled kernel for grids larger than the machine
     i64 tiled_persist_wpc = 0;  // workgroups per CU of that form (0 = derived from threads / LDS)

@@ -6,8 +6,12 @@
 //     dest = op(initop(dest_old), partial)     in the epilogue,
 // where `partial` is a deterministic tree reduction (per-lane accumulators -> wave64
 // __shfl_xor butterflies -> LDS across the workgroup's waves -> one partial per workgroup ->
-// a single-workgroup second pass).  No float atomics, so results are run-to-run identical;
+// a fold of the partials).  No float atomics, so results are run-to-run identical;
 // this mirrors the reference's per-task partial slots + serial fold (:153-170).
+// The fold of a split reduction runs inside the SAME launch (Options::reduce_single): every workgroup publishes
+// its partials, bumps the arrival counter of its output group, and the workgroup that arrives last folds the group's
+// partials in slot order -- which workgroup that is varies from run to run, what it computes does not.  (The second
+// launch this replaces cost more than the 19-48 MiB reductions it served: a kernel boundary is 1.2-2 us.)
 //   REDUCE_ALL : complete reduction (destination is one element)
 //   REDUCE_PART: some dims kept; TR lanes cooperate per destination element
 #include "smr_dispatch.h"
@@ -34,6 +38,8 @@ struct RedArgs {
     int32_t g0log, g1log, txlog, xsplit, qsplit, ntl;  // ntl: non-temporal loads in REDUCE_ALL (Options::nt_load)
     i64 L0, Q, xchunk, qchunk;
     i64 nkb0;         // COL: workgroups along kept dim 0
+    unsigned* counters;  // one-launch split reductions: arrival counter per output group (zero between launches)
+    int32_t single;      // 1: the last workgroup to arrive folds the partials; 0: a second launch does
 };
 
 template <class T>
@@ -84,11 +90,83 @@ SMR_DEV void decompose(const RedArgs& a, i64 i, int d0, int d1, i64* off) {
     }
 }
 
+// One-launch split reductions.  The L2s of the eight XCDs are not coherent with each other and a CU's L1 is never
+// refreshed by another CU's stores, so partials that are folded inside the launch travel write-through: agent-scope
+// relaxed atomic stores (global_store ... sc1, at most 8 bytes each) and agent-scope loads in the folding workgroup, ordered
+// by "every wave waits for its stores' acknowledgements -> barrier -> one relaxed agent-scope ticket".  No release /
+// acquire fences: buffer_wbl2 / buffer_inv cost 1.7 us each on this part, as much as the launch they would save.
+template <class T>
+SMR_DEV void put_partial(const RedArgs& a, i64 idx, T v) {
+    T* p = (T*)a.partials + idx;
+    if (!a.single) {
+        *p = v;
+        return;
+    }
+    if constexpr (sizeof(T) == 4) {
+        unsigned u;
+        __builtin_memcpy(&u, &v, 4);
+        __hip_atomic_store((unsigned*)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        unsigned long long u[sizeof(T) / 8];
+        __builtin_memcpy(u, &v, sizeof(T));
+#pragma unroll
+        for (unsigned j = 0; j < sizeof(T) / 8; ++j) __hip_atomic_store((unsigned long long*)p + j, u[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <class T>
+SMR_DEV T get_partial(const RedArgs& a, i64 idx) {
+    const T* p = (const T*)a.partials + idx;
+    if (!a.single) return *p;
+    T v;
+    if constexpr (sizeof(T) == 4) {
+        const unsigned u = __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_memcpy(&v, &u, 4);
+    } else {
+        unsigned long long u[sizeof(T) / 8];
+#pragma unroll
+        for (unsigned j = 0; j < sizeof(T) / 8; ++j) u[j] = __hip_atomic_load((const unsigned long long*)p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_memcpy(&v, u, sizeof(T));
+    }
+    return v;
+}
+// Called by every thread of a workgroup after its partials were stored; true in the workgroup that arrived last of the
+// `nparts` sharing counter `group` (it may then read all their partials).  The last one also zeroes the counter for the
+// next launch of this plan.
+SMR_DEV bool arrive_last(const RedArgs& a, i64 group, int nparts) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.counters + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == (unsigned)(nparts - 1);
+        if (last) __hip_atomic_store(a.counters + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 // ---- complete reduction -------------------------------------------------------------------------
 template <class T, int V>
 struct alignas(sizeof(T) * V) RVec {
     T v[V];
 };
+
+// fold of the per-workgroup partials of a complete reduction (one workgroup, slot order fixed by the thread layout)
+template <class T, bool MIXED>
+SMR_DEV void fold_all(const RedArgs& a, int redop, T* wsum) {
+    T v = neutral<T>(redop);
+    for (int i = threadIdx.x; i < a.nparts; i += 256) v = red_apply<T>(redop, v, get_partial<T>(a, i));
+    v = wave_reduce(v, redop, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = red_apply<T>(redop, red_apply<T>(redop, wsum[0], wsum[1]), red_apply<T>(redop, wsum[2], wsum[3]));
+        epilogue<T, MIXED>(a, 0, v);
+    }
+}
 
 template <class T, class F, bool MIXED, int V, int OPC>
 SMR_DEV void reduce_all_impl(const RedArgs& a, F f) {
@@ -204,7 +282,11 @@ SMR_DEV void reduce_all_impl(const RedArgs& a, F f) {
         if (gridDim.x == 1)
             epilogue<T, MIXED>(a, 0, v);
         else
-            ((T*)a.partials)[blockIdx.x] = v;
+            put_partial<T>(a, blockIdx.x, v);
+    }
+    if (gridDim.x > 1 && a.single) {
+        if (!arrive_last(a, 0, (int)gridDim.x)) return;
+        fold_all<T, MIXED>(a, redop, wsum);
     }
 }
 template <class T, class F, bool MIXED, int V>
@@ -218,15 +300,43 @@ SMR_DEV void reduce_all_body(const RedArgs a, F f) {
 template <class T, bool MIXED>
 __global__ void __launch_bounds__(256) k_reduce_final(RedArgs a) {
     __shared__ T wsum[4];
-    T v = neutral<T>(a.redop);
-    for (int i = threadIdx.x; i < a.nparts; i += 256) v = red_apply<T>(a.redop, v, ((const T*)a.partials)[i]);
-    v = wave_reduce(v, a.redop, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) wsum[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        v = red_apply<T>(a.redop, red_apply<T>(a.redop, wsum[0], wsum[1]), red_apply<T>(a.redop, wsum[2], wsum[3]));
-        epilogue<T, MIXED>(a, 0, v);
+    fold_all<T, MIXED>(a, a.redop, wsum);
+}
+
+// fold of the nsplit partials of outputs [obase, obase + ocount) by one workgroup: 2^lpolog consecutive lanes per output
+// walk its partials (slot order fixed by the lane layout), wave butterfly, epilogue.  Used by the workgroup that arrived
+// last (one-launch form) and, one output group per workgroup, by nothing else: the two-launch form has its own kernel.
+template <class T, bool MIXED>
+SMR_DEV void fold_part(const RedArgs& a, int redop, i64 obase, int ocount) {
+    int lpolog = 0;
+    while (lpolog < 6 && (ocount << (lpolog + 1)) <= 256 && (2 << lpolog) <= a.nsplit) ++lpolog;
+    const int lpo = 1 << lpolog;
+    const int l = threadIdx.x & (lpo - 1);
+    const int per = 256 >> lpolog;
+    for (int o0 = 0; o0 < ocount; o0 += per) {  // uniform trip count: the butterfly below needs whole lane groups
+        const int oo = o0 + (threadIdx.x >> lpolog);
+        const bool live = oo < ocount;
+        const i64 o = obase + oo;
+        T acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = neutral<T>(redop);
+        if (live) {
+            const i64 p = o * a.nsplit;
+            for (int i = l; i < a.nsplit; i += 4 * lpo) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j * lpo < a.nsplit) acc[j] = red_apply<T>(redop, acc[j], get_partial<T>(a, p + i + j * lpo));
+            }
+        }
+        T v = red_apply<T>(redop, red_apply<T>(redop, acc[0], acc[1]), red_apply<T>(redop, acc[2], acc[3]));
+        v = wave_reduce(v, redop, lpo);
+        if (live && l == 0) {
+            i64 ooff[MAXM];
+#pragma unroll
+            for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
+            decompose(a, o, 0, a.NK, ooff);
+            epilogue<T, MIXED>(a, ooff[0], v);
+        }
     }
 }
 
@@ -284,7 +394,12 @@ SMR_DEV void reduce_part_impl(const RedArgs& a, F f) {
         if (a.nsplit == 1)
             epilogue<T, MIXED>(a, ooff[0], acc);
         else
-            ((T*)a.partials)[o * a.nsplit + sp] = acc;
+            put_partial<T>(a, o * a.nsplit + sp, acc);
+    }
+    if (a.nsplit > 1 && a.single) {
+        if (!arrive_last(a, og, a.nsplit)) return;
+        const i64 left = a.nout - og * ob;
+        fold_part<T, MIXED>(a, redop, og * ob, (int)(left < ob ? left : ob));
     }
 }
 template <class T, class F, bool MIXED>
@@ -427,7 +542,12 @@ SMR_DEV void reduce_row_impl(const RedArgs& a, F f) {
         if (a.nsplit == 1)
             epilogue<T, MIXED>(a, ooff[0], v);
         else
-            ((T*)a.partials)[o * a.nsplit + sp] = v;
+            put_partial<T>(a, o * a.nsplit + sp, v);
+    }
+    if (a.nsplit > 1 && a.single) {
+        if (!arrive_last(a, og, a.nsplit)) return;
+        const i64 ob = 256 >> glog, left = a.nout - og * ob;
+        fold_part<T, MIXED>(a, redop, og * ob, (int)(left < ob ? left : ob));
     }
 }
 template <class T, class F, bool MIXED, int V>
@@ -573,9 +693,14 @@ SMR_DEV void reduce_col_impl(const RedArgs& a, F f) {
                 epilogue<T, MIXED>(a, ooff[0] + e * a.strides[0][0], acc[e]);
             } else {
                 const i64 o = i0 + e + krest * a.dims[0];
-                ((T*)a.partials)[o * a.nsplit + sp] = acc[e];
+                put_partial<T>(a, o * a.nsplit + sp, acc[e]);
             }
         }
+    }
+    if (a.nsplit > 1 && a.single) {
+        if (!arrive_last(a, kb, a.nsplit)) return;
+        const i64 per = (i64)TX * V, ibeg = c0 * per, left = a.dims[0] - ibeg;
+        fold_part<T, MIXED>(a, redop, krest * a.dims[0] + ibeg, (int)(left < per ? left : per));
     }
 }
 template <class T, class F, bool MIXED, int V>
@@ -676,6 +801,8 @@ static void fill_args(const Plan& plan, void* const* bases, RedArgs& a) {
     for (int k = 0; k < MAXM; ++k)
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
     a.partials = plan.scratch;
+    a.counters = plan.scratch ? (unsigned*)((char*)plan.scratch + plan.counter_off) : nullptr;
+    a.single = 0;  // set by go_all / go_part when the number of partials per output is at most Options::reduce_single
     // non-temporal loads: 64 MiB 18.5 -> 16.5 us, 512 MiB 96 -> 92 us, 4 GiB 700 +- 15 us either way (tools/reduce_nt.py)
     a.ntl = (options().nt_load > 0 || (options().nt_load < 0 && (long double)c.total * c.esize[1] < 2147483648.0L)) ? 1 : 0;
 }
@@ -689,6 +816,7 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     int blocks = plan.red_blocks;
     if (blocks > 1 && !plan.scratch) blocks = 1;
     a.nparts = blocks;
+    a.single = (blocks > 1 && blocks <= options().reduce_single) ? 1 : 0;
     // vector path: one fused dim, every input unit stride / broadcast, 16-B aligned
     constexpr int VMAX = (sizeof(T) >= 16) ? 1 : (int)(16 / sizeof(T));
     bool vec = !MIXED && VMAX > 1 && c.N == 1 && (c.total % VMAX == 0) && c.total >= 4096;
@@ -707,7 +835,7 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     }
     if (!done) rc = launch_all<T, F, MIXED, 1>(c, a, blocks, s, f);
     if (rc) return rc;
-    if (blocks > 1 && !jit_no_launch()) {
+    if (blocks > 1 && !a.single && !jit_no_launch()) {
         clear_sticky_error();
     hipLaunchKernelGGL((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
         rc = check_launch("k_reduce_final");
@@ -749,6 +877,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     const bool have_scratch = plan.scratch != nullptr;
     int nsplit = (plan.part_split > 1 && have_scratch) ? plan.part_split : 1;
     a.nsplit = nsplit;
+    a.single = (nsplit > 1 && nsplit <= options().reduce_single) ? 1 : 0;
     a.xsplit = a.qsplit = 1;
     i64 blocks = 0;
     int rc;
@@ -760,6 +889,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         const int ob = 256 / a.tr;
         const i64 groups = (c.nout + ob - 1) / ob;
         a.ngroups = (int32_t)groups;
+        if (groups > RED_COUNTERS) a.single = 0;
         a.chunk = ((a.nred + nsplit - 1) / nsplit + a.tr - 1) / a.tr * a.tr;
         blocks = groups * nsplit;
         if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
@@ -790,6 +920,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             a.xchunk = ((a.L0 + a.xsplit - 1) / a.xsplit + unit - 1) / unit * unit;
             const i64 groups = (c.nout + (256 >> (a.g0log + a.g1log)) - 1) / (256 >> (a.g0log + a.g1log));
             a.ngroups = (int32_t)groups;
+        if (groups > RED_COUNTERS) a.single = 0;
             blocks = groups * nsplit;
             if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
             rc = SMR_OK;
@@ -807,6 +938,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             a.nkb0 = (c.dims[0] + per - 1) / per;
             const i64 groups = a.nkb0 * (c.nout / c.dims[0]);
             a.ngroups = (int32_t)groups;
+        if (groups > RED_COUNTERS) a.single = 0;
             blocks = groups * nsplit;
             if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
             rc = SMR_OK;
@@ -820,7 +952,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             if (!done) rc = launch_part<T, F, MIXED, 2, 1>(c, a, blocks, s, f);
         }
     }
-    if (rc || nsplit == 1 || jit_no_launch()) return rc;
+    if (rc || nsplit == 1 || a.single || jit_no_launch()) return rc;
     // lanes per output of the folding pass: as many as there are partials (up to a wave), fewer
     // when there are plenty of outputs anyway
     int lpolog = 0;

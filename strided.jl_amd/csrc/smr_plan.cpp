@@ -1265,6 +1265,19 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 // rows of the reduced space per workgroup: fewer when the reduction is short (sum over a trailing dim of 7:
                 // every lane then walks its 7 rows itself instead of 8 lanes sharing them through LDS)
                 txlog = std::min<int>(txlog, std::max<int>((int)o.reduce_col_txlog, 8 - p2ceil(std::max<i64>(1, red / 8))));
+                // too few workgroups along the kept dims: narrower row segments (down to 128 bytes) give 2-4x as many and more
+                // rows to each -- when that makes the split unnecessary it saves the partials and the second launch
+                // (sum(A; dims=2) of 512x384x64 f32: 16.0 -> 12.4 us, 256^3: 18.4 -> 14.7 us, tools/reduce_sweep.py)
+                auto kb_at = [&](int t) { return ((K0 + (((i64)vmax) << t) - 1) / (((i64)vmax) << t)) * (c.nout / K0); };
+                if (o.reduce_col_narrow && kb_at(txlog) < o.reduce_part_wgs) {
+                    for (int t = txlog - 1; t >= 3 && (((i64)vmax << t) * es >= 128); --t) {
+                        if ((red >> (8 - t)) < 8) break;  // fewer than 8 rows of the reduced space per lane row
+                        if (kb_at(t) >= o.reduce_part_wgs) {
+                            txlog = t;
+                            break;
+                        }
+                    }
+                }
                 plan.part_txlog = txlog;
                 const int tylog = 8 - txlog;
                 plan.part_g0log = std::min(tylog, p2ceil(L0));
@@ -1272,7 +1285,9 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 const i64 kb = ((K0 + (((i64)vmax) << txlog) - 1) / (((i64)vmax) << txlog)) * (c.nout / K0);
                 i64 split = 1;
                 const i64 rows_per_wg = (i64)1 << tylog;
-                if (kb < 2048 && red >= rows_per_wg * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / kb, red / (rows_per_wg * 8)));
+                // half the ROW form's target: every workgroup leaves TX*V partials per chunk, and the sweep has 512 ahead of 1024-4096
+                const i64 target = std::max<i64>(1, o.reduce_part_wgs / 2);
+                if (kb < target && red >= rows_per_wg * 16) split = std::max<i64>(1, std::min<i64>(target / kb, red / (rows_per_wg * 8)));
                 split = std::min<i64>(split, 4096);
                 // cut the outer reduced index first, the inner reduced dim with what is left (a short Q -- a trailing
                 // dim of 7 -- used to forbid any cut but 2 along L0: 160 workgroups for 19 MiB)
@@ -1289,7 +1304,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 plan.part_g1log = glog - plan.part_g0log;
                 const i64 groups = (c.nout + (256 >> glog) - 1) / (256 >> glog);
                 i64 split = 1;
-                if (groups < 2048 && red >= ((i64)vmax << glog) * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / groups, red / (((i64)vmax << glog) * 8)));
+                if (groups < o.reduce_part_wgs && red >= ((i64)vmax << glog) * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / groups, red / (((i64)vmax << glog) * 8)));
                 split = std::min<i64>(split, 4096);
                 plan.part_qsplit = (int)std::max<i64>(1, std::min<i64>(split, Q >> plan.part_g1log));
                 plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split / plan.part_qsplit, L0 / (((i64)vmax * 4) << plan.part_g0log)));

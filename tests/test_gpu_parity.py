@@ -361,6 +361,97 @@ def test_every_kernel_family_is_exercised():
     o = x.similar(size=(32, 1, 32, 1))
     d = S.make_plan(S.fn.sin, "+", None, x.size, S.promoteshape(x.size, o, x)).describe()
     assert "family=reduce_part" in d
+    # round 3: ORBIT (permuted views of one buffer) and FLAT (short leading dims that are not powers of two)
+    ps = [x.permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]
+    assert "family=orbit" in S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps)).describe()
+    img = dview(np.zeros((640, 480, 3)))
+    out = dview(np.zeros((3, 480, 640)))
+    assert "family=flat" in S.make_plan(lambda v: v, None, None, out.size, (out, img.permutedims((2, 1, 0)))).describe()
+
+
+@pytest.mark.parametrize("T", [np.float32, np.float64, np.complex64, np.int32, np.int64])
+def test_flat_family_image_layouts_are_bit_exact(T):
+    """Round 3: planar <-> interleaved channels and the transposition of 3-element groups (FLAT family, all three forms),
+    scaled copies included; integer types move as bit copies / in the integer class."""
+    import torch
+    rng = np.random.default_rng(11)
+    H, W, Cn = 160, 202, 3
+    if np.issubdtype(np.dtype(T), np.integer):
+        a = rng.integers(-1000, 1000, size=(W, H, Cn)).astype(T)
+    elif np.issubdtype(np.dtype(T), np.complexfloating):
+        a = (rng.standard_normal((W, H, Cn)) + 1j * rng.standard_normal((W, H, Cn))).astype(T)
+    else:
+        a = rng.standard_normal((W, H, Cn)).astype(T)
+    A = dview(a)
+    seen = set()
+    for q in ((2, 1, 0), (2, 0, 1), (1, 0, 2)):          # (3,H,W), (3,W,H), (H,W,3)
+        B = dview(np.zeros(tuple(a.shape[i] for i in q), dtype=T))
+        plan = S.make_plan(lambda v: v, None, None, B.size, (B, A.permutedims(q)))
+        seen.add(plan.describe().split()[0])
+        S.permutedims_(B, A, q)
+        torch.cuda.synchronize()
+        assert np.array_equal(B.toarray(), a.transpose(q)), (q, plan.describe())
+        # and back, with a scale
+        C2 = dview(np.zeros(a.shape, dtype=T))
+        inv = tuple(int(i) for i in np.argsort(q))
+        S.map_(lambda v: v * 3, C2, B.permutedims(inv))
+        torch.cuda.synchronize()
+        assert np.array_equal(C2.toarray(), a * T(3)), (q, "back")
+    b = np.asfortranarray(a.transpose(2, 0, 1))          # (3, W, H): transposition of 3-element groups
+    Bv = dview(b)
+    D = dview(np.zeros((Cn, H, W), dtype=T))
+    d = S.make_plan(lambda v: v, None, None, D.size, (D, Bv.permutedims((0, 2, 1)))).describe()
+    S.permutedims_(D, Bv, (0, 2, 1))
+    torch.cuda.synchronize()
+    assert np.array_equal(D.toarray(), b.transpose(0, 2, 1)), d
+    assert "family=flat" in seen and "shared-lead" in d
+
+
+@pytest.mark.parametrize("T", [np.float64, np.float32, np.complex128, np.int64])
+def test_one_launch_split_reductions_never_fold_stale_partials(T):
+    """Round 3: a split reduction folds its partials inside the launch (the workgroup that arrives last at the group's
+    counter reads what the others published write-through).  The per-XCD L2s are not coherent and a CU's L1 is never
+    refreshed by other CUs' stores, so a broken hand-off shows as partials of the PREVIOUS launch: the input changes
+    every launch here, the expected sums are exact, other kernels run on a second stream to make the load uneven, and
+    the counters must be back at zero for the next launch (several hundred back-to-back launches of ONE plan)."""
+    import torch
+    lib = S._lib.load()
+    keep = lib.smr_get_option(b"reduce_single")
+    S._lib.check(lib.smr_set_option(b"reduce_single", 1 << 20))   # the one-launch form whatever the number of chunks
+    try:
+        _stale_partials_body(T, torch)
+    finally:
+        S._lib.check(lib.smr_set_option(b"reduce_single", keep))
+
+
+def _stale_partials_body(T, torch):
+    dims = (96, 50, 40, 7)
+    a = np.ones(dims, dtype=T)
+    A = dview(a)
+    outs = []
+    for rd in ((1, 2, 3), (0, 1, 2), (0, 1, 2, 3), (2, 3)):
+        odims = tuple(1 if d in rd else n for d, n in enumerate(dims))
+        out = A.similar(size=odims)
+        plan = S.make_plan(lambda x: x, "+", "zero", dims, S.promoteshape(dims, out, A))
+        d = plan.describe()
+        assert "reduce" in d
+        outs.append((rd, odims, out, plan, d))
+    assert any("split=" in d and "split=1 " not in d for (_, _, _, _, d) in outs if "reduce_part" in d)
+    big = torch.randn(1 << 24, device="cuda")
+    side = torch.cuda.Stream()
+    cur = lambda: int(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+    for it in range(1, 121):
+        A.parent.fill_(it)
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                big.mul_(1.0001)
+        for (rd, odims, out, plan, d) in outs:
+            plan.execute(cur())
+        torch.cuda.synchronize()
+        for (rd, odims, out, plan, d) in outs:
+            cnt = int(np.prod([dims[i] for i in rd]))
+            got = out.toarray()
+            assert np.all(got == T(it * cnt)), (it, rd, d, got.ravel()[:4], it * cnt)
 
 
 def test_plain_array_rule_upload_on_the_device():
