@@ -1252,6 +1252,15 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 while (((i64)1 << l) < v) ++l;
                 return l;
             };
+            // number of chunks an index range of `n` is cut into when about `want` are asked for: all of n when that is
+            // within 2x (a trailing dim of 7 cut 6 ways would leave chunks of 2,2,2,1 and two idle workgroups), else a
+            // count that leaves no chunk empty
+            auto even_cut = [](i64 want, i64 n) -> i64 {
+                if (n <= 1 || want <= 1) return 1;
+                if (n <= 2 * want) return n;
+                const i64 per = (n + want - 1) / want;
+                return (n + per - 1) / per;
+            };
             if (o.reduce_part_kind >= 0) {  // tuning / testing override
                 row = row && o.reduce_part_kind == 1;
                 col = col && o.reduce_part_kind == 2;
@@ -1291,7 +1300,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 split = std::min<i64>(split, 4096);
                 // cut the outer reduced index first, the inner reduced dim with what is left (a short Q -- a trailing
                 // dim of 7 -- used to forbid any cut but 2 along L0: 160 workgroups for 19 MiB)
-                plan.part_qsplit = (int)std::max<i64>(1, std::min<i64>(split, Q >> plan.part_g1log));
+                plan.part_qsplit = (int)even_cut(split, Q >> plan.part_g1log);
                 plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split / plan.part_qsplit, L0 / ((i64)4 << plan.part_g0log)));
                 plan.part_split = plan.part_xsplit * plan.part_qsplit;
                 plan.part_tr = 1 << tylog;
@@ -1306,7 +1315,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 i64 split = 1;
                 if (groups < o.reduce_part_wgs && red >= ((i64)vmax << glog) * 16) split = std::max<i64>(1, std::min<i64>(o.reduce_part_wgs / groups, red / (((i64)vmax << glog) * 8)));
                 split = std::min<i64>(split, 4096);
-                plan.part_qsplit = (int)std::max<i64>(1, std::min<i64>(split, Q >> plan.part_g1log));
+                plan.part_qsplit = (int)even_cut(split, Q >> plan.part_g1log);
                 plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split / plan.part_qsplit, L0 / (((i64)vmax * 4) << plan.part_g0log)));
                 plan.part_split = plan.part_xsplit * plan.part_qsplit;
                 plan.part_tr = 1 << glog;
