@@ -519,6 +519,8 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_part_wgs") o.reduce_part_wgs = value;
     else if (n == "reduce_single") o.reduce_single = value;
     else if (n == "reduce_col_narrow") o.reduce_col_narrow = value;
+    else if (n == "reduce_row_floor") o.reduce_row_floor = value;
+    else if (n == "reduce_row_dense") o.reduce_row_dense = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
@@ -573,6 +575,8 @@ int64_t smr_get_option(const char* name) {
     if (n == "reduce_part_wgs") return o.reduce_part_wgs;
     if (n == "reduce_single") return o.reduce_single;
     if (n == "reduce_col_narrow") return o.reduce_col_narrow;
+    if (n == "reduce_row_floor") return o.reduce_row_floor;
+    if (n == "reduce_row_dense") return o.reduce_row_dense;
     if (n == "jit_compiles") return jit_stats().compiles;
     if (n == "jit_hits") return jit_stats().hits;
     if (n == "jit_failures") return jit_stats().failures;

@@ -217,6 +217,8 @@ struct Options {
     i64 reduce_col_txlog = 5;   // COL form: log2 of the lanes along kept dim 0 (cap)
     i64 reduce_part_wgs = 1024; // partial reductions with fewer workgroups than this are split until about this many run (4096 until
                                 // round 3: 512-1024 is as fast or faster on every shape of tools/reduce_sweep.py, with 4x fewer partials)
+    i64 reduce_row_floor = -1;  // ROW form: least log2 lanes per output (-1 = planner's rule)
+    i64 reduce_row_dense = 1;   // ROW form: lanes along the outputs when the inner reduced dim is at most 64 bytes and kept dim 0 is dense behind it
     i64 reduce_col_narrow = 1;  // COL form: narrow the row segments when that yields reduce_part_wgs workgroups without a split
     i64 reduce_part_kind = -1;  // -1 = planner's choice; 0/1/2 force general / ROW / COL when applicable
     i64 reduce_single = 4;     // split reductions of at most this many chunks fold their partials inside the SAME launch (the workgroup

@@ -64,8 +64,14 @@ SMR_DEV T wave_reduce(T v, int op, int width) {
 template <class T, bool MIXED>
 SMR_DEV void epilogue(const RedArgs& a, i64 off0, T acc) {
     typedef typename tr<T>::real R;
-    T old = load_op<T, MIXED>(a.ops, 0, off0);
-    if (a.initop != SMR_INIT_NONE) old = init_apply<T>(a.initop, old, mk<T>(rcast<R>(a.beta[0]), rcast<R>(a.beta[1])));
+    const T beta = mk<T>(rcast<R>(a.beta[0]), rcast<R>(a.beta[1]));
+    T old;
+    if (a.initop == SMR_INIT_ZERO || a.initop == SMR_INIT_CONST) {
+        old = init_apply<T>(a.initop, T{}, beta);  // does not depend on what the destination held: no load
+    } else {
+        old = load_op<T, MIXED>(a.ops, 0, off0);
+        if (a.initop != SMR_INIT_NONE) old = init_apply<T>(a.initop, old, beta);
+    }
     store_op<T, MIXED>(a.ops, off0, red_apply<T>(a.redop, old, acc));
 }
 

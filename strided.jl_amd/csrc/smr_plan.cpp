@@ -1308,7 +1308,21 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 // ROW: G consecutive lanes per output, vector loads along the inner reduced dim
                 plan.part_kind = 1;
                 int glog = 8;
-                while (glog > 4 && red < ((i64)vmax << glog) * 4) --glog;
+                // (no floor on the lanes per output -- rounds 1-3 had 16: sum(A; dims=1) of a 3 x N array then ran on 1 lane in 16
+                // and took 200 us for 33 MB (now 15.4), of 100 x 50400 f32 7.6 us (now 4.75 with 4 lanes of 6 vectors each), of
+                // 32 x 200000 21.5 (now 5.6); tools/reduce_sweep.py, profiles/r03_reduce_sweep.txt)
+                const int gfloor = o.reduce_row_floor >= 0 ? (int)o.reduce_row_floor : 0;
+                while (glog > gfloor && red < ((i64)vmax << glog) * 4) --glog;
+                // a very short inner dim with kept dim 0 right behind it in memory (sum over the channels AND the rows of a
+                // 3 x W x H image): lanes along the outputs read neighbouring segments; lanes along the outer reduced index -- what
+                // the rule above picks when the whole reduction is long -- would each fetch 12 bytes from a line of their own
+                bool dense0 = o.reduce_row_dense && c.NK >= 1 && Q > 1 && c.dims[0] >= 256 && L0 * es <= 64;
+                for (int k = 1; k < c.M && dense0; ++k)
+                    if (c.strides[k][c.NK] == 1 && c.strides[k][0] != L0) dense0 = false;
+                if (dense0) {
+                    glog = 8;
+                    while (glog > 0 && L0 < ((i64)vmax << glog) * 4) --glog;
+                }
                 plan.part_g0log = std::min(glog, p2ceil((L0 + vmax - 1) / vmax));
                 plan.part_g1log = glog - plan.part_g0log;
                 const i64 groups = (c.nout + (256 >> glog) - 1) / (256 >> glog);

@@ -444,6 +444,21 @@ def test_planner_rules_for_short_dims_big_transposes_and_short_reductions():
     assert "form=col lanes_per_out=1 " in red((100, 90, 80, 7), (3,))           # 7 rows per output: one lane walks them
     assert "form=col lanes_per_out=8 " in red((512, 384, 64), (2,))             # 64 rows: shared through LDS as before
     assert "split=7 " in red((100, 90, 80, 7), (1, 3)) + " "                      # outer (7) x inner (1) cuts together
+    # round 3 (tools/reduce_sweep.py): no floor of 16 lanes per output in the ROW form ...
+    assert "form=row lanes_per_out=1 split=1" in red((3, 1920, 1080), (0,))      # sum over 3 channels: one lane per pixel (200 -> 15 us)
+    assert "form=row lanes_per_out=4 split=1" in red((100, 90, 80, 7), (0,))     # 100 floats: 4 lanes x 6 vectors (7.6 -> 4.75 us)
+    assert "form=row lanes_per_out=2 split=1" in red((32, 200000), (0,))
+    # ... narrower COL row segments when that fills the device without a split ...
+    assert "form=col lanes_per_out=32 split=1" in red((512, 384, 64), (1,))      # 16.0 -> 12.4 us
+    assert "form=col lanes_per_out=16 split=1" in red((256, 256, 256), (1,))     # 18.4 -> 14.2 us
+    # ... and splits aim at 1024 (ROW) / 512 (COL) workgroups instead of 4096
+    assert "form=col lanes_per_out=8 split=512" in red((100, 90, 80, 7), (1, 2, 3))
+    assert "form=row lanes_per_out=256 split=2 " in red((512, 384, 64), (0, 2)) + " "
+    # at most `reduce_single` chunks: folded inside the launch; the option round-trips and 0 restores the two-launch form
+    assert S.get_option("reduce_single") == 4
+    S.set_option("reduce_single", 0)
+    assert S.get_option("reduce_single") == 0
+    S.set_option("reduce_single", 4)
 
 
 def test_plans_of_the_baseline_configs():

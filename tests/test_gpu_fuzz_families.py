@@ -130,6 +130,10 @@ def recipe(name, seed, T):
         dims = pick([(500, 300, 7), (1 << 20,), (128, 128, 64), (90, 41, 33, 4)])
         reduce_dims = tuple(range(len(dims)))
         mkview = lambda rng, mk, data, k: _perm_view(rng, mk, data, dims) if coin[k] % 2 else mk(data(dims))  # noqa: E731
+    elif name == "reduce_short":   # short inner reduced dim (round 3: ROW form with 1-8 lanes per output instead of at least 16)
+        dims = pick([(100, 600, 9), (3, 3000, 40), (7, 50000), (12, 50, 60, 10), (25, 2000, 3), (6, 1000, 2, 30)])
+        reduce_dims = pick([(0,), (0,), (0, len(dims) - 1)] + ([(0, 2)] if len(dims) > 3 else []))
+        mkview = lambda rng, mk, data, k: mk(data(dims))  # noqa: E731
     else:  # reduce_part
         dims = pick([(2048, 600), (600, 2048), (64, 300, 50), (40, 3, 5000), (300, 40, 40, 4)])
         k = int(rng0.integers(1, len(dims)))
@@ -196,7 +200,7 @@ def _initop_fn(i):
 
 
 RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_short0", "tiled_big", "orbit", "orbit_pipe", "aliased_classic", "generic",
-           "reduce_all", "reduce_part", "tiled_blocks", "flat"]
+           "reduce_all", "reduce_part", "tiled_blocks", "flat", "reduce_short"]
 
 SEED_OFFSET = int(os.environ.get("SMR_FUZZ_SEED_OFFSET", "0"))  # other seeds for longer campaigns on a GPU box
 
@@ -210,7 +214,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
         oraclelib.mapreduce(p, 4)
         return arrays[0]
 
-    n = {"tiled_big": 40, "tiled_blocks": 30, "flat": 50, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
+    n = {"reduce_short": 40, "tiled_big": 40, "tiled_blocks": 30, "flat": 50, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:

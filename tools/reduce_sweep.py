@@ -17,7 +17,7 @@ from bench import colmajor_view, event_time_ms, graph_of  # noqa: E402
 lib = S._lib.load()
 FULL = "--full" in sys.argv
 DEFAULTS = {"reduce_part_wgs": lib.smr_get_option(b"reduce_part_wgs"), "reduce_col_txlog": lib.smr_get_option(b"reduce_col_txlog"), "reduce_part_kind": -1,
-            "reduce_single": lib.smr_get_option(b"reduce_single"), "reduce_col_narrow": lib.smr_get_option(b"reduce_col_narrow")}
+            "reduce_single": lib.smr_get_option(b"reduce_single"), "reduce_col_narrow": lib.smr_get_option(b"reduce_col_narrow"), "reduce_row_floor": -1, "reduce_row_dense": 1}
 
 
 def cur():
@@ -39,7 +39,10 @@ def setopts(**kw):
 
 
 for dims, dt in (((100, 90, 80, 7), torch.float32), ((512, 384, 64), torch.float32), ((100, 90, 80, 7), torch.float64), ((256, 256, 256), torch.float32),
-                 ((64, 64, 64), torch.float64), ((1000, 1000), torch.float64), ((4096, 4096), torch.float32)):
+                 ((64, 64, 64), torch.float64), ((1000, 1000), torch.float64), ((4096, 4096), torch.float32),
+                 ((3, 1920, 1080), torch.float32), ((3, 1920, 1080), torch.float64), ((7, 1000000), torch.float64), ((48, 300, 300), torch.complex64),
+                 ((64, 100000), torch.float32), ((20, 30, 40, 50), torch.float64), ((12, 400000), torch.float32), ((32, 200000), torch.float32),
+                 ((200, 50000), torch.float32), ((1000, 20000), torch.float32), ((7, 1000, 1000), torch.float64), ((4, 512, 512, 8), torch.float32)):
     n = int(np.prod(dims))
     A = colmajor_view(S, torch.randn(n, dtype=dt, device="cuda"), dims)
     for k in range(1, len(dims)):
@@ -51,6 +54,17 @@ for dims, dt in (((100, 90, 80, 7), torch.float32), ((512, 384, 64), torch.float
             plan = S.make_plan(lambda x: x, "+", "zero", dims, S.promoteshape(dims, out, A))
             d = plan.describe()
             res.append((time_plan(plan, 30), "defaults: %s" % d[d.find("form="):d.find(" algbytes")]))
+            setopts(reduce_row_dense=0)
+            plan = S.make_plan(lambda x: x, "+", "zero", dims, S.promoteshape(dims, out, A))
+            d2 = plan.describe()
+            if d2 != d:
+                res.append((time_plan(plan, 30), "row_dense=0: %s" % d2[d2.find("form="):d2.find(" algbytes")]))
+            for fl in (0, 2, 4):
+                setopts(reduce_row_floor=fl)
+                plan = S.make_plan(lambda x: x, "+", "zero", dims, S.promoteshape(dims, out, A))
+                d2 = plan.describe()
+                if "form=row" in d2:
+                    res.append((time_plan(plan, 30), "row_floor=%d: %s" % (fl, d2[d2.find("form="):d2.find(" algbytes")])))
             for kind in (-1, 1, 2):
                 for wgs in (1024, 256, 512, 2048, 4096):
                     for tx in (5, 3, 4, 6, 7, 8):
