@@ -298,7 +298,8 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * "orbit_lg" / "orbit_min" / "orbit_few" (orbit tile edge and thresholds), "orbit_pipe" (persistent
  * pipelined orbits: -1 auto, 0, 1), "nt_store" (non-temporal stores: -1 auto, 0 never, 1 always),
  * "nt_stream_min", "nt_load" (non-temporal loads of complete reductions: -1 auto, 0, 1), "flat" (FLAT family for short
- * leading dims that are not powers of two, on/off), "tile_block" (block tile order for distinct arrays with several unit
+ * leading dims that are not powers of two, on/off), "flat2" (its two-sided form: 0 off, 1 planner's rule, 2 wherever it applies) /
+ * "flat2_bytes" / "flat2_lead_bytes", "reduce_row_floor", "reduce_row_dense", "tile_block" (block tile order for distinct arrays with several unit
  * axes: -1 auto, 0 off, n), "tile_block_xcd", "orbit_group", "orbit_minrun", "orbit_wgs".  Experiment
  * switches: "stream_u", "orbit_lds_min", "orbit_skew", "tile_block_min_axes"; "stamp_base" / "stamp_cap" / "stamp_used" (debug build
  * with device-side wall-clock stamps, csrc/smr_device.h).  Read-only counters through

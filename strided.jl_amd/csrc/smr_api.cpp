@@ -521,6 +521,9 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_col_narrow") o.reduce_col_narrow = value;
     else if (n == "reduce_row_floor") o.reduce_row_floor = value;
     else if (n == "reduce_row_dense") o.reduce_row_dense = value;
+    else if (n == "flat2") o.flat2 = value;
+    else if (n == "flat2_bytes") o.flat2_bytes = value;
+    else if (n == "flat2_lead_bytes") o.flat2_lead_bytes = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
@@ -577,6 +580,9 @@ int64_t smr_get_option(const char* name) {
     if (n == "reduce_col_narrow") return o.reduce_col_narrow;
     if (n == "reduce_row_floor") return o.reduce_row_floor;
     if (n == "reduce_row_dense") return o.reduce_row_dense;
+    if (n == "flat2") return o.flat2;
+    if (n == "flat2_bytes") return o.flat2_bytes;
+    if (n == "flat2_lead_bytes") return o.flat2_lead_bytes;
     if (n == "jit_compiles") return jit_stats().compiles;
     if (n == "jit_hits") return jit_stats().hits;
     if (n == "jit_failures") return jit_stats().failures;

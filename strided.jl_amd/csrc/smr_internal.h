@@ -171,12 +171,23 @@ struct FlatPlan {
     int32_t roff[64];  // line-side element offset of the leading index r
 };
 
+// Two-sided form of the FLAT family: BOTH sides' memory runs are short groups of leading dims (permutedims of (5,300,300,7)
+// into (7,300,300,5), of (17,33,65,31) reversed).  Side 0 = destination, 1 = input: run = leading dims taken whole (product R)
+// x a tile TP of the next contiguous dim p; the two runs share no dim.
+struct Flat2Plan {
+    bool on = false;
+    int R[2] = {1, 1}, TP[2] = {1, 1}, p[2] = {-1, -1};
+    bool ingroup[2][MAXN] = {{false, false, false, false, false, false, false, false}, {false, false, false, false, false, false, false, false}};
+    int32_t roff[2][64];  // roff[s][r]: element offset on the OTHER side of leading index r of side s's run
+};
+
 struct Plan {
     Canon c;
     int family = FAM_GENERIC;
     TilePlan tile;
     OrbitPlan orbit;
     FlatPlan flat;
+    Flat2Plan flat2;
     // STREAM
     int vec = 1;        // elements per vector access
     // reductions
@@ -218,6 +229,9 @@ struct Options {
     i64 reduce_part_wgs = 1024; // partial reductions with fewer workgroups than this are split until about this many run (4096 until
                                 // round 3: 512-1024 is as fast or faster on every shape of tools/reduce_sweep.py, with 4x fewer partials)
     i64 reduce_row_floor = -1;  // ROW form: least log2 lanes per output (-1 = planner's rule)
+    i64 flat2 = 1;              // two-sided FLAT form (both sides' runs are short leading dims): on / off
+    i64 flat2_bytes = 384;      // ... target bytes of a run
+    i64 flat2_lead_bytes = 512; // ... both sides' unit-stride dims must be shorter than this
     i64 reduce_row_dense = 1;   // ROW form: lanes along the outputs when the inner reduced dim is at most 64 bytes and kept dim 0 is dense behind it
     i64 reduce_col_narrow = 1;  // COL form: narrow the row segments when that yields reduce_part_wgs workgroups without a split
     i64 reduce_part_kind = -1;  // -1 = planner's choice; 0/1/2 force general / ROW / COL when applicable

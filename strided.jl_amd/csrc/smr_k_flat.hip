@@ -247,10 +247,143 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
     }
 }
 
+// ---- two-sided form ------------------------------------------------------------------------------------------------
+// Both sides' memory runs are short groups of leading dims (plan_flat2): run s = R[s] leading elements x a tile TP[s] of the next
+// contiguous dim p[s], L[s] = R[s] * TP[s] <= 128 consecutive elements of side s's memory; side 0 = destination, 1 = input.
+// A tile is the L[0] x L[1] product.  Phase 1 enumerates it input-run-major (lanes along the input's memory), phase 2
+// destination-run-major; LDS[b][a] with an odd row pitch.  No lane is spent on padding: extents of 5, 7, 17, 31 fill the tile.
+struct Flat2Args {
+    OpTab ops;
+    int32_t R[2], TP[2], L[2];
+    int32_t nouter, conjv;
+    uint32_t ntp[2];                      // tiles along p[0] / p[1]
+    uint32_t magicR[2], magicL[2];        // floor(2^32 / d) + 1 for d = R[s], L[s]
+    i64 dimp[2];                          // extents of p[s] (1 when there is none)
+    i64 spo[2];                           // stride of p[s] on the OTHER side
+    int32_t roff[2][FLAT_MAXR];           // offset on the other side of leading index r of run s
+    i64 oext[MAXN], os0[MAXN], os1[MAXN]; // outer dims: extents, destination / input strides
+};
+
+template <class T, class F>
+SMR_DEV void flat2_body(const Flat2Args a, F f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_flat[];
+    T* lds = reinterpret_cast<T*>(smem_flat);
+    const uint32_t tid = threadIdx.x;
+    uint32_t b = blockIdx.x;
+    const uint32_t t0 = b % a.ntp[0];
+    b /= a.ntp[0];
+    const uint32_t t1 = b % a.ntp[1];
+    b /= a.ntp[1];
+    i64 bd = 0, bs = 0;  // element offsets of the tile origin in the destination / the input
+    for (int i = 0; i < a.nouter; ++i) {
+        const uint32_t e = (uint32_t)a.oext[i];
+        const uint32_t c = b % e;
+        b /= e;
+        bd += (i64)c * a.os0[i];
+        bs += (i64)c * a.os1[i];
+    }
+    const i64 p0 = (i64)t0 * a.TP[0], p1 = (i64)t1 * a.TP[1];
+    bd += p0 * a.R[0] + p1 * a.spo[1];
+    bs += p1 * a.R[1] + p0 * a.spo[0];
+    const int n0 = (int)(((a.dimp[0] - p0 < a.TP[0]) ? (a.dimp[0] - p0) : a.TP[0]) * a.R[0]);  // valid prefix of the destination run
+    const int n1 = (int)(((a.dimp[1] - p1 < a.TP[1]) ? (a.dimp[1] - p1) : a.TP[1]) * a.R[1]);  // ... of the input run
+    const int L0 = a.L[0], L1 = a.L[1], PITCH = L0 | 1;
+    const T* src = (const T*)a.ops.base[1];
+    T* dst = (T*)a.ops.base[0];
+    const bool cin = a.conjv && a.ops.conj[1], cout = a.conjv && a.ops.conj[0];
+    (void)cin;
+    (void)cout;
+    // phase 1: (x along the destination run) x (y along the input run), lanes along y
+    for (int i = (int)tid; i < n0 * L1; i += 256) {
+        const int x = (int)fdiv16((uint32_t)i, a.magicL[1]), y = i - x * L1;
+        if (y < n1) {
+            const int jp = (int)fdiv16((uint32_t)x, a.magicR[0]), r = x - jp * a.R[0];
+            lds[y * PITCH + x] = src[bs + y + a.roff[0][r] + (i64)jp * a.spo[0]];
+        }
+    }
+    __syncthreads();
+    // phase 2: lanes along x
+    for (int i = (int)tid; i < n1 * L0; i += 256) {
+        const int y = (int)fdiv16((uint32_t)i, a.magicL[0]), x = i - y * L0;
+        if (x < n0) {
+            const int jp = (int)fdiv16((uint32_t)y, a.magicR[1]), r = y - jp * a.R[1];
+            T arg[MAXIN];
+#pragma unroll
+            for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
+            T t = lds[y * PITCH + x];
+            if constexpr (tr<T>::cx) {
+                if (cin) t = cj(t);
+            }
+            arg[0] = t;
+            T rr = f(arg);
+            if constexpr (tr<T>::cx) {
+                if (cout) rr = cj(rr);
+            }
+            dst[bd + x + a.roff[1][r] + (i64)jp * a.spo[1]] = rr;
+        }
+    }
+}
+
 #ifndef SMR_JIT
 template <class T, class F, int DIR, int VL, int VF>
 __global__ void __launch_bounds__(256) k_flat_map(const FlatArgs a, F f) {
     flat_map_body<T, F, DIR, VL, VF>(a, f);
+}
+template <class T, class F>
+__global__ void __launch_bounds__(256) k_flat2_map(const Flat2Args a, F f) {
+    flat2_body<T, F>(a, f);
+}
+
+template <class T, class F>
+static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    const Canon& c = plan.c;
+    const Flat2Plan& fp = plan.flat2;
+    Flat2Args a;
+    std::memset(&a, 0, sizeof a);
+    a.ops = make_optab(c, bases);
+    i64 blocks = 1;
+    for (int t = 0; t < 2; ++t) {
+        a.R[t] = fp.R[t];
+        a.TP[t] = fp.TP[t];
+        a.L[t] = fp.R[t] * fp.TP[t];
+        a.dimp[t] = fp.p[t] >= 0 ? c.dims[fp.p[t]] : 1;
+        a.spo[t] = fp.p[t] >= 0 ? c.strides[1 - t][fp.p[t]] : 0;
+        a.ntp[t] = (unsigned)((a.dimp[t] + fp.TP[t] - 1) / fp.TP[t]);
+        a.magicR[t] = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.R[t] + 1);
+        a.magicL[t] = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.L[t] + 1);
+        for (int r = 0; r < fp.R[t]; ++r) a.roff[t][r] = fp.roff[t][r];
+        blocks *= a.ntp[t];
+    }
+    a.conjv = (c.conj[0] || c.conj[1]) ? 1 : 0;
+    for (int d = 0; d < c.N; ++d) {
+        if (d == fp.p[0] || d == fp.p[1] || fp.ingroup[0][d] || fp.ingroup[1][d]) continue;
+        a.oext[a.nouter] = c.dims[d];
+        a.os0[a.nouter] = c.strides[0][d];
+        a.os1[a.nouter] = c.strides[1][d];
+        blocks *= c.dims[d];
+        ++a.nouter;
+    }
+    if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "flat plan: too many tiles");
+    const size_t lds = (size_t)a.L[1] * (size_t)(a.L[0] | 1) * sizeof(T);
+    const unsigned grid = (unsigned)blocks;
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "flat";
+        l.tname = tname<T>();
+        l.argtype = "smr::Flat2Args";
+        l.entry = std::string("smr::flat2_body<") + tname<T>() + ", smr::FJit>(a, smr::FJit{kc});";
+        l.grid = grid;
+        l.block = 256;
+        l.lds = lds;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(plan.c, l, s);
+    } else {
+        if (jit_no_launch()) return SMR_OK;
+        clear_sticky_error();
+        hipLaunchKernelGGL((k_flat2_map<T, F>), dim3(grid), dim3(256), lds, s, a, f);
+        return check_launch("k_flat2_map");
+    }
 }
 
 template <class T, class F, int DIR, int VL, int VF>
@@ -370,12 +503,13 @@ template <>
 int launch_flat_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t s) {
     typedef ct_type<SMR_CT>::type T;
     const Canon& c = plan.c;
+    const bool two = plan.flat2.on;
     if (c.bitcopy) {
 #if SMR_CT == SMR_F32
         switch (c.esize[0]) {
-            case 4: return go<float, FIdent<float>>(plan, bases, s, FIdent<float>{});
-            case 8: return go<double, FIdent<double>>(plan, bases, s, FIdent<double>{});
-            case 16: return go<c64, FIdent<c64>>(plan, bases, s, FIdent<c64>{});
+            case 4: return two ? go2<float, FIdent<float>>(plan, bases, s, FIdent<float>{}) : go<float, FIdent<float>>(plan, bases, s, FIdent<float>{});
+            case 8: return two ? go2<double, FIdent<double>>(plan, bases, s, FIdent<double>{}) : go<double, FIdent<double>>(plan, bases, s, FIdent<double>{});
+            case 16: return two ? go2<c64, FIdent<c64>>(plan, bases, s, FIdent<c64>{}) : go<c64, FIdent<c64>>(plan, bases, s, FIdent<c64>{});
             default: return set_error(SMR_EINVAL, "flat plan: 1- / 2-byte moves take the generic family");
         }
 #else
@@ -383,10 +517,13 @@ int launch_flat_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t
 #endif
     }
     switch (c.fkind) {
-        case FK_IDENT: return go<T, FIdent<T>>(plan, bases, s, FIdent<T>{});
-        case FK_SCALE: return go<T, FScale<T>>(plan, bases, s, FScale<T>{hostmk<T>(c.fc[0], c.fc[1])});
+        case FK_IDENT: return two ? go2<T, FIdent<T>>(plan, bases, s, FIdent<T>{}) : go<T, FIdent<T>>(plan, bases, s, FIdent<T>{});
+        case FK_SCALE:
+            return two ? go2<T, FScale<T>>(plan, bases, s, FScale<T>{hostmk<T>(c.fc[0], c.fc[1])})
+                       : go<T, FScale<T>>(plan, bases, s, FScale<T>{hostmk<T>(c.fc[0], c.fc[1])});
         default: break;
     }
+    if (two) return with_prog<T>(c, [&](auto f) { return go2<T, decltype(f)>(plan, bases, s, f); });
     return with_prog<T>(c, [&](auto f) { return go<T, decltype(f)>(plan, bases, s, f); });
 }
 #endif  // !SMR_JIT

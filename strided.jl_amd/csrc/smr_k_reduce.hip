@@ -822,7 +822,10 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     int blocks = plan.red_blocks;
     if (blocks > 1 && !plan.scratch) blocks = 1;
     a.nparts = blocks;
-    a.single = (blocks > 1 && blocks <= options().reduce_single) ? 1 : 0;
+    // up to 64 partials are folded inside the launch (1 MiB: 4.9 -> 4.1 us; tools/reduce_all_sweep.py) -- the arrivals of ONE
+    // counter serialise, so larger reductions keep the second launch (8 MiB with 256 workgroups: 6.6 vs 5.4 us)
+    const i64 rs = options().reduce_single;
+    a.single = (blocks > 1 && rs > 0 && blocks <= std::max<i64>(rs, 64)) ? 1 : 0;
     // vector path: one fused dim, every input unit stride / broadcast, 16-B aligned
     constexpr int VMAX = (sizeof(T) >= 16) ? 1 : (int)(16 / sizeof(T));
     bool vec = !MIXED && VMAX > 1 && c.N == 1 && (c.total % VMAX == 0) && c.total >= 4096;

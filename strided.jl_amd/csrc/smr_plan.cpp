@@ -1132,6 +1132,102 @@ static bool plan_flat(const Canon& c, FlatPlan& f) {
     return plan_flat_side(c, f, 0, es) || plan_flat_side(c, f, 1, es);
 }
 
+// Two-sided FLAT form: the unit-stride dims of BOTH sides are short (under 256 bytes) and at least one of them is not a
+// power of two (or under 32 bytes): no power-of-two tile fits either side -- (17,33,65,31) reversed runs a 32 x 32 tile over a
+// 31 x 17 face with 51 % of its lanes.  Each side's run = its leading dims taken whole while the run stays short + a tile of the
+// next contiguous dim, about flat2_bytes long; the runs share no dim (smr_k_flat.hip, flat2_body).
+static bool plan_flat2(const Canon& c, Flat2Plan& f) {
+    const Options& o = options();
+    f.on = false;
+    if (!o.flat2 || !o.flat || c.redop != SMR_RED_NONE || c.M != 2 || c.mixed || c.N < 2) return false;
+    const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+    if (es < 4 || c.total < 65536) return false;
+    int lead[2] = {-1, -1};
+    for (int s = 0; s < 2; ++s)
+        for (int d = 0; d < c.N; ++d) {
+            if (c.strides[s][d] <= 0) return false;
+            if (c.strides[s][d] == 1 && c.dims[d] > 1) lead[s] = d;
+        }
+    if (lead[0] < 0 || lead[1] < 0 || lead[0] == lead[1]) return false;
+    bool awkward = false;
+    for (int s = 0; s < 2; ++s) {
+        const i64 e = c.dims[lead[s]];
+        if (e * es >= o.flat2_lead_bytes) return false;
+        if ((e & (e - 1)) != 0 || e * es < 32) awkward = true;
+    }
+    if (!awkward) return false;
+    bool used[MAXN];
+    for (int d = 0; d < MAXN; ++d) used[d] = f.ingroup[0][d] = f.ingroup[1][d] = false;
+    used[lead[0]] = used[lead[1]] = true;
+    const i64 target = std::max<i64>(64, o.flat2_bytes);
+    for (int s = 0; s < 2; ++s) {
+        f.ingroup[s][lead[s]] = true;
+        i64 R = c.dims[lead[s]];
+        f.p[s] = -1;
+        f.TP[s] = 1;
+        for (;;) {
+            int nxt = -1;
+            for (int d = 0; d < c.N; ++d)
+                if (!used[d] && c.strides[s][d] == R && c.dims[d] > 1) nxt = d;
+            if (nxt < 0) break;
+            used[nxt] = true;
+            if (R * c.dims[nxt] <= 64 && R * c.dims[nxt] * es <= target) {
+                f.ingroup[s][nxt] = true;
+                R *= c.dims[nxt];
+                continue;
+            }
+            i64 tp = std::max<i64>(1, std::min<i64>(std::min<i64>(target / (R * es), 128 / R), c.dims[nxt]));
+            const i64 nt = (c.dims[nxt] + tp - 1) / tp;
+            tp = (c.dims[nxt] + nt - 1) / nt;  // evened out over the extent
+            f.p[s] = nxt;
+            f.TP[s] = (int)tp;
+            break;
+        }
+        if (R > 64) return false;
+        f.R[s] = (int)R;
+    }
+    // enough tiles for the device: shorten the longer run while it stays above 128 bytes
+    auto ntiles = [&]() {
+        i64 n = 1;
+        for (int d = 0; d < c.N; ++d) {
+            if (f.ingroup[0][d] || f.ingroup[1][d]) continue;
+            if (d == f.p[0]) n *= (c.dims[d] + f.TP[0] - 1) / f.TP[0];
+            else if (d == f.p[1]) n *= (c.dims[d] + f.TP[1] - 1) / f.TP[1];
+            else n *= c.dims[d];
+        }
+        return n;
+    };
+    for (int guard = 0; guard < 16 && ntiles() < 1024; ++guard) {
+        const int s = ((i64)f.R[0] * f.TP[0] >= (i64)f.R[1] * f.TP[1]) ? 0 : 1;
+        int pick = -1;
+        for (int t : {s, 1 - s})
+            if (pick < 0 && f.TP[t] > 1 && (i64)f.R[t] * ((f.TP[t] + 1) / 2) * es >= 128) pick = t;
+        if (pick < 0) break;
+        f.TP[pick] = (f.TP[pick] + 1) / 2;
+    }
+    if ((i64)f.R[0] * f.TP[0] > 128 || (i64)f.R[1] * f.TP[1] > 128) return false;
+    if ((i64)f.R[0] * f.TP[0] * es < 64 && (i64)f.R[1] * f.TP[1] * es < 64) return false;  // nothing gained over the generic kernel
+    if (ntiles() > 0x7fffffffLL) return false;
+    // offsets on the other side of the leading index r of each run (mixed radix over the group dims in this side's stride order)
+    for (int s = 0; s < 2; ++s) {
+        std::vector<int> order;
+        for (int d = 0; d < c.N; ++d)
+            if (f.ingroup[s][d]) order.push_back(d);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return c.strides[s][x] < c.strides[s][y]; });
+        for (i64 r = 0; r < f.R[s]; ++r) {
+            i64 rem = r, off = 0;
+            for (int d : order) {
+                off += (rem % c.dims[d]) * c.strides[1 - s][d];
+                rem /= c.dims[d];
+            }
+            if (off > 2147483647LL) return false;
+            f.roff[s][r] = (int32_t)off;
+        }
+    }
+    f.on = true;
+    return true;
+}
+
 // ---- family selection -------------------------------------------------------------------------------
 int make_plan(const smr_problem* p, Plan& plan) {
     int rc = canonicalise(p, plan.c);
@@ -1139,7 +1235,16 @@ int make_plan(const smr_problem* p, Plan& plan) {
     const Canon& c = plan.c;
     const Options& o = options();
     int fam = FAM_GENERIC;
-    if (c.redop == SMR_RED_NONE && o.force_family == 0 && plan_flat(c, plan.flat)) {
+    plan.flat2.on = false;
+    // FLAT: the one-sided form first -- unless its line side is under 8 elements long, where the two-sided form's bigger tiles win
+    // (ComplexF64 (6,64,64,64,5) reversed 94 -> 40 us, (4,300,300,3) 16.5 -> 7.6; with 24-element lines the one-sided form's
+    // vector accesses are 1.5x ahead; profiles/r03_flat2_ab.txt).  flat2 = 2: the two-sided form wherever it applies (experiments)
+    const bool flat_ok = c.redop == SMR_RED_NONE && o.force_family == 0;
+    const bool one = flat_ok && plan_flat(c, plan.flat);
+    const bool two_first = flat_ok && (o.flat2 >= 2 || !one || (!plan.flat.fuse && !plan.flat.lshare && c.dims[plan.flat.q] < 8));
+    if (two_first && plan_flat2(c, plan.flat2)) {
+        fam = FAM_FLAT;
+    } else if (one) {
         fam = FAM_FLAT;
     } else if (c.redop == SMR_RED_NONE) {
         bool stream = true;
@@ -1393,6 +1498,9 @@ void describe(Plan& plan) {
                 first = false;
             }
         n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.list.size());
+    } else if (plan.family == FAM_FLAT && plan.flat2.on) {
+        const Flat2Plan& f2 = plan.flat2;
+        n += std::snprintf(buf + n, sizeof buf - n, " two-sided dest_run=%dx%d(d%d) input_run=%dx%d(d%d)", f2.R[0], f2.TP[0], f2.p[0], f2.R[1], f2.TP[1], f2.p[1]);
     } else if (plan.family == FAM_FLAT) {
         const FlatPlan& fp = plan.flat;
         n += std::snprintf(buf + n, sizeof buf - n, " flat_side=%s run=%dx%d(d%d)%s line=d%d:%d", fp.dir == 0 ? "dest" : "input", fp.R, 1 << fp.tplog, fp.p,

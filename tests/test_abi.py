@@ -431,6 +431,18 @@ def test_planner_rules_for_short_dims_big_transposes_and_short_reductions():
     d = perm((100, 3, 100, 3, 10), (4, 3, 2, 1, 0))
     assert "family=flat" in d and "run=30x2(d2)" in d, d
     assert "family=flat" not in perm((4, 1000, 700), (2, 1, 0))      # powers of two stay with the tiled family
+    # ... and when BOTH sides' unit-stride dims are short, each side gets a run of its own (two-sided form)
+    d = perm((5, 300, 300, 7), (3, 2, 1, 0))
+    assert "family=flat" in d and "two-sided dest_run=7x6(d1) input_run=5x9(d2)" in d, d
+    d = perm((17, 33, 65, 31), (3, 2, 1, 0))
+    assert "two-sided dest_run=31x1(d1) input_run=17x2(d2)" in d, d
+    assert "two-sided" in perm((6, 64, 64, 64, 5), (4, 3, 2, 1, 0), np.complex128)   # one-sided line of 5 elements: two-sided first
+    assert "two-sided" not in perm((24, 100, 100, 20), (3, 2, 1, 0), np.float32)     # 24-element lines: one-sided with 16-byte accesses
+    S.set_option("flat2", 0)
+    try:
+        assert "family=tiled" in perm((5, 300, 300, 7), (3, 2, 1, 0))
+    finally:
+        S.set_option("flat2", 1)
     # HBM-sized transposes of 8-/16-byte elements: 128 x 32 tiles on 1024 lanes; Float32 and smaller problems: 32 x 32
     assert "tile=d0:128,d1:32" in perm((8192, 8192), (1, 0)) and "threads=1024" in perm((8192, 8192), (1, 0))
     assert "tile=d0:32,d1:32" in perm((8192, 8192), (1, 0), np.float32)

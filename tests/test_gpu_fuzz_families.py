@@ -105,6 +105,14 @@ def recipe(name, seed, T):
         f, nin, exact = UN[int(rng0.integers(0, len(UN)))]
         dims = pick([(3, 480, 640), (3, 100, 70, 5), (5, 33, 200), (10, 3, 100, 3, 10), (6, 50, 41, 9), (3, 64, 1000), (7, 7, 300), (12, 40, 130)])
         mkview = None
+    elif name == "flat2":
+        # round 3: both sides' unit-stride dims are short and not powers of two (two-sided FLAT form); the input's leading dim is drawn
+        # among the box dims, so one-sided FLAT, TILED and STREAM plans are mixed in
+        UN = [(lambda a: a, 1, True), (lambda a: a * 2.5, 1, True), (lambda a: fn.abs2(a) + 1, 1, True), (lambda a: fn.conj(a) * 3, 1, True)]
+        f, nin, exact = UN[int(rng0.integers(0, len(UN)))]
+        dims = pick([(5, 60, 50, 7), (17, 9, 33, 31), (3, 100, 90, 3), (7, 30, 40, 9), (6, 16, 16, 16, 5), (12, 10, 14, 9, 11), (10, 50, 60, 10), (31, 65, 33, 17)])
+        coin[2] = len(dims) - 2 if coin[4] % 3 else coin[2]   # two times in three the LAST box dim leads the input
+        mkview = None
     elif name == "tiled_blocks":
         # round 3: distinct arrays with three or four different unit axes, the tiles visited in compact blocks
         # (forced block edge / XCD runs / tile size; VERDICT r2 item 4: `add4 of 4 distinct arrays`, a 3-array map)
@@ -151,7 +159,11 @@ def recipe(name, seed, T):
     def run(mk, describe=None):
         rng = np.random.default_rng(vseed)
         data = _data(rng, T)
-        if name == "flat":
+        if name == "flat2":
+            ins = [_flat_line_view(mk, data, dims, coin)]
+            if np.issubdtype(np.dtype(T), np.complexfloating) and coin[1] % 3 == 0:
+                ins = [ins[0].conj()]
+        elif name == "flat":
             ins = [_flat_line_view(mk, data, dims, coin) if coin[0] % 2 else mk(data(dims))]
             if np.issubdtype(np.dtype(T), np.complexfloating) and coin[1] % 3 == 0:
                 ins = [ins[0].conj()]
@@ -200,7 +212,7 @@ def _initop_fn(i):
 
 
 RECIPES = ["stream", "stream_strided", "tiled", "tiled_reversed", "tiled_persistent", "tiled_short0", "tiled_big", "orbit", "orbit_pipe", "aliased_classic", "generic",
-           "reduce_all", "reduce_part", "tiled_blocks", "flat", "reduce_short"]
+           "reduce_all", "reduce_part", "tiled_blocks", "flat", "reduce_short", "flat2"]
 
 SEED_OFFSET = int(os.environ.get("SMR_FUZZ_SEED_OFFSET", "0"))  # other seeds for longer campaigns on a GPU box
 
@@ -214,7 +226,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
         oraclelib.mapreduce(p, 4)
         return arrays[0]
 
-    n = {"reduce_short": 40, "tiled_big": 40, "tiled_blocks": 30, "flat": 50, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
+    n = {"reduce_short": 40, "flat2": 40, "tiled_big": 40, "tiled_blocks": 30, "flat": 50, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:
@@ -234,6 +246,8 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
                     S.set_option(k, {"tiled_persist_min": 32, "orbit": 1, "orbit_pipe": -1, "tile_block": -1, "tile_block_xcd": -1, "tile_log2": 0}[k])
             d = desc[0]
             key = d[d.find("family=") + 7:d.find(" ct=")]
+            if key == "flat" and "two-sided" in d:
+                key = "flat:two-sided"
             if key == "reduce_part":
                 key += ":" + d[d.find("form=") + 5:].split()[0]
             if key == "tiled":
@@ -265,4 +279,5 @@ def test_every_family_was_hit_often_enough():
         by_family[k.split(":")[0]] += v
     for famname in ("stream", "tiled", "orbit", "generic", "reduce_all", "reduce_part"):
         assert by_family[famname] >= 200, (famname, dict(by_family))
+    assert COUNTS["flat:two-sided"] >= 40, dict(COUNTS)    # round 3: two-sided FLAT form
     assert by_family["flat"] >= 60, dict(by_family)   # round 3: the FLAT family (short leading dims that are not powers of two)
