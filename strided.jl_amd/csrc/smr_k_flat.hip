@@ -293,33 +293,60 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
     const bool cin = a.conjv && a.ops.conj[1], cout = a.conjv && a.ops.conj[0];
     (void)cin;
     (void)cout;
-    // phase 1: (x along the destination run) x (y along the input run), lanes along y
-    for (int i = (int)tid; i < n0 * L1; i += 256) {
-        const int x = (int)fdiv16((uint32_t)i, a.magicL[1]), y = i - x * L1;
-        if (y < n1) {
-            const int jp = (int)fdiv16((uint32_t)x, a.magicR[0]), r = x - jp * a.R[0];
-            lds[y * PITCH + x] = src[bs + y + a.roff[0][r] + (i64)jp * a.spo[0]];
+    // the other side's offset of every position of the two runs, once per workgroup (the loops below then cost one LDS read per
+    // element instead of two multiply-highs and a table load from the kernel arguments)
+    i64* offs = reinterpret_cast<i64*>(smem_flat + (((size_t)L1 * PITCH * sizeof(T) + 15) & ~(size_t)15));  // input offset of x
+    i64* offd = offs + L0;                                                                                  // destination offset of y
+    if ((int)tid < L0) {
+        const int jp = (int)fdiv16(tid, a.magicR[0]), r = (int)tid - jp * a.R[0];
+        offs[tid] = (i64)a.roff[0][r] + (i64)jp * a.spo[0];
+    } else if ((int)tid >= 128 && (int)tid - 128 < L1) {
+        const int y = (int)tid - 128;
+        const int jp = (int)fdiv16((uint32_t)y, a.magicR[1]), r = y - jp * a.R[1];
+        offd[y] = (i64)a.roff[1][r] + (i64)jp * a.spo[1];
+    }
+    __syncthreads();
+    // phase 1: (x along the destination run) x (y along the input run), lanes along y; (x, y) advance by 256 positions per step
+    {
+        const int dx = (int)fdiv16(256u, a.magicL[1]), dy = 256 - dx * L1;
+        int x = (int)fdiv16(tid, a.magicL[1]), y = (int)tid - x * L1;
+        while (x < n0) {
+            if (y < n1) lds[y * PITCH + x] = src[bs + y + offs[x]];
+            x += dx;
+            y += dy;
+            if (y >= L1) {
+                y -= L1;
+                ++x;
+            }
         }
     }
     __syncthreads();
     // phase 2: lanes along x
-    for (int i = (int)tid; i < n1 * L0; i += 256) {
-        const int y = (int)fdiv16((uint32_t)i, a.magicL[0]), x = i - y * L0;
-        if (x < n0) {
-            const int jp = (int)fdiv16((uint32_t)y, a.magicR[1]), r = y - jp * a.R[1];
-            T arg[MAXIN];
+    {
+        const int dy = (int)fdiv16(256u, a.magicL[0]), dx = 256 - dy * L0;
+        int y = (int)fdiv16(tid, a.magicL[0]), x = (int)tid - y * L0;
+        while (y < n1) {
+            if (x < n0) {
+                T arg[MAXIN];
 #pragma unroll
-            for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
-            T t = lds[y * PITCH + x];
-            if constexpr (tr<T>::cx) {
-                if (cin) t = cj(t);
+                for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
+                T t = lds[y * PITCH + x];
+                if constexpr (tr<T>::cx) {
+                    if (cin) t = cj(t);
+                }
+                arg[0] = t;
+                T rr = f(arg);
+                if constexpr (tr<T>::cx) {
+                    if (cout) rr = cj(rr);
+                }
+                dst[bd + x + offd[y]] = rr;
             }
-            arg[0] = t;
-            T rr = f(arg);
-            if constexpr (tr<T>::cx) {
-                if (cout) rr = cj(rr);
+            y += dy;
+            x += dx;
+            if (x >= L0) {
+                x -= L0;
+                ++y;
             }
-            dst[bd + x + a.roff[1][r] + (i64)jp * a.spo[1]] = rr;
         }
     }
 }
@@ -364,7 +391,7 @@ static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         ++a.nouter;
     }
     if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "flat plan: too many tiles");
-    const size_t lds = (size_t)a.L[1] * (size_t)(a.L[0] | 1) * sizeof(T);
+    const size_t lds = (((size_t)a.L[1] * (size_t)(a.L[0] | 1) * sizeof(T) + 15) & ~(size_t)15) + (size_t)(a.L[0] + a.L[1]) * sizeof(i64);
     const unsigned grid = (unsigned)blocks;
     if constexpr (is_jit<F>::value) {
         JitLaunch l;

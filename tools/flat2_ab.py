@@ -46,7 +46,7 @@ for dt in (torch.float64, torch.float32, torch.complex128):
         n = len(shape)
         ref = tA.reshape(tuple(reversed(shape))).permute(*[n - 1 - q[n - 1 - i] for i in range(n)]).contiguous().reshape(-1)
         row = []
-        for mode, lead, rb in ((0, 256, 384), (1, 256, 384), (1, 512, 384), (1, 512, 256), (1, 512, 512), (2, 512, 384)):
+        for mode, lead, rb in ((0, 512, 384), (1, 512, 384), (1, 512, 256), (1, 512, 512), (2, 512, 384)):
             S._lib.check(lib.smr_set_option(b"flat2", mode))
             S._lib.check(lib.smr_set_option(b"flat2_lead_bytes", lead))
             S._lib.check(lib.smr_set_option(b"flat2_bytes", rb))
