@@ -176,6 +176,7 @@ struct FlatPlan {
 // x a tile TP of the next contiguous dim p; the two runs share no dim.
 struct Flat2Plan {
     bool on = false;
+    bool shared = false;  // the input's run would continue along p[0] as well: phase 1 walks the destination run tile-index-major
     int R[2] = {1, 1}, TP[2] = {1, 1}, p[2] = {-1, -1};
     bool ingroup[2][MAXN] = {{false, false, false, false, false, false, false, false}, {false, false, false, false, false, false, false, false}};
     int32_t roff[2][64];  // roff[s][r]: element offset on the OTHER side of leading index r of side s's run

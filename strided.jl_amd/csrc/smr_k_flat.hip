@@ -256,6 +256,8 @@ struct Flat2Args {
     OpTab ops;
     int32_t R[2], TP[2], L[2];
     int32_t nouter, conjv;
+    int32_t shared;                       // the input would continue along p[0] too (stride R[1]): phase 1 walks the destination run tile-index-major
+    uint32_t magicTP0;
     uint32_t ntp[2];                      // tiles along p[0] / p[1]
     uint32_t magicR[2], magicL[2];        // floor(2^32 / d) + 1 for d = R[s], L[s]
     i64 dimp[2];                          // extents of p[s] (1 when there is none)
@@ -295,13 +297,25 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
     (void)cout;
     // the other side's offset of every position of the two runs, once per workgroup (the loops below then cost one LDS read per
     // element instead of two multiply-highs and a table load from the kernel arguments)
-    i64* offs = reinterpret_cast<i64*>(smem_flat + (((size_t)L1 * PITCH * sizeof(T) + 15) & ~(size_t)15));  // input offset of x
+    // Phase 1 visits the destination run in the order x' -> column xcol[x']: the identity, or -- `shared`: both sides continue
+    // along the SAME dim behind their leads, (5,N,7) -> (7,N,5) -- tile index fastest, so that consecutive (x', y) are consecutive
+    // in the input's memory (r1 + R[1] * jd) although the input's own run is only its lead.
+    i64* offs = reinterpret_cast<i64*>(smem_flat + (((size_t)L1 * PITCH * sizeof(T) + 15) & ~(size_t)15));  // input offset of x'
     i64* offd = offs + L0;                                                                                  // destination offset of y
-    if ((int)tid < L0) {
-        const int jp = (int)fdiv16(tid, a.magicR[0]), r = (int)tid - jp * a.R[0];
-        offs[tid] = (i64)a.roff[0][r] + (i64)jp * a.spo[0];
-    } else if ((int)tid >= 128 && (int)tid - 128 < L1) {
-        const int y = (int)tid - 128;
+    int* xcol = reinterpret_cast<int*>(offd + L1);
+    for (int t = (int)tid; t < L0; t += 256) {
+        int jp, r;
+        if (a.shared) {
+            r = (int)fdiv16((uint32_t)t, a.magicTP0);
+            jp = t - r * a.TP[0];
+        } else {
+            jp = (int)fdiv16((uint32_t)t, a.magicR[0]);
+            r = t - jp * a.R[0];
+        }
+        offs[t] = (i64)a.roff[0][r] + (i64)jp * a.spo[0];
+        xcol[t] = r + jp * a.R[0];
+    }
+    for (int y = 255 - (int)tid; y < L1; y += 256) {  // (the other end of the workgroup: L0 + L1 <= 256 is the common case)
         const int jp = (int)fdiv16((uint32_t)y, a.magicR[1]), r = y - jp * a.R[1];
         offd[y] = (i64)a.roff[1][r] + (i64)jp * a.spo[1];
     }
@@ -310,8 +324,9 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
     {
         const int dx = (int)fdiv16(256u, a.magicL[1]), dy = 256 - dx * L1;
         int x = (int)fdiv16(tid, a.magicL[1]), y = (int)tid - x * L1;
-        while (x < n0) {
-            if (y < n1) lds[y * PITCH + x] = src[bs + y + offs[x]];
+        while (x < L0) {
+            const int xc = xcol[x];
+            if (y < n1 && xc < n0) lds[y * PITCH + xc] = src[bs + y + offs[x]];
             x += dx;
             y += dy;
             if (y >= L1) {
@@ -391,7 +406,10 @@ static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         ++a.nouter;
     }
     if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "flat plan: too many tiles");
-    const size_t lds = (((size_t)a.L[1] * (size_t)(a.L[0] | 1) * sizeof(T) + 15) & ~(size_t)15) + (size_t)(a.L[0] + a.L[1]) * sizeof(i64);
+    const size_t lds = (((size_t)a.L[1] * (size_t)(a.L[0] | 1) * sizeof(T) + 15) & ~(size_t)15) + (size_t)(a.L[0] + a.L[1]) * sizeof(i64) +
+                       (size_t)a.L[0] * sizeof(int);
+    a.shared = (fp.shared && fp.TP[0] > 1) ? 1 : 0;
+    a.magicTP0 = fp.TP[0] > 1 ? (uint32_t)(((uint64_t)1 << 32) / (uint32_t)fp.TP[0] + 1) : 0u;
     const unsigned grid = (unsigned)blocks;
     if constexpr (is_jit<F>::value) {
         JitLaunch l;

@@ -1186,6 +1186,15 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
         if (R > 64) return false;
         f.R[s] = (int)R;
     }
+    // both sides continue along the same dim behind their leads ((5,N,7) -> (7,N,5)): the destination got it; the input's run is
+    // its lead alone, but input memory is still walked contiguously (Flat2Plan::shared)
+    f.shared = f.p[1] < 0 && f.p[0] >= 0 && c.strides[1][f.p[0]] == f.R[1] && f.TP[0] > 1;
+    if (f.shared) {  // the tile is R[0] x TP[0] x R[1]: a longer tile along the shared dim (16 KiB, at most 512 positions of the destination run)
+        const i64 dimp = c.dims[f.p[0]];
+        i64 tp = std::max<i64>(1, std::min<i64>(std::min<i64>(512 / f.R[0], 16384 / ((i64)f.R[0] * f.R[1] * es)), dimp));
+        const i64 nt = (dimp + tp - 1) / tp;
+        f.TP[0] = (int)((dimp + nt - 1) / nt);
+    }
     // enough tiles for the device: shorten the longer run while it stays above 128 bytes
     auto ntiles = [&]() {
         i64 n = 1;
@@ -1205,7 +1214,8 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
         if (pick < 0) break;
         f.TP[pick] = (f.TP[pick] + 1) / 2;
     }
-    if ((i64)f.R[0] * f.TP[0] > 128 || (i64)f.R[1] * f.TP[1] > 128) return false;
+    if (f.TP[0] <= 1) f.shared = false;  // one position along the shared dim: the two orders coincide
+    if ((i64)f.R[0] * f.TP[0] > (f.shared ? 512 : 128) || (i64)f.R[1] * f.TP[1] > 128) return false;
     if ((i64)f.R[0] * f.TP[0] * es < 64 && (i64)f.R[1] * f.TP[1] * es < 64) return false;  // nothing gained over the generic kernel
     if (ntiles() > 0x7fffffffLL) return false;
     // offsets on the other side of the leading index r of each run (mixed radix over the group dims in this side's stride order)
@@ -1500,7 +1510,8 @@ void describe(Plan& plan) {
         n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.list.size());
     } else if (plan.family == FAM_FLAT && plan.flat2.on) {
         const Flat2Plan& f2 = plan.flat2;
-        n += std::snprintf(buf + n, sizeof buf - n, " two-sided dest_run=%dx%d(d%d) input_run=%dx%d(d%d)", f2.R[0], f2.TP[0], f2.p[0], f2.R[1], f2.TP[1], f2.p[1]);
+        n += std::snprintf(buf + n, sizeof buf - n, " two-sided dest_run=%dx%d(d%d) input_run=%dx%d(d%d)%s", f2.R[0], f2.TP[0], f2.p[0], f2.R[1], f2.TP[1], f2.p[1],
+                           f2.shared ? " shared-dim" : "");
     } else if (plan.family == FAM_FLAT) {
         const FlatPlan& fp = plan.flat;
         n += std::snprintf(buf + n, sizeof buf - n, " flat_side=%s run=%dx%d(d%d)%s line=d%d:%d", fp.dir == 0 ? "dest" : "input", fp.R, 1 << fp.tplog, fp.p,
