@@ -165,6 +165,7 @@ struct OrbitPlan {
 struct FlatPlan {
     int dir = 0, R = 1, tplog = 0, tqlog = 5;
     int p = -1, q = -1;
+    int kt = 1;  // the input with the other layout; every other input has the destination's strides
     bool lshare = false;  // the line side is unit-stride along the SAME lead and continues along q (a transposition of R-element groups)
     bool fuse = false;  // the flat side's run continues along q itself (planar <-> interleaved): the R x TQ tile is one run
     bool ingroup[MAXN] = {false, false, false, false, false, false, false, false};
@@ -176,6 +177,7 @@ struct FlatPlan {
 // x a tile TP of the next contiguous dim p; the two runs share no dim.
 struct Flat2Plan {
     bool on = false;
+    int kt = 1;  // the input with the other layout (side 1); every other input has the destination's strides
     bool shared = false;  // the input's run would continue along p[0] as well: phase 1 walks the destination run tile-index-major
     int R[2] = {1, 1}, TP[2] = {1, 1}, p[2] = {-1, -1};
     bool ingroup[2][MAXN] = {{false, false, false, false, false, false, false, false}, {false, false, false, false, false, false, false, false}};

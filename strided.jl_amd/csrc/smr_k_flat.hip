@@ -28,6 +28,8 @@ struct FlatArgs {
     int32_t N, dir, R, TPlog, TQ, L;      // L = R << TPlog; TQ: tile of the line side (a vector multiple, not necessarily a power of two)
     int32_t p, q;                         // tiled group dim of the flat side (-1: none), unit axis of the line side
     int32_t nouter, conjv;                // dims handled by the block index besides p and q; conjv: any conj flag set
+    int32_t nin, kt;                      // inputs of f; kt: the ONE input with the other layout (crosses LDS) -- every other input has the
+                                          // destination's strides and is read in phase 2 at the destination's offsets
     int32_t fuse, lshare;                  // fuse: the flat side continues along q itself (stride of q = R): the whole R x TQ tile is ONE run;
                                           // lshare: the LINE side is unit-stride along the shared lead and continues along q (stride R): a
                                           // transposition of R-element groups ((3,W,H) -> (3,H,W)); its rows are runs of R * TQ elements
@@ -48,6 +50,40 @@ struct alignas(sizeof(T) * V) FVec {
 
 // n / d for n < 65536, d < 65536 with magic = floor(2^32 / d) + 1
 SMR_DEV uint32_t fdiv16(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
+
+// Phase 2 of every form: V consecutive destination elements at element offset `off`.  tv[] = what the transposed input (operand kt)
+// contributed through LDS; the other inputs share the destination's layout and are loaded here, at the same offset.
+// (C .= beta .* C .+ alpha .* permutedims(A, p) -- TensorOperations' tensoradd! -- is the model case.)
+template <class T, class F, int V>
+SMR_DEV void flat_emit(const OpTab& ops, int nin_rt, int kt, bool anyconj, i64 off, const T (&tv)[V], F& f) {
+    const int nin = (F::NIN >= 0) ? F::NIN : nin_rt;
+    FVec<T, V> dv[MAXIN];
+#pragma unroll
+    for (int k = 0; k < MAXIN; ++k)
+        if (k < nin && k + 1 != kt) dv[k] = *reinterpret_cast<const FVec<T, V>*>((const T*)ops.base[k + 1] + off);
+    FVec<T, V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        T arg[MAXIN];
+#pragma unroll
+        for (int k = 0; k < MAXIN; ++k) {
+            arg[k] = T{};
+            if (k < nin) {
+                T v = (k + 1 == kt) ? tv[e] : dv[k].v[e];
+                if constexpr (tr<T>::cx) {
+                    if (anyconj && ops.conj[k + 1]) v = cj(v);
+                }
+                arg[k] = v;
+            }
+        }
+        T r = f(arg);
+        if constexpr (tr<T>::cx) {
+            if (anyconj && ops.conj[0]) r = cj(r);
+        }
+        o.v[e] = r;
+    }
+    *reinterpret_cast<FVec<T, V>*>((T*)ops.base[0] + off) = o;
+}
 
 // VL / VF: elements per access on the line / flat side (1 or 16 bytes' worth)
 template <class T, class F, int DIR, int VL, int VF>
@@ -79,11 +115,8 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
     const int nq = (int)((a.dimq - q0 < TQ) ? (a.dimq - q0) : TQ);                       // valid columns
     const i64 vp = (a.dimp - p0 < ((i64)1 << a.TPlog)) ? (a.dimp - p0) : ((i64)1 << a.TPlog);
     const int nj = (int)(vp * a.R);                                                        // valid flat run (a contiguous prefix)
-    const T* src = (const T*)a.ops.base[1];
-    T* dst = (T*)a.ops.base[0];
-    const bool cin = a.conjv && a.ops.conj[1], cout = a.conjv && a.ops.conj[0];
-    (void)cin;
-    (void)cout;
+    const T* src = (const T*)a.ops.base[a.kt];
+    const bool anyconj = a.conjv != 0;
 
     // ---- phase 1: global -> LDS[j][x] --------------------------------------------------------------------------------
     if constexpr (DIR == 0) {
@@ -146,48 +179,22 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
         if (a.fuse) {
             const int nt = a.R * nq;
             for (int t0 = (int)tid * VF; t0 < nt; t0 += 256 * VF) {
-                FVec<T, VF> o;
+                T tv[VF];
 #pragma unroll
                 for (int e = 0; e < VF; ++e) {
                     const int x = (int)fdiv16((uint32_t)(t0 + e), a.magicR), r = t0 + e - x * a.R;
-                    T arg[MAXIN];
-#pragma unroll
-                    for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
-                    T t = lds[r * PITCH + x];
-                    if constexpr (tr<T>::cx) {
-                        if (cin) t = cj(t);
-                    }
-                    arg[0] = t;
-                    T rr = f(arg);
-                    if constexpr (tr<T>::cx) {
-                        if (cout) rr = cj(rr);
-                    }
-                    o.v[e] = rr;
+                    tv[e] = lds[r * PITCH + x];
                 }
-                *reinterpret_cast<FVec<T, VF>*>(dst + bf + t0) = o;
+                flat_emit<T, F, VF>(a.ops, a.nin, a.kt, anyconj, bf + t0, tv, f);
             }
         } else
         for (int v = (int)tid; v < nvec; v += 256) {
             const int x = (int)fdiv16((uint32_t)v, a.magicLv), j = (v - x * LV) * VF;
             if (j < nj && x < nq) {
-                FVec<T, VF> o;
+                T tv[VF];
 #pragma unroll
-                for (int e = 0; e < VF; ++e) {
-                    T arg[MAXIN];
-#pragma unroll
-                    for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
-                    T t = lds[(j + e) * PITCH + x];
-                    if constexpr (tr<T>::cx) {
-                        if (cin) t = cj(t);
-                    }
-                    arg[0] = t;
-                    T r = f(arg);
-                    if constexpr (tr<T>::cx) {
-                        if (cout) r = cj(r);
-                    }
-                    o.v[e] = r;
-                }
-                *reinterpret_cast<FVec<T, VF>*>(dst + bf + (i64)x * a.sfq + j) = o;
+                for (int e = 0; e < VF; ++e) tv[e] = lds[(j + e) * PITCH + x];
+                flat_emit<T, F, VF>(a.ops, a.nin, a.kt, anyconj, bf + (i64)x * a.sfq + j, tv, f);
             }
         }
     } else {
@@ -197,25 +204,13 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
             for (int v = (int)tid; v < rowv * njp; v += 256) {
                 const int jp = (int)fdiv16((uint32_t)v, a.magicRow), t0 = (v - jp * rowv) * VL;
                 if (t0 < nt) {
-                    FVec<T, VL> o;
+                    T tv[VL];
 #pragma unroll
                     for (int e = 0; e < VL; ++e) {
                         const int x = (int)fdiv16((uint32_t)(t0 + e), a.magicR), r = t0 + e - x * a.R;
-                        T arg[MAXIN];
-#pragma unroll
-                        for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
-                        T t = lds[(r + a.R * jp) * PITCH + x];
-                        if constexpr (tr<T>::cx) {
-                            if (cin) t = cj(t);
-                        }
-                        arg[0] = t;
-                        T rr = f(arg);
-                        if constexpr (tr<T>::cx) {
-                            if (cout) rr = cj(rr);
-                        }
-                        o.v[e] = rr;
+                        tv[e] = lds[(r + a.R * jp) * PITCH + x];
                     }
-                    *reinterpret_cast<FVec<T, VL>*>(dst + bl + (i64)jp * a.slp + t0) = o;
+                    flat_emit<T, F, VL>(a.ops, a.nin, a.kt, anyconj, bl + (i64)jp * a.slp + t0, tv, f);
                 }
             }
         } else
@@ -224,24 +219,10 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
             if (j < nj && x < nq) {
                 const uint32_t jp = fdiv16((uint32_t)j, a.magicR);
                 const int r = j - (int)jp * a.R;
-                FVec<T, VL> o;
+                T tv[VL];
 #pragma unroll
-                for (int e = 0; e < VL; ++e) {
-                    T arg[MAXIN];
-#pragma unroll
-                    for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
-                    T t = lds[j * PITCH + x + e];
-                    if constexpr (tr<T>::cx) {
-                        if (cin) t = cj(t);
-                    }
-                    arg[0] = t;
-                    T rr = f(arg);
-                    if constexpr (tr<T>::cx) {
-                        if (cout) rr = cj(rr);
-                    }
-                    o.v[e] = rr;
-                }
-                *reinterpret_cast<FVec<T, VL>*>(dst + bl + a.roff[r] + (i64)jp * a.slp + x) = o;
+                for (int e = 0; e < VL; ++e) tv[e] = lds[j * PITCH + x + e];
+                flat_emit<T, F, VL>(a.ops, a.nin, a.kt, anyconj, bl + a.roff[r] + (i64)jp * a.slp + x, tv, f);
             }
         }
     }
@@ -256,6 +237,7 @@ struct Flat2Args {
     OpTab ops;
     int32_t R[2], TP[2], L[2];
     int32_t nouter, conjv;
+    int32_t nin, kt;                      // as in FlatArgs
     int32_t shared;                       // the input would continue along p[0] too (stride R[1]): phase 1 walks the destination run tile-index-major
     uint32_t magicTP0;
     uint32_t ntp[2];                      // tiles along p[0] / p[1]
@@ -290,11 +272,8 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
     const int n0 = (int)(((a.dimp[0] - p0 < a.TP[0]) ? (a.dimp[0] - p0) : a.TP[0]) * a.R[0]);  // valid prefix of the destination run
     const int n1 = (int)(((a.dimp[1] - p1 < a.TP[1]) ? (a.dimp[1] - p1) : a.TP[1]) * a.R[1]);  // ... of the input run
     const int L0 = a.L[0], L1 = a.L[1], PITCH = L0 | 1;
-    const T* src = (const T*)a.ops.base[1];
-    T* dst = (T*)a.ops.base[0];
-    const bool cin = a.conjv && a.ops.conj[1], cout = a.conjv && a.ops.conj[0];
-    (void)cin;
-    (void)cout;
+    const T* src = (const T*)a.ops.base[a.kt];
+    const bool anyconj = a.conjv != 0;
     // the other side's offset of every position of the two runs, once per workgroup (the loops below then cost one LDS read per
     // element instead of two multiply-highs and a table load from the kernel arguments)
     // Phase 1 visits the destination run in the order x' -> column xcol[x']: the identity, or -- `shared`: both sides continue
@@ -342,19 +321,8 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
         int y = (int)fdiv16(tid, a.magicL[0]), x = (int)tid - y * L0;
         while (y < n1) {
             if (x < n0) {
-                T arg[MAXIN];
-#pragma unroll
-                for (int k = 0; k < MAXIN; ++k) arg[k] = T{};
-                T t = lds[y * PITCH + x];
-                if constexpr (tr<T>::cx) {
-                    if (cin) t = cj(t);
-                }
-                arg[0] = t;
-                T rr = f(arg);
-                if constexpr (tr<T>::cx) {
-                    if (cout) rr = cj(rr);
-                }
-                dst[bd + x + offd[y]] = rr;
+                const T tv[1] = {lds[y * PITCH + x]};
+                flat_emit<T, F, 1>(a.ops, a.nin, a.kt, anyconj, bd + x + offd[y], tv, f);
             }
             y += dy;
             x += dx;
@@ -389,19 +357,22 @@ static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         a.TP[t] = fp.TP[t];
         a.L[t] = fp.R[t] * fp.TP[t];
         a.dimp[t] = fp.p[t] >= 0 ? c.dims[fp.p[t]] : 1;
-        a.spo[t] = fp.p[t] >= 0 ? c.strides[1 - t][fp.p[t]] : 0;
+        a.spo[t] = fp.p[t] >= 0 ? c.strides[t == 0 ? fp.kt : 0][fp.p[t]] : 0;
         a.ntp[t] = (unsigned)((a.dimp[t] + fp.TP[t] - 1) / fp.TP[t]);
         a.magicR[t] = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.R[t] + 1);
         a.magicL[t] = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.L[t] + 1);
         for (int r = 0; r < fp.R[t]; ++r) a.roff[t][r] = fp.roff[t][r];
         blocks *= a.ntp[t];
     }
-    a.conjv = (c.conj[0] || c.conj[1]) ? 1 : 0;
+    a.nin = c.M - 1;
+    a.kt = fp.kt;
+    for (int k = 0; k < c.M; ++k)
+        if (c.conj[k]) a.conjv = 1;
     for (int d = 0; d < c.N; ++d) {
         if (d == fp.p[0] || d == fp.p[1] || fp.ingroup[0][d] || fp.ingroup[1][d]) continue;
         a.oext[a.nouter] = c.dims[d];
         a.os0[a.nouter] = c.strides[0][d];
-        a.os1[a.nouter] = c.strides[1][d];
+        a.os1[a.nouter] = c.strides[fp.kt][d];
         blocks *= c.dims[d];
         ++a.nouter;
     }
@@ -478,7 +449,9 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.TQ = TQ;
     a.p = fp.p;
     a.q = fp.q;
-    const int kf = fp.dir == 0 ? 0 : 1, kl = 1 - kf;  // operand index of the flat / line side
+    const int kf = fp.dir == 0 ? 0 : fp.kt, kl = fp.dir == 0 ? fp.kt : 0;  // operand index of the flat / line side
+    a.nin = c.M - 1;
+    a.kt = fp.kt;
     a.dimp = fp.p >= 0 ? c.dims[fp.p] : 1;
     a.dimq = c.dims[fp.q];
     a.sfq = c.strides[kf][fp.q];
@@ -486,7 +459,9 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.slp = fp.p >= 0 ? c.strides[kl][fp.p] : 0;
     a.ntp = (unsigned)((a.dimp + ((i64)1 << fp.tplog) - 1) >> fp.tplog);
     a.ntq = (unsigned)((a.dimq + TQ - 1) / TQ);
-    a.conjv = (c.conj[0] || c.conj[1]) ? 1 : 0;
+    a.conjv = 0;
+    for (int k = 0; k < c.M; ++k)
+        if (c.conj[k]) a.conjv = 1;
     a.fuse = fp.fuse ? 1 : 0;
     a.lshare = fp.lshare ? 1 : 0;
     for (int r = 0; r < fp.R; ++r) a.roff[r] = fp.roff[r];
@@ -525,6 +500,9 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         for (int d = 0; d < c.N; ++d)
             if (!fp.ingroup[d] && d != fp.p && c.strides[kf][d] % VMAX) vf = 1;
     }
+    // inputs that share the destination's layout are read with the destination's vector width
+    for (int k = 1; k < c.M; ++k)
+        if (k != fp.kt && !aligned(k)) (fp.dir == 0 ? vf : vl) = 1;
     a.magicR = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)fp.R + 1);
     a.magicRow = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)((fp.R * TQ) / vl) + 1);
     a.magicXV = (TQ / vl) > 1 ? (uint32_t)(((uint64_t)1 << 32) / (uint32_t)(TQ / vl) + 1) : 0u;
@@ -561,15 +539,9 @@ int launch_flat_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t
         return set_error(SMR_EINVAL, "bitcopy is dispatched through the f32 object");
 #endif
     }
-    switch (c.fkind) {
-        case FK_IDENT: return two ? go2<T, FIdent<T>>(plan, bases, s, FIdent<T>{}) : go<T, FIdent<T>>(plan, bases, s, FIdent<T>{});
-        case FK_SCALE:
-            return two ? go2<T, FScale<T>>(plan, bases, s, FScale<T>{hostmk<T>(c.fc[0], c.fc[1])})
-                       : go<T, FScale<T>>(plan, bases, s, FScale<T>{hostmk<T>(c.fc[0], c.fc[1])});
-        default: break;
-    }
-    if (two) return with_prog<T>(c, [&](auto f) { return go2<T, decltype(f)>(plan, bases, s, f); });
-    return with_prog<T>(c, [&](auto f) { return go<T, decltype(f)>(plan, bases, s, f); });
+    const unsigned mask = fbit(FK_IDENT) | fbit(FK_SCALE) | fbit(FK_ADD2) | fbit(FK_AXPY) | fbit(FK_AXPBY);
+    if (two) return with_functor<T>(c, mask, [&](auto f) { return go2<T, decltype(f)>(plan, bases, s, f); });
+    return with_functor<T>(c, mask, [&](auto f) { return go<T, decltype(f)>(plan, bases, s, f); });
 }
 #endif  // !SMR_JIT
 

@@ -1037,8 +1037,23 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
 // A unary transposing map in which one side's memory run consists of short leading dims with extents that are not powers of
 // two (an image's 3 channels, a physical index of 3 in a tensor network): smr_k_flat.hip addresses that side through the
 // flattened run.  side = 0: the destination is flat, 1: the input.
+// The FLAT forms take ONE input with a layout of its own (it crosses LDS); any further input must have exactly the destination's
+// strides (C .= beta .* C .+ alpha .* permutedims(A, p)).  Returns that input's operand index, or -1.
+static int flat_transposed_input(const Canon& c) {
+    int kt = -1;
+    for (int k = 1; k < c.M; ++k) {
+        bool same = true;
+        for (int d = 0; d < c.N; ++d)
+            if (c.strides[k][d] != c.strides[0][d]) same = false;
+        if (same) continue;
+        if (kt >= 0) return -1;
+        kt = k;
+    }
+    return kt;
+}
+
 static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
-    const int kf = side == 0 ? 0 : 1, kl = 1 - kf;
+    const int kf = side == 0 ? 0 : f.kt, kl = side == 0 ? f.kt : 0;
     const i64* sf = c.strides[kf];
     const i64* sl = c.strides[kl];
     // leading dim of the flat side
@@ -1121,11 +1136,11 @@ static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
 
 static bool plan_flat(const Canon& c, FlatPlan& f) {
     const Options& o = options();
-    if (!o.flat || c.redop != SMR_RED_NONE || c.M != 2 || c.mixed || c.N < 2) return false;
+    if (!o.flat || c.redop != SMR_RED_NONE || c.M < 2 || c.mixed || c.N < 2) return false;
     const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
     if (es < 4) return false;
-    if (c.prog.len > 0) {  // unary f: every ARG is input 1 (M == 2 guarantees it)
-    }
+    f.kt = flat_transposed_input(c);
+    if (f.kt < 0) return false;
     if (c.total < 65536) return false;  // small boxes: generic / tiled are fine and launch-bound anyway
     for (int d = 0; d < c.N; ++d)
         if (c.strides[0][d] <= 0) return false;
@@ -1139,14 +1154,17 @@ static bool plan_flat(const Canon& c, FlatPlan& f) {
 static bool plan_flat2(const Canon& c, Flat2Plan& f) {
     const Options& o = options();
     f.on = false;
-    if (!o.flat2 || !o.flat || c.redop != SMR_RED_NONE || c.M != 2 || c.mixed || c.N < 2) return false;
+    if (!o.flat2 || !o.flat || c.redop != SMR_RED_NONE || c.M < 2 || c.mixed || c.N < 2) return false;
     const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
     if (es < 4 || c.total < 65536) return false;
+    f.kt = flat_transposed_input(c);
+    if (f.kt < 0) return false;
+    const i64* st[2] = {c.strides[0], c.strides[f.kt]};  // side 0 = destination, side 1 = the transposed input
     int lead[2] = {-1, -1};
     for (int s = 0; s < 2; ++s)
         for (int d = 0; d < c.N; ++d) {
-            if (c.strides[s][d] <= 0) return false;
-            if (c.strides[s][d] == 1 && c.dims[d] > 1) lead[s] = d;
+            if (st[s][d] <= 0) return false;
+            if (st[s][d] == 1 && c.dims[d] > 1) lead[s] = d;
         }
     if (lead[0] < 0 || lead[1] < 0 || lead[0] == lead[1]) return false;
     bool awkward = false;
@@ -1168,7 +1186,7 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
         for (;;) {
             int nxt = -1;
             for (int d = 0; d < c.N; ++d)
-                if (!used[d] && c.strides[s][d] == R && c.dims[d] > 1) nxt = d;
+                if (!used[d] && st[s][d] == R && c.dims[d] > 1) nxt = d;
             if (nxt < 0) break;
             used[nxt] = true;
             if (R * c.dims[nxt] <= 64 && R * c.dims[nxt] * es <= target) {
@@ -1188,7 +1206,7 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
     }
     // both sides continue along the same dim behind their leads ((5,N,7) -> (7,N,5)): the destination got it; the input's run is
     // its lead alone, but input memory is still walked contiguously (Flat2Plan::shared)
-    f.shared = f.p[1] < 0 && f.p[0] >= 0 && c.strides[1][f.p[0]] == f.R[1] && f.TP[0] > 1;
+    f.shared = f.p[1] < 0 && f.p[0] >= 0 && st[1][f.p[0]] == f.R[1] && f.TP[0] > 1;
     if (f.shared) {  // the tile is R[0] x TP[0] x R[1]: a longer tile along the shared dim (16 KiB, at most 512 positions of the destination run)
         const i64 dimp = c.dims[f.p[0]];
         i64 tp = std::max<i64>(1, std::min<i64>(std::min<i64>(512 / f.R[0], 16384 / ((i64)f.R[0] * f.R[1] * es)), dimp));
@@ -1223,11 +1241,11 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
         std::vector<int> order;
         for (int d = 0; d < c.N; ++d)
             if (f.ingroup[s][d]) order.push_back(d);
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return c.strides[s][x] < c.strides[s][y]; });
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return st[s][x] < st[s][y]; });
         for (i64 r = 0; r < f.R[s]; ++r) {
             i64 rem = r, off = 0;
             for (int d : order) {
-                off += (rem % c.dims[d]) * c.strides[1 - s][d];
+                off += (rem % c.dims[d]) * st[1 - s][d];
                 rem /= c.dims[d];
             }
             if (off > 2147483647LL) return false;

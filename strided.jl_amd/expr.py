@@ -28,6 +28,10 @@ _NARY_FOLD = {"add", "mul", "min", "max"}  # Julia's +(a,b,c,d) folds left: ((a+
 class _OpsMixin:
     """Operator overloading shared by Expr (map! closures) and Broadcasted (dot-fusion)."""
 
+    # NumPy scalars on the LEFT (`np.float32(0.5) * a`) must reach __rmul__ & co. as they are: without this NumPy converts the
+    # scalar to a Python float first and a Float32 literal would silently become a Float64 one (and widen the whole call)
+    __array_ufunc__ = None
+
     @classmethod
     def _make(cls, op, *args):  # overridden
         raise NotImplementedError

@@ -443,6 +443,19 @@ def test_planner_rules_for_short_dims_big_transposes_and_short_reductions():
         assert "family=tiled" in perm((5, 300, 300, 7), (3, 2, 1, 0))
     finally:
         S.set_option("flat2", 1)
+    # n-ary maps: ONE input with the other layout, the rest laid out like the destination (tensoradd!: C .= beta .* C .+ alpha .* permutedims(A, p))
+    cA, cC, cC2 = (S.StridedView(np.zeros(sh, dtype=np.float64, order="F")) for sh in ((640, 480, 3), (3, 480, 640), (3, 480, 640)))
+    d = S.make_plan(lambda c, a: 0.5 * c + 2.0 * a, None, None, cC.size, (cC, cC, cA.permutedims((2, 1, 0)))).describe()
+    assert "family=flat" in d and "f=axpby" in d and "M=3" in d, d
+    d = S.make_plan(lambda c, a, e: c + a * e, None, None, cC.size, (cC, cC, cA.permutedims((2, 1, 0)), cC2)).describe()
+    assert "family=flat" in d and "M=4" in d, d
+    tA = S.StridedView(np.zeros((5, 60, 50, 7), dtype=np.float64, order="F"))
+    tC = S.StridedView(np.zeros((7, 50, 60, 5), dtype=np.float64, order="F"))
+    d = S.make_plan(lambda c, a: c + a, None, None, tC.size, (tC, tC, tA.permutedims((3, 2, 1, 0)))).describe()
+    assert "two-sided" in d and "M=3" in d, d
+    # two inputs with layouts of their own: not this family
+    d = S.make_plan(lambda a, b: a + b, None, None, cC.size, (cC, cA.permutedims((2, 1, 0)), S.StridedView(np.zeros((480, 3, 640), order="F")).permutedims((1, 0, 2)))).describe()
+    assert "family=flat" not in d, d
     # HBM-sized transposes of 8-/16-byte elements: 128 x 32 tiles on 1024 lanes; Float32 and smaller problems: 32 x 32
     assert "tile=d0:128,d1:32" in perm((8192, 8192), (1, 0)) and "threads=1024" in perm((8192, 8192), (1, 0))
     assert "tile=d0:32,d1:32" in perm((8192, 8192), (1, 0), np.float32)

@@ -101,14 +101,16 @@ def recipe(name, seed, T):
         # round 3: unary transposing maps whose flat side has short leading dims with extents that are not powers of two
         # (destination or input flat, ragged tiles along p and q, outer dims, a sub-box offset, conj views, scalar / jit f)
         UN = [(lambda a: a, 1, True), (lambda a: a * 2.5, 1, True), (lambda a: fn.abs2(a) + 1, 1, True), (lambda a: a * a - a / 3, 1, True),
-              (lambda a: fn.conj(a) * 3, 1, True)]
+              (lambda a: fn.conj(a) * 3, 1, True), (lambda a, b: a + b, 2, True), (lambda a, b: 2 * a + 3 * b, 2, True), (lambda a, b, c: a * b - c, 3, True)]
         f, nin, exact = UN[int(rng0.integers(0, len(UN)))]
         dims = pick([(3, 480, 640), (3, 100, 70, 5), (5, 33, 200), (10, 3, 100, 3, 10), (6, 50, 41, 9), (3, 64, 1000), (7, 7, 300), (12, 40, 130)])
         mkview = None
     elif name == "flat2":
         # round 3: both sides' unit-stride dims are short and not powers of two (two-sided FLAT form); the input's leading dim is drawn
         # among the box dims, so one-sided FLAT, TILED and STREAM plans are mixed in
-        UN = [(lambda a: a, 1, True), (lambda a: a * 2.5, 1, True), (lambda a: fn.abs2(a) + 1, 1, True), (lambda a: fn.conj(a) * 3, 1, True)]
+        UN = [(lambda a: a, 1, True), (lambda a: a * 2.5, 1, True), (lambda a: fn.abs2(a) + 1, 1, True), (lambda a: fn.conj(a) * 3, 1, True),
+              (lambda a, b: a + b, 2, True), (lambda a, b: a * 2.5 + b, 2, True), (lambda a, b: 3 * a - b * 0.5, 2, True),
+              (lambda a, b, c: a + b * c, 3, True)]   # n-ary: ONE input has the other layout, the rest the destination's
         f, nin, exact = UN[int(rng0.integers(0, len(UN)))]
         dims = pick([(5, 60, 50, 7), (17, 9, 33, 31), (3, 100, 90, 3), (7, 30, 40, 9), (6, 16, 16, 16, 5), (12, 10, 14, 9, 11), (10, 50, 60, 10), (31, 65, 33, 17)])
         coin[2] = len(dims) - 2 if coin[4] % 3 else coin[2]   # two times in three the LAST box dim leads the input
@@ -160,13 +162,18 @@ def recipe(name, seed, T):
         rng = np.random.default_rng(vseed)
         data = _data(rng, T)
         if name == "flat2":
-            ins = [_flat_line_view(mk, data, dims, coin)]
+            kt = coin[5] % nin       # which input has the other layout; the rest are dense like the destination
+            ins = [_flat_line_view(mk, data, dims, coin) if k == kt else mk(data(dims)) for k in range(nin)]
             if np.issubdtype(np.dtype(T), np.complexfloating) and coin[1] % 3 == 0:
-                ins = [ins[0].conj()]
+                ins[coin[6] % nin] = ins[coin[6] % nin].conj()
         elif name == "flat":
-            ins = [_flat_line_view(mk, data, dims, coin) if coin[0] % 2 else mk(data(dims))]
+            kt = coin[5] % nin
+            if coin[0] % 2:          # the transposed input is the line side, destination and the other inputs dense in box order
+                ins = [_flat_line_view(mk, data, dims, coin) if k == kt else mk(data(dims)) for k in range(nin)]
+            else:                    # destination (and the inputs that share its layout) = the line side, the odd input dense
+                ins = [mk(data(dims)) if k == kt else _flat_line_view(mk, data, dims, coin) for k in range(nin)]
             if np.issubdtype(np.dtype(T), np.complexfloating) and coin[1] % 3 == 0:
-                ins = [ins[0].conj()]
+                ins[coin[6] % nin] = ins[coin[6] % nin].conj()
         elif name in ("tiled_big", "tiled_blocks"):
             ins = [mk(data(dims)).permutedims(tuple((d + k) % N for d in range(N))) if len(set(dims)) == 1
                    else _perm_view(rng, mk, data, dims) for k in range(nin)]
@@ -226,7 +233,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
         oraclelib.mapreduce(p, 4)
         return arrays[0]
 
-    n = {"reduce_short": 40, "flat2": 40, "tiled_big": 40, "tiled_blocks": 30, "flat": 50, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
+    n = {"reduce_short": 40, "flat2": 60, "tiled_big": 40, "tiled_blocks": 30, "flat": 70, "generic": 110, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:

@@ -248,3 +248,22 @@ def test_fprog_cache_never_serves_a_stale_program():
     fn = S.fn
     assert MR._closure_key(lambda x: x * fn.exp(-2 * x)) is not None
     assert MR._closure_key(lambda x: (lambda y: y * _SCALE_FOR_TEST)(x)) is None  # noqa: F821
+
+
+def test_numpy_scalar_on_the_left_keeps_its_type():
+    """`Float32(0.5) .* A` is a Float32 product in the reference (Julia types every operation of the fused expression); a NumPy scalar
+    on the LEFT of a traced argument must not decay to a Python float (= Float64) on its way into the f-program: NumPy does that
+    conversion before calling __rmul__ unless the class opts out of the ufunc protocol."""
+    import strided_jl_amd.expr as E
+    h = np.float32(0.5)
+    for e in (h * E.Arg(1), E.Arg(1) * h, h + E.Arg(1), h - E.Arg(1), h / E.Arg(1)):
+        consts = [a for a in e.args if isinstance(a, E.Const)]
+        assert len(consts) == 1 and consts[0].dtype == np.dtype(np.float32), e
+    a = S.StridedView(np.zeros((640, 480, 3), dtype=np.float32, order="F"))
+    c = S.StridedView(np.zeros((3, 480, 640), dtype=np.float32, order="F"))
+    w = np.float32(2.0)
+    d = S.make_plan(lambda x, y: h * x + w * y, None, None, c.size, (c, c, a.permutedims((2, 1, 0)))).describe()
+    assert "ct=f32 " in d and "(mixed)" not in d, d
+    # ... while a Python float IS a Float64 literal and widens the call, as in Julia
+    d = S.make_plan(lambda x, y: 0.5 * x + 2.0 * y, None, None, c.size, (c, c, a.permutedims((2, 1, 0)))).describe()
+    assert "ct=f64(mixed)" in d, d
