@@ -1267,7 +1267,9 @@ int make_plan(const smr_problem* p, Plan& plan) {
     // FLAT: the one-sided form first -- unless its line side is under 8 elements long, where the two-sided form's bigger tiles win
     // (ComplexF64 (6,64,64,64,5) reversed 94 -> 40 us, (4,300,300,3) 16.5 -> 7.6; with 24-element lines the one-sided form's
     // vector accesses are 1.5x ahead; profiles/r03_flat2_ab.txt).  flat2 = 2: the two-sided form wherever it applies (experiments)
-    const bool flat_ok = c.redop == SMR_RED_NONE && o.force_family == 0;
+    bool flat_ok = c.redop == SMR_RED_NONE && o.force_family == 0;
+    // several inputs that are permuted views of ONE buffer: the orbit kernel reads the buffer once, the n-ary FLAT forms would read it per view
+    if (flat_ok && c.M > 2 && plan_orbit(c, plan.orbit)) flat_ok = false;
     const bool one = flat_ok && plan_flat(c, plan.flat);
     const bool two_first = flat_ok && (o.flat2 >= 2 || !one || (!plan.flat.fuse && !plan.flat.lshare && c.dims[plan.flat.q] < 8));
     if (two_first && plan_flat2(c, plan.flat2)) {

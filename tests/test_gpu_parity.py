@@ -137,7 +137,10 @@ def test_aliased_permuted_inputs_with_orbit_tile_order(shape, T):
             B.assign(e)
             plan = S.make_plan((lambda *xs: sum(xs[1:], xs[0])), None, None, B.size, (B, *views))
             d = plan.describe()
-            if orbit == 0:
+            if orbit == 0 and shape == (33, 65, 33) and np.dtype(T).itemsize < 16:
+                # round 3: one input laid out like the destination + one transposed, unit-stride dims of 33 elements: n-ary two-sided FLAT
+                assert "family=flat" in d and "two-sided" in d, d
+            elif orbit == 0:
                 assert "family=tiled" in d
                 assert ("order=orbits" in d) == (order == 1 and bool(plan.tile_order()))
             else:
