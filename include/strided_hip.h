@@ -233,6 +233,15 @@ int64_t smr_plan_algorithmic_bytes(const smr_plan* plan);
  * min(n, cap) entries: out[b] = linear tile id executed by workgroup b, 0xffffffff = idle
  * padding.  Workgroup b runs on XCD b mod 8.                                              */
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap);
+/* Introspection of the two-sided FLAT form (no reference counterpart): the two memory runs a tile is the product of, for the
+ * planner tests (tests/test_abi.py walks every tile with these numbers on the CPU and checks that each element of the box is
+ * moved exactly once, from the right place to the right place).  Returns the number of values the description has -- 0 when the
+ * plan is of another kind -- and writes min(that, cap) of them:
+ *   [0] kt (operand index of the transposed input)   [1] shared   [2] N (canonical rank)
+ *   [3..4] R[0], R[1]   [5..6] TP[0], TP[1]   [7..8] p[0], p[1] (-1: none)
+ *   then N dims, N destination strides, N strides of operand kt, N flags ingroup[0], N flags ingroup[1],
+ *   R[0] offsets roff[0][r], R[1] offsets roff[1][r]      (side 0 = destination, 1 = operand kt; canonical dim order) */
+int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap);
 
 /* Runtime compilation.  An `f` without a natively compiled functor is specialised the way
  * Julia specialises the reference's @generated kernel per closure (src/mapreduce.jl:229-425):

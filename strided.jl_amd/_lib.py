@@ -74,7 +74,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option",
 ]
@@ -138,6 +138,8 @@ def load():
     lib.smr_mapreduce_scalar.argtypes = [C.c_void_p, C.c_void_p]
     lib.smr_plan_tile_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t]
     lib.smr_plan_tile_order.restype = C.c_int64
+    lib.smr_plan_flat_runs.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_size_t]
+    lib.smr_plan_flat_runs.restype = C.c_int64
     lib.smr_shard.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.POINTER(smr_problem),
                               C.POINTER(C.c_int)]
     lib.smr_shard_ex.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.c_uint32, C.POINTER(smr_problem),
@@ -219,6 +221,25 @@ class Plan:
         buf = (C.c_uint32 * n)()
         self._lib.smr_plan_tile_order(self._h, buf, n)
         return list(buf)
+
+    def flat_runs(self):
+        """The two-sided FLAT form's runs as a dict (None for any other plan); layout: include/strided_hip.h."""
+        n = int(self._lib.smr_plan_flat_runs(self._h, None, 0))
+        if n == 0:
+            return None
+        buf = (C.c_int64 * n)()
+        self._lib.smr_plan_flat_runs(self._h, buf, n)
+        v = list(buf)
+        N = v[2]
+        o = 9
+        out = dict(kt=v[0], shared=bool(v[1]), N=N, R=v[3:5], TP=v[5:7], p=v[7:9])
+        for name in ("dims", "s0", "s1", "in0", "in1"):
+            out[name] = v[o:o + N]
+            o += N
+        out["roff0"] = v[o:o + out["R"][0]]
+        o += out["R"][0]
+        out["roff1"] = v[o:o + out["R"][1]]
+        return out
 
     @property
     def algorithmic_bytes(self) -> int:

@@ -378,6 +378,23 @@ int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
     return (int64_t)ord.size();
 }
 
+int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap) {
+    if (!plan || plan->plan.family != FAM_FLAT || !plan->plan.flat2.on) return 0;
+    const Canon& c = plan->plan.c;
+    const Flat2Plan& f = plan->plan.flat2;
+    std::vector<int64_t> v = {f.kt, f.shared ? 1 : 0, c.N, f.R[0], f.R[1], f.TP[0], f.TP[1], f.p[0], f.p[1]};
+    for (int d = 0; d < c.N; ++d) v.push_back(c.dims[d]);
+    for (int d = 0; d < c.N; ++d) v.push_back(c.strides[0][d]);
+    for (int d = 0; d < c.N; ++d) v.push_back(c.strides[f.kt][d]);
+    for (int s = 0; s < 2; ++s)
+        for (int d = 0; d < c.N; ++d) v.push_back(f.ingroup[s][d] ? 1 : 0);
+    for (int s = 0; s < 2; ++s)
+        for (int r = 0; r < f.R[s]; ++r) v.push_back(f.roff[s][r]);
+    if (out)
+        for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return (int64_t)v.size();
+}
+
 int smr_mapreduce(const smr_problem* problem) {
     if (!problem) return set_error(SMR_EINVAL, "null problem");
     if (problem->N < 1 || problem->N > SMR_MAXN || problem->M < 1 || problem->M > SMR_MAXM)

@@ -3,6 +3,7 @@ the library loads, exports every declared symbol, validates problems with the do
 codes, plans without a device, shards with the reference's offset arithmetic, and REFUSES to
 compute without a GPU (no CPU fallback)."""
 import ctypes as C
+import itertools
 import os
 import re
 
@@ -510,3 +511,73 @@ def test_plans_of_the_baseline_configs():
     E, F_ = cm((2048, 2048), np.float32), cm((2048, 2048), np.float32)
     d = S.make_plan(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, (2048, 2048), (F_, E)).describe()  # configs[4]
     assert "family=stream" in d and "f=expr5" in d and "vec=4" in d and "N=1" in d, d
+
+
+def _walk_two_sided_flat(fr):
+    """CPU model of smr_k_flat.hip's flat2_body + its launcher: every (destination offset, input offset) pair the launch touches, tile
+    by tile, from the numbers smr_plan_flat_runs reports."""
+    dims, s0, s1 = fr["dims"], fr["s0"], fr["s1"]
+    R, TP, p = fr["R"], fr["TP"], fr["p"]
+    outer = [d for d in range(fr["N"]) if not fr["in0"][d] and not fr["in1"][d] and d not in (p[0], p[1])]
+    dimp = [dims[p[t]] if p[t] >= 0 else 1 for t in (0, 1)]
+    spo = [(s1 if t == 0 else s0)[p[t]] if p[t] >= 0 else 0 for t in (0, 1)]     # stride of p[t] on the OTHER side
+    ntp = [(dimp[t] + TP[t] - 1) // TP[t] for t in (0, 1)]
+    roff0, roff1 = np.array(fr["roff0"], dtype=np.int64), np.array(fr["roff1"], dtype=np.int64)
+    dst, src = [], []
+    for oidx in itertools.product(*[range(dims[d]) for d in outer]):
+        bd0 = sum(i * s0[d] for i, d in zip(oidx, outer))
+        bs0 = sum(i * s1[d] for i, d in zip(oidx, outer))
+        for t0 in range(ntp[0]):
+            for t1 in range(ntp[1]):
+                p0, p1 = t0 * TP[0], t1 * TP[1]
+                bd = bd0 + p0 * R[0] + p1 * spo[1]
+                bs = bs0 + p1 * R[1] + p0 * spo[0]
+                n0 = min(TP[0], dimp[0] - p0) * R[0]
+                n1 = min(TP[1], dimp[1] - p1) * R[1]
+                x = np.arange(n0, dtype=np.int64)
+                y = np.arange(n1, dtype=np.int64)
+                offs = roff0[x % R[0]] + (x // R[0]) * spo[0]       # input offset of position x of the destination run
+                offd = roff1[y % R[1]] + (y // R[1]) * spo[1]       # destination offset of position y of the input run
+                dst.append((bd + x[:, None] + offd[None, :]).ravel())
+                src.append((bs + y[None, :] + offs[:, None]).ravel())
+    return np.concatenate(dst), np.concatenate(src)
+
+
+def test_two_sided_flat_plans_move_every_element_exactly_once():
+    """Planner check without a GPU: for a spread of shapes / permutations that take the two-sided FLAT form, walk all tiles with the
+    plan's own numbers (runs, tiles, offset tables) and compare with the definition -- destination offset sum(i_d * s0_d) receives input
+    offset sum(i_d * s1_d) for every index of the box, once."""
+    rng = np.random.default_rng(2026)
+    shapes = [(5, 60, 50, 7), (17, 9, 33, 31), (3, 100, 90, 3), (7, 30, 40, 9), (6, 16, 16, 16, 5), (12, 10, 14, 9, 11), (10, 50, 60, 10), (31, 65, 33, 17),
+              (5, 3000, 7), (3, 40, 50, 3, 9), (24, 30, 30, 20), (9, 11, 700), (13, 6, 900, 2)]
+    seen = shared = ragged = 0
+    for shape in shapes:
+        n = len(shape)
+        perms = [tuple(reversed(range(n))), (n - 1,) + tuple(range(1, n - 1)) + (0,)] + [tuple(int(i) for i in rng.permutation(n)) for _ in range(6)]
+        for q in perms:
+            for dt in (np.float64, np.float32, np.complex128):
+                a = S.StridedView(np.zeros(shape, dtype=dt, order="F"))
+                b = S.StridedView(np.zeros(tuple(shape[i] for i in q), dtype=dt, order="F"))
+                plan = S.make_plan(lambda x: x, None, None, b.size, (b, a.permutedims(q)))
+                fr = plan.flat_runs()
+                if fr is None:
+                    continue
+                assert "two-sided" in plan.describe()
+                seen += 1
+                shared += fr["shared"]
+                dims = fr["dims"]
+                ragged += any(fr["p"][t] >= 0 and dims[fr["p"][t]] % fr["TP"][t] for t in (0, 1))
+                assert fr["R"][0] * fr["TP"][0] <= (512 if fr["shared"] else 128) and fr["R"][1] * fr["TP"][1] <= 128
+                # the two runs share no dim
+                g0 = {d for d in range(fr["N"]) if fr["in0"][d]} | ({fr["p"][0]} - {-1})
+                g1 = {d for d in range(fr["N"]) if fr["in1"][d]} | ({fr["p"][1]} - {-1})
+                assert not (g0 & g1), (shape, q, fr)
+                idx = np.indices(dims).reshape(len(dims), -1).astype(np.int64)
+                want_d = (idx * np.array(fr["s0"], dtype=np.int64)[:, None]).sum(0)
+                want_s = (idx * np.array(fr["s1"], dtype=np.int64)[:, None]).sum(0)
+                got_d, got_s = _walk_two_sided_flat(fr)
+                assert got_d.size == want_d.size, (shape, q, np.dtype(dt).name, fr)
+                o1, o2 = np.argsort(got_d, kind="stable"), np.argsort(want_d, kind="stable")
+                assert np.array_equal(got_d[o1], want_d[o2]), (shape, q, np.dtype(dt).name, fr)      # every destination element once
+                assert np.array_equal(got_s[o1], want_s[o2]), (shape, q, np.dtype(dt).name, fr)      # ... from the element it is the image of
+    assert seen >= 60 and shared >= 5 and ragged >= 20, (seen, shared, ragged)
