@@ -242,6 +242,11 @@ int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap);
  *   then N dims, N destination strides, N strides of operand kt, N flags ingroup[0], N flags ingroup[1],
  *   R[0] offsets roff[0][r], R[1] offsets roff[1][r]      (side 0 = destination, 1 = operand kt; canonical dim order) */
 int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap);
+/* The same for the ONE-sided FLAT forms (plain, fused, shared-lead); 0 for any other plan.  Values:
+ *   [0] dir (0: the destination is the flat side, 1: operand kt is)   [1] R   [2] tplog   [3] tqlog   [4] p   [5] q
+ *   [6] lshare   [7] fuse   [8] kt   [9] N   then N dims, N destination strides, N strides of operand kt, N flags ingroup,
+ *   R offsets roff[r] (line-side offset of leading index r of the flat run)                                                */
+int64_t smr_plan_flat_side(const smr_plan* plan, int64_t* out, size_t cap);
 
 /* Runtime compilation.  An `f` without a natively compiled functor is specialised the way
  * Julia specialises the reference's @generated kernel per closure (src/mapreduce.jl:229-425):

@@ -74,7 +74,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option",
 ]
@@ -140,6 +140,8 @@ def load():
     lib.smr_plan_tile_order.restype = C.c_int64
     lib.smr_plan_flat_runs.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_size_t]
     lib.smr_plan_flat_runs.restype = C.c_int64
+    lib.smr_plan_flat_side.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_size_t]
+    lib.smr_plan_flat_side.restype = C.c_int64
     lib.smr_shard.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.POINTER(smr_problem),
                               C.POINTER(C.c_int)]
     lib.smr_shard_ex.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.c_uint32, C.POINTER(smr_problem),
@@ -239,6 +241,22 @@ class Plan:
         out["roff0"] = v[o:o + out["R"][0]]
         o += out["R"][0]
         out["roff1"] = v[o:o + out["R"][1]]
+        return out
+
+    def flat_side(self):
+        """The one-sided FLAT forms' plan as a dict (None for any other plan); layout: include/strided_hip.h."""
+        n = int(self._lib.smr_plan_flat_side(self._h, None, 0))
+        if n == 0:
+            return None
+        buf = (C.c_int64 * n)()
+        self._lib.smr_plan_flat_side(self._h, buf, n)
+        v = list(buf)
+        out = dict(dir=v[0], R=v[1], tplog=v[2], tqlog=v[3], p=v[4], q=v[5], lshare=bool(v[6]), fuse=bool(v[7]), kt=v[8], N=v[9])
+        N, o = v[9], 10
+        for name in ("dims", "s0", "s1", "ingroup"):
+            out[name] = v[o:o + N]
+            o += N
+        out["roff"] = v[o:o + out["R"]]
         return out
 
     @property

@@ -395,6 +395,21 @@ int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap) {
     return (int64_t)v.size();
 }
 
+int64_t smr_plan_flat_side(const smr_plan* plan, int64_t* out, size_t cap) {
+    if (!plan || plan->plan.family != FAM_FLAT || plan->plan.flat2.on) return 0;
+    const Canon& c = plan->plan.c;
+    const FlatPlan& f = plan->plan.flat;
+    std::vector<int64_t> v = {f.dir, f.R, f.tplog, f.tqlog, f.p, f.q, f.lshare ? 1 : 0, f.fuse ? 1 : 0, f.kt, c.N};
+    for (int d = 0; d < c.N; ++d) v.push_back(c.dims[d]);
+    for (int d = 0; d < c.N; ++d) v.push_back(c.strides[0][d]);
+    for (int d = 0; d < c.N; ++d) v.push_back(c.strides[f.kt][d]);
+    for (int d = 0; d < c.N; ++d) v.push_back(f.ingroup[d] ? 1 : 0);
+    for (int r = 0; r < f.R; ++r) v.push_back(f.roff[r]);
+    if (out)
+        for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return (int64_t)v.size();
+}
+
 int smr_mapreduce(const smr_problem* problem) {
     if (!problem) return set_error(SMR_EINVAL, "null problem");
     if (problem->N < 1 || problem->N > SMR_MAXN || problem->M < 1 || problem->M > SMR_MAXM)

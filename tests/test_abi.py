@@ -2,6 +2,7 @@
 the library loads, exports every declared symbol, validates problems with the documented status
 codes, plans without a device, shards with the reference's offset arithmetic, and REFUSES to
 compute without a GPU (no CPU fallback)."""
+import collections
 import ctypes as C
 import itertools
 import os
@@ -581,3 +582,76 @@ def test_two_sided_flat_plans_move_every_element_exactly_once():
                 assert np.array_equal(got_d[o1], want_d[o2]), (shape, q, np.dtype(dt).name, fr)      # every destination element once
                 assert np.array_equal(got_s[o1], want_s[o2]), (shape, q, np.dtype(dt).name, fr)      # ... from the element it is the image of
     assert seen >= 60 and shared >= 5 and ragged >= 20, (seen, shared, ragged)
+
+
+def _walk_one_sided_flat(fs, es):
+    """CPU model of smr_k_flat.hip's flat_map_body + its launcher (plain, fused and shared-lead forms): every (destination offset,
+    offset in operand kt) pair the launch touches."""
+    dims, R, p, q = fs["dims"], fs["R"], fs["p"], fs["q"]
+    sflat, sline = (fs["s0"], fs["s1"]) if fs["dir"] == 0 else (fs["s1"], fs["s0"])
+    vmax = max(1, 16 // es)
+    TQ = 1 << fs["tqlog"]
+    nt = (dims[q] + TQ - 1) // TQ
+    TQ = (dims[q] + nt - 1) // nt
+    TQ = (TQ + vmax - 1) // vmax * vmax
+    TP = 1 << fs["tplog"]
+    dimp = dims[p] if p >= 0 else 1
+    slp = sline[p] if p >= 0 else 0
+    sfq = sflat[q]
+    ntp, ntq = (dimp + TP - 1) // TP, (dims[q] + TQ - 1) // TQ
+    outer = [d for d in range(fs["N"]) if d != p and d != q and not fs["ingroup"][d]]
+    roff = np.array(fs["roff"], dtype=np.int64)
+    fl, ln = [], []
+    for oidx in itertools.product(*[range(dims[d]) for d in outer]):
+        bf0 = sum(i * sflat[d] for i, d in zip(oidx, outer))
+        bl0 = sum(i * sline[d] for i, d in zip(oidx, outer))
+        for tp in range(ntp):
+            for tq in range(ntq):
+                q0, p0 = tq * TQ, tp * TP
+                bf = bf0 + q0 * sfq + p0 * R
+                bl = bl0 + q0 * (R if fs["lshare"] else 1) + p0 * slp
+                nq = min(TQ, dims[q] - q0)
+                nj = min(TP, dimp - p0) * R
+                j = np.arange(nj, dtype=np.int64)[:, None]
+                x = np.arange(nq, dtype=np.int64)[None, :]
+                r, jp = j % R, j // R
+                fl.append((bf + x * sfq + j).ravel())
+                if fs["lshare"]:
+                    ln.append((bl + jp * slp + x * R + r).ravel())
+                else:
+                    ln.append((bl + roff[r] + jp * slp + x).ravel())
+    fl, ln = np.concatenate(fl), np.concatenate(ln)
+    return (fl, ln) if fs["dir"] == 0 else (ln, fl)
+
+
+def test_one_sided_flat_plans_move_every_element_exactly_once():
+    """The same planner check for the one-sided FLAT forms: plain (either operand flat), fused (planar <-> interleaved) and shared-lead
+    (transposition of R-element groups), ragged tiles along both tiled dims, outer dims."""
+    rng = np.random.default_rng(7)
+    shapes = [(640, 480, 3), (3, 480, 640), (3, 100, 70, 5), (5, 33, 200), (10, 3, 100, 3, 10), (6, 50, 41, 9), (3, 64, 1000), (7, 7, 300), (12, 40, 130),
+              (3, 130, 96), (5, 1000, 30), (100, 3, 100, 3), (9, 500, 40)]
+    seen = collections.Counter()
+    for shape in shapes:
+        n = len(shape)
+        perms = {tuple(reversed(range(n))), (0,) + tuple(reversed(range(1, n))), tuple(range(1, n)) + (0,), (n - 1,) + tuple(range(n - 1))}
+        perms |= {tuple(int(i) for i in rng.permutation(n)) for _ in range(5)}
+        for qperm in sorted(perms):
+            for dt in (np.float64, np.float32, np.complex128):
+                a = S.StridedView(np.zeros(shape, dtype=dt, order="F"))
+                b = S.StridedView(np.zeros(tuple(shape[i] for i in qperm), dtype=dt, order="F"))
+                plan = S.make_plan(lambda x: x, None, None, b.size, (b, a.permutedims(qperm)))
+                fs = plan.flat_side()
+                if fs is None:
+                    continue
+                seen["fuse" if fs["fuse"] else ("lshare" if fs["lshare"] else "plain%d" % fs["dir"])] += 1
+                dims = fs["dims"]
+                idx = np.indices(dims).reshape(len(dims), -1).astype(np.int64)
+                want_d = (idx * np.array(fs["s0"], dtype=np.int64)[:, None]).sum(0)
+                want_s = (idx * np.array(fs["s1"], dtype=np.int64)[:, None]).sum(0)
+                got_d, got_s = _walk_one_sided_flat(fs, np.dtype(dt).itemsize)
+                msg = (shape, qperm, np.dtype(dt).name, plan.describe())
+                assert got_d.size == want_d.size, msg
+                o1, o2 = np.argsort(got_d, kind="stable"), np.argsort(want_d, kind="stable")
+                assert np.array_equal(got_d[o1], want_d[o2]), msg
+                assert np.array_equal(got_s[o1], want_s[o2]), msg
+    assert seen["plain0"] >= 10 and seen["plain1"] >= 10 and seen["fuse"] >= 5 and seen["lshare"] >= 3, dict(seen)
