@@ -201,6 +201,56 @@ int smr_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int smr_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int smr_stream_sync(void* stream);
 
+/* ---- overlap windows: independent launches of one stream may run concurrently -----------------
+ * The reference runs the independent halves of a problem as concurrent tasks and waits only where it
+ * must (src/mapreduce.jl:203-223).  The GPU analogue: between smr_overlap_begin(stream) and
+ * smr_overlap_end(stream) the library tracks the byte ranges its launches on `stream` read and write;
+ * a launch that conflicts with none of the launches still in flight (no read-after-write, write-after-
+ * write, write-after-read on any operand or on a plan's own partials) is dispatched without the AQL
+ * barrier bit, so its waves start while its predecessors are still running or draining (a kernel
+ * boundary costs 1.6-1.9 us on MI355X: more than a third of a 16 MiB launch); every other launch is
+ * stream-ordered as usual.  Results are those of in-order execution.  The FIRST launch after begin is
+ * always ordered (after whatever the caller queued before); end issues one ordered empty kernel when
+ * needed, so that work the caller queues afterwards -- kernels, copies, events, synchronisation -- is
+ * ordered after everything in the window.  Inside an open window the caller must not put work of its
+ * own on `stream` (or must call smr_overlap_fence(stream) first).  Windows nest; they survive stream
+ * capture into a hipGraph.  smr_stream_create returns a stream whose window is permanently open and
+ * that the library fences by itself before every copy / synchronisation it performs on it
+ * (smr_memcpy_*, smr_stream_sync, smr_mapreduce_scalar): the stream of a host (the Julia shim) that
+ * routes ALL its device work through this library.                                                  */
+int smr_overlap_begin(void* stream);
+int smr_overlap_end(void* stream);
+int smr_overlap_fence(void* stream);
+int smr_stream_create(void** out);
+int smr_stream_destroy(void* stream);
+
+/* ---- recorded sequences: the library's own replay of a list of plan executions ---------------------
+ * smr_seq_add records executions of plans (with optional rebinding of base pointers, as smr_plan_execute);
+ * smr_seq_run(seq, reps, stream) performs the recorded list `reps` times with the results of in-order
+ * execution on `stream`.  On MI355X the replay does not go through HIP's launch path: every launch
+ * becomes a pre-built AQL dispatch packet (kernel object of the code object HIP loaded, kernarg block
+ * resident in device memory) on the library's own HSA queue, and only launches that conflict with an
+ * earlier launch still in flight (read-after-write, write-after-write, write-after-read on any operand
+ * or on a plan's partials) carry the AQL barrier bit -- independent launches of a step overlap on the
+ * device (src/mapreduce.jl:203-223: spawn what is independent, wait where it must), and a replay costs
+ * ~0.1 us of host time per launch instead of HIP's 3.6-4 us.  Work queued on `stream` before the call
+ * completes first (the call waits for it on the host when the stream is busy); work queued on `stream`
+ * afterwards waits for the replay (hipStreamWaitValue64 on the completion signal); smr_seq_wait blocks
+ * the host until the last replay has completed (active wait on the signal: microseconds sooner than
+ * hipStreamSynchronize).  A sequence holding a runtime-compiled kernel or a kernel that needs scratch
+ * memory is replayed through HIP, in order (smr_seq_info tells which).  One replay per device is in
+ * flight at a time.  The recorded base pointers / plans must stay alive while the sequence exists.    */
+typedef struct smr_seq smr_seq;
+int smr_seq_create(smr_seq** out);
+int smr_seq_add(smr_seq* seq, smr_plan* plan, void* const* bases);
+int smr_seq_run(smr_seq* seq, int reps, void* stream);
+int smr_seq_wait(smr_seq* seq);
+int smr_seq_info(smr_seq* seq, char* buf, size_t buflen);
+/* experiments: "fence_scope" (acquire/release scope of the packets inside a replay: 0 none, 1 agent, 2 system),
+ * "order" (0: every packet ordered, 1: dependency-aware)                                              */
+int smr_seq_set(smr_seq* seq, const char* name, int64_t value);
+int smr_seq_destroy(smr_seq* seq);
+
 /* ---- the hot path --------------------------------------------------------------------- */
 /* One-shot replacement of _mapreduce_fuse! (src/mapreduce.jl:98): canonicalise, pick the
  * kernel family, launch on problem->stream.  Plans are cached per problem signature.    */
@@ -317,7 +367,8 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * axes: -1 auto, 0 off, n), "tile_block_xcd", "orbit_group", "orbit_minrun", "orbit_wgs".  Experiment
  * switches: "stream_u", "orbit_lds_min", "orbit_skew", "tile_block_min_axes"; "stamp_base" / "stamp_cap" / "stamp_used" (debug build
  * with device-side wall-clock stamps, csrc/smr_device.h).  Read-only counters through
- * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms".             */
+ * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms", "overlap_any" / "overlap_ordered" /
+ * "overlap_fences" (launches dispatched without / with the barrier bit inside overlap windows, fences issued).      */
 int smr_set_option(const char* name, int64_t value);
 int64_t smr_get_option(const char* name);
 

@@ -9,7 +9,7 @@ the modules here are the host-side mirror of the reference's operator interface
 (StridedView, broadcast lowering, map!/mapreduce fronts) that ends in the C ABI.
 """
 from . import _lib  # noqa: F401
-from ._lib import Plan, StridedHIPError, UnsupportedOnDevice, build, get_option, set_option  # noqa: F401
+from ._lib import Plan, Sequence, Stream, StridedHIPError, UnsupportedOnDevice, build, get_option, overlap, set_option  # noqa: F401
 from .stridedview import DimensionMismatch, StridedView, isstrided, sreshape, sview  # noqa: F401
 from . import fn  # noqa: F401
 from .broadcast import (Broadcasted, Ref, broadcast_shape, capturestridedargs, copyto_,  # noqa: F401

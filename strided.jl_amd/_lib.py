@@ -76,7 +76,8 @@ EXPORTS = [
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
     "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
-    "smr_get_option",
+    "smr_get_option", "smr_overlap_begin", "smr_overlap_end", "smr_overlap_fence", "smr_stream_create", "smr_stream_destroy",
+    "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_set", "smr_seq_destroy",
 ]
 
 
@@ -155,6 +156,18 @@ def load():
     lib.smr_set_option.argtypes = [C.c_char_p, C.c_int64]
     lib.smr_get_option.argtypes = [C.c_char_p]
     lib.smr_get_option.restype = C.c_int64
+    lib.smr_overlap_begin.argtypes = [C.c_void_p]
+    lib.smr_overlap_end.argtypes = [C.c_void_p]
+    lib.smr_overlap_fence.argtypes = [C.c_void_p]
+    lib.smr_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.smr_stream_destroy.argtypes = [C.c_void_p]
+    lib.smr_seq_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.smr_seq_add.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.smr_seq_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.smr_seq_wait.argtypes = [C.c_void_p]
+    lib.smr_seq_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.smr_seq_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.smr_seq_destroy.argtypes = [C.c_void_p]
     if lib.smr_abi_version() != 1:
         raise ImportError("libstrided_hip.so ABI version mismatch; rebuild")
     _lib = lib
@@ -176,6 +189,83 @@ def set_option(name: str, value: int):
 
 def get_option(name: str) -> int:
     return int(load().smr_get_option(name.encode()))
+
+
+class overlap:
+    """`with overlap(stream):` -- an overlap window (smr_overlap_begin / smr_overlap_end): launches issued inside on `stream`
+    that touch none of the data of the launches still in flight start without waiting for them (the GPU form of the
+    reference's spawn-what-is-independent, src/mapreduce.jl:203-223); results are those of in-order execution.  `stream` is a
+    raw hipStream_t handle (None = the null stream; with torch pass torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, stream: int | None = None):
+        self.stream = C.c_void_p(stream or 0)
+
+    def __enter__(self):
+        check(load().smr_overlap_begin(self.stream))
+        return self
+
+    def __exit__(self, *exc):
+        check(load().smr_overlap_end(self.stream))
+        return False
+
+
+class Stream:
+    """A stream made by the library (smr_stream_create): its overlap window is permanently open and the library fences it by
+    itself before every copy / synchronisation it performs on it."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(load().smr_stream_create(C.byref(h)))
+        self.handle = int(h.value)
+
+    def synchronize(self):
+        check(load().smr_stream_sync(C.c_void_p(self.handle)))
+
+    def close(self):
+        if self.handle:
+            check(load().smr_stream_destroy(C.c_void_p(self.handle)))
+            self.handle = 0
+
+
+class Sequence:
+    """smr_seq: a recorded list of plan executions, replayed by the library itself (on MI355X as pre-built AQL packets on its
+    own HSA queue; independent launches overlap on the device) with the results of in-order execution on `stream`."""
+
+    def __init__(self):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self._keep = []
+        check(self._lib.smr_seq_create(C.byref(self._h)))
+
+    def add(self, plan: "Plan", bases=None):
+        arr = None
+        if bases is not None:
+            arr = (C.c_void_p * len(bases))(*bases)
+        check(self._lib.smr_seq_add(self._h, plan._h, arr))
+        self._keep.append(plan)
+        return self
+
+    def run(self, reps: int = 1, stream: int | None = None):
+        check(self._lib.smr_seq_run(self._h, int(reps), C.c_void_p(stream or 0)))
+
+    def wait(self):
+        check(self._lib.smr_seq_wait(self._h))
+
+    def info(self) -> str:
+        buf = C.create_string_buffer(512)
+        check(self._lib.smr_seq_info(self._h, buf, 512))
+        return buf.value.decode()
+
+    def set(self, name: str, value: int):
+        check(self._lib.smr_seq_set(self._h, name.encode(), int(value)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.smr_seq_destroy(self._h)
+                self._h = None
+        except Exception:  # pragma: no cover
+            pass
 
 
 class Plan:

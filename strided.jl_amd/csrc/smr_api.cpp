@@ -44,7 +44,142 @@ int launch_reduce_part(const Plan& plan, void* const* bases, hipStream_t s) { SM
 int launch_orbit_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_orbit_map) }
 int launch_flat_map(const Plan& plan, void* const* bases, hipStream_t s) { SMR_DISPATCH_CT(launch_flat_map) }
 
+// ---- overlap window: dependency-aware launch order --------------------------------------------------------------------
+// The reference runs the independent halves of a problem as concurrent tasks and waits only where it must
+// (src/mapreduce.jl:203-223: spawn one half, run the other, wait).  On the GPU the analogous unit is the LAUNCH: a 16 MiB
+// launch here is a span of 1.6-3.2 us followed by a 1.6-1.9 us boundary (drain, write-back, next dispatch -- profiles/
+// r03_device_span.txt) that a stream-ordered successor pays even when it touches none of the predecessor's data.  Inside an
+// overlap window (smr_overlap_begin / _end, or any stream made by smr_stream_create) the library therefore keeps, per stream,
+// the byte ranges read and written by the launches that went out since the last ORDERED one; a new launch whose ranges do
+// not conflict with them (no read-after-write, write-after-write or write-after-read) is dispatched without the AQL barrier
+// bit (hipExtAnyOrderLaunch) -- its waves start while the earlier launches are still running or draining -- anything else
+// goes out in order and becomes the new window base.  Closing the window (and, on library-owned streams, every copy /
+// synchronisation the library performs) first issues one ordered empty kernel, so that "the stream's last command has
+// completed" again implies "everything before it has" for whatever follows (events, copies, hipStreamSynchronize).
+namespace {
+struct Span {
+    uintptr_t lo, hi;
+};
+struct Window {
+    int depth = 0;        // nesting of smr_overlap_begin
+    bool owned = false;   // smr_stream_create: permanently open
+    bool loose = false;   // the last launch went out without the barrier bit: a fence is due before foreign work
+    int unordered = 0;    // launches since the window base
+    std::vector<Span> reads, writes;
+};
+struct Windows {
+    std::mutex mu;
+    std::unordered_map<void*, Window> map;
+    long stat_any = 0, stat_ordered = 0, stat_fences = 0;
+};
+Windows& windows() {
+    static Windows* w = new Windows();
+    return *w;
+}
+thread_local unsigned tl_launch_flags = 0;
+constexpr int WINDOW_CAP = 32;  // launches tracked before the window is re-based by an ordered launch
+
+__global__ void k_window_fence() {}
+
+bool overlaps(const std::vector<Span>& v, const Span& x) {
+    for (const Span& y : v)
+        if (x.lo < y.hi && y.lo < x.hi) return true;
+    return false;
+}
+
+// byte ranges one execution of `plan` reads and writes (every operand's bounding range; the plan's own partials)
+void footprint(const Plan& plan, void* const* bases, std::vector<Span>& rd, std::vector<Span>& wr) {
+    const Canon& c = plan.c;
+    for (int k = 0; k < c.M; ++k) {
+        i64 lo = c.offsets[k], hi = c.offsets[k];
+        for (int d = 0; d < c.N; ++d) {
+            const i64 ext = (c.dims[d] - 1) * c.strides[k][d];
+            (ext < 0 ? lo : hi) += ext;
+        }
+        const uintptr_t b = (uintptr_t)(bases ? bases[c.orig[k]] : c.base[k]);
+        const Span sp{b + (uintptr_t)(lo * (i64)c.esize[k]), b + (uintptr_t)((hi + 1) * (i64)c.esize[k])};
+        if (k == 0) {
+            wr.push_back(sp);
+            if (c.redop != SMR_RED_NONE) rd.push_back(sp);  // reductions accumulate into the destination
+        } else {
+            rd.push_back(sp);
+        }
+    }
+    if (plan.scratch) {
+        const Span sp{(uintptr_t)plan.scratch, (uintptr_t)plan.scratch + plan.counter_off + RED_COUNTERS * sizeof(unsigned)};
+        wr.push_back(sp);
+        rd.push_back(sp);
+    }
+}
+
+// decides the ordering of the execution about to be launched on `s`
+void window_admit(const Plan& plan, void* const* bases, hipStream_t s) {
+    tl_launch_flags = 0;
+    Windows& W = windows();
+    std::lock_guard<std::mutex> g(W.mu);
+    if (W.map.empty()) return;
+    auto it = W.map.find((void*)s);
+    if (it == W.map.end() || (it->second.depth == 0 && !it->second.owned)) return;
+    Window& w = it->second;
+    std::vector<Span> rd, wr;
+    footprint(plan, bases, rd, wr);
+    bool free_ = w.unordered > 0 && w.unordered < WINDOW_CAP;
+    for (size_t i = 0; free_ && i < wr.size(); ++i) free_ = !overlaps(w.reads, wr[i]) && !overlaps(w.writes, wr[i]);
+    for (size_t i = 0; free_ && i < rd.size(); ++i) free_ = !overlaps(w.writes, rd[i]);
+    if (free_) {
+        tl_launch_flags = hipExtAnyOrderLaunch;
+        w.loose = true;
+        ++W.stat_any;
+    } else {
+        w.reads.clear();
+        w.writes.clear();
+        w.unordered = 0;
+        w.loose = false;
+        ++W.stat_ordered;
+    }
+    ++w.unordered;
+    w.reads.insert(w.reads.end(), rd.begin(), rd.end());
+    w.writes.insert(w.writes.end(), wr.begin(), wr.end());
+}
+
+// one ordered empty kernel: everything launched before it has completed when it has
+int window_fence_locked(Windows& W, Window& w, hipStream_t s) {
+    w.reads.clear();
+    w.writes.clear();
+    w.unordered = 0;
+    if (!w.loose) return SMR_OK;
+    w.loose = false;
+    ++W.stat_fences;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_window_fence, dim3(1), dim3(64), 0, s);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SMR_OK : hip_error(e, "overlap window fence");
+}
+int window_fence(hipStream_t s) {
+    Windows& W = windows();
+    std::lock_guard<std::mutex> g(W.mu);
+    auto it = W.map.find((void*)s);
+    if (it == W.map.end()) return SMR_OK;
+    return window_fence_locked(W, it->second, s);
+}
+}  // namespace
+
+unsigned take_launch_flags() {
+    const unsigned f = tl_launch_flags;
+    tl_launch_flags = 0;
+    return f;
+}
+
+static int execute_family(const Plan& plan, void* const* bases, hipStream_t s);
+
 static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
+    if (!jit_no_launch()) window_admit(plan, bases, s);
+    const int rc = execute_family(plan, bases, s);
+    tl_launch_flags = 0;  // an execution that launched nothing must not leak its flag to the next one
+    return rc;
+}
+
+static int execute_family(const Plan& plan, void* const* bases, hipStream_t s) {
     switch (plan.family) {
         case FAM_GENERIC: return launch_generic_map(plan, bases, s);
         case FAM_STREAM: return launch_stream_map(plan, bases, s);
@@ -147,6 +282,21 @@ static void plan_free(smr_plan* h) {
     delete h;
 }
 
+// ---- hooks for smr_seq.cpp (the smr_plan struct is private to this file) ------------------------------------------------
+namespace smr {
+int seq_execute_plan(smr_plan* plan, void* const* bases, hipStream_t s, bool prepare_only) {
+    if (prepare_only) return smr_plan_prepare(plan);
+    return smr_plan_execute(plan, bases, (void*)s);
+}
+void seq_footprint(smr_plan* plan, void* const* bases, std::vector<std::pair<uintptr_t, uintptr_t>>& rd, std::vector<std::pair<uintptr_t, uintptr_t>>& wr) {
+    std::vector<Span> r, w;
+    footprint(plan->plan, bases, r, w);
+    for (const Span& x : r) rd.emplace_back(x.lo, x.hi);
+    for (const Span& x : w) wr.emplace_back(x.lo, x.hi);
+}
+int seq_nops(smr_plan* plan) { return plan->nops; }
+}  // namespace smr
+
 // ---- plan cache for the one-shot entry point ---------------------------------------------------------
 // Plans are held by shared_ptr: a thread that found a plan keeps it alive while it executes, eviction only
 // drops the cache's reference (the last owner frees the device tables -- after draining the plan's stream,
@@ -158,7 +308,10 @@ struct PlanDeleter {
     void operator()(smr_plan* h) const {
         if (!h) return;
         if (h->plan.scratch || h->plan.ordtab || h->plan.lanetab[0] || h->plan.lanetab[1] || h->plan.lanetab[2] || h->plan.lanetab[3])
+        {
+            (void)window_fence((hipStream_t)h->stream);
             (void)hipStreamSynchronize((hipStream_t)h->stream);  // queued kernels may still read the tables
+        }
         plan_free(h);
     }
 };
@@ -272,16 +425,78 @@ int smr_free(void* p) {
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipFree");
 }
 int smr_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (int rc = window_fence((hipStream_t)stream)) return rc;
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipMemcpyAsync(h2d)");
 }
 int smr_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    if (int rc = window_fence((hipStream_t)stream)) return rc;
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipMemcpyAsync(d2h)");
 }
 int smr_stream_sync(void* stream) {
+    int rc = window_fence((hipStream_t)stream);
+    if (rc) return rc;
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipStreamSynchronize");
+}
+
+int smr_overlap_begin(void* stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    Windows& W = windows();
+    std::lock_guard<std::mutex> g(W.mu);
+    Window& w = W.map[stream];
+    if (w.depth++ == 0 && !w.owned) {  // the first launch of a window is always ordered (after whatever the caller queued before)
+        w.reads.clear();
+        w.writes.clear();
+        w.unordered = 0;
+        w.loose = false;
+    }
+    return SMR_OK;
+}
+
+int smr_overlap_end(void* stream) {
+    Windows& W = windows();
+    std::lock_guard<std::mutex> g(W.mu);
+    auto it = W.map.find(stream);
+    if (it == W.map.end() || it->second.depth == 0) return set_error(SMR_EINVAL, "smr_overlap_end without smr_overlap_begin on this stream");
+    Window& w = it->second;
+    if (--w.depth > 0) return SMR_OK;
+    const int rc = window_fence_locked(W, w, (hipStream_t)stream);
+    if (!w.owned) W.map.erase(it);
+    return rc;
+}
+
+int smr_overlap_fence(void* stream) { return window_fence((hipStream_t)stream); }
+
+int smr_stream_create(void** out) {
+    if (!out) return set_error(SMR_EINVAL, "null out");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) return hip_error(e, "hipStreamCreateWithFlags");
+    Windows& W = windows();
+    std::lock_guard<std::mutex> g(W.mu);
+    W.map[(void*)s].owned = true;
+    *out = (void*)s;
+    return SMR_OK;
+}
+
+int smr_stream_destroy(void* stream) {
+    if (!stream) return set_error(SMR_EINVAL, "null stream");
+    {
+        Windows& W = windows();
+        std::lock_guard<std::mutex> g(W.mu);
+        auto it = W.map.find(stream);
+        if (it == W.map.end() || !it->second.owned) return set_error(SMR_EINVAL, "smr_stream_destroy: not a stream made by smr_stream_create");
+        (void)window_fence_locked(W, it->second, (hipStream_t)stream);
+        W.map.erase(it);
+    }
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamDestroy((hipStream_t)stream);
+    return e == hipSuccess ? SMR_OK : hip_error(e, "hipStreamDestroy");
 }
 
 int smr_plan_create(const smr_problem* problem, smr_plan** out) {
@@ -343,6 +558,8 @@ int smr_mapreduce_scalar(const smr_problem* problem, void* host_result) {
     if (rc) return rc;
     const smr_operand& d = problem->ops[0];
     const size_t es = (size_t)dtype_size(d.dtype);
+    rc = window_fence((hipStream_t)problem->stream);
+    if (rc) return rc;
     hipError_t e = hipMemcpyAsync(host_result, (const char*)d.base + d.offset * (int64_t)es, es, hipMemcpyDeviceToHost,
                                   (hipStream_t)problem->stream);
     if (e != hipSuccess) return hip_error(e, "hipMemcpyAsync(scalar result)");
@@ -615,6 +832,11 @@ int64_t smr_get_option(const char* name) {
     if (n == "flat2") return o.flat2;
     if (n == "flat2_bytes") return o.flat2_bytes;
     if (n == "flat2_lead_bytes") return o.flat2_lead_bytes;
+    if (n == "overlap_any" || n == "overlap_ordered" || n == "overlap_fences") {
+        Windows& W = windows();
+        std::lock_guard<std::mutex> g(W.mu);
+        return n == "overlap_any" ? W.stat_any : (n == "overlap_ordered" ? W.stat_ordered : W.stat_fences);
+    }
     if (n == "jit_compiles") return jit_stats().compiles;
     if (n == "jit_hits") return jit_stats().hits;
     if (n == "jit_failures") return jit_stats().failures;

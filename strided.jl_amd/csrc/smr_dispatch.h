@@ -9,6 +9,8 @@
 #ifndef SMR_JIT
 #include <algorithm>
 #include <cstring>
+#include <initializer_list>
+#include <vector>
 #endif
 
 #include "smr_device.h"
@@ -117,6 +119,37 @@ inline OpTab make_optab(const Canon& c, void* const* bases) {
     }
     return t;
 }
+
+// Every kernel launch of the library goes through SMR_LAUNCH.  take_launch_flags() hands out -- ONCE, to the first launch of
+// the execution in progress -- the AQL ordering the overlap window decided on (smr_api.cpp: hipExtAnyOrderLaunch = the
+// dispatch packet goes out without the barrier bit, so its waves may start while earlier, independent launches of the
+// same stream are still draining); every later launch of the same execution (a folding pass) is ordered as usual.
+// While a sequence records (smr_seq.cpp) nothing is launched: the launch is appended to the recorder with its arguments packed the
+// way the kernarg segment holds them (every argument at its natural alignment, in order).
+template <class T> inline void pack_arg(std::vector<unsigned char>& b, const T& v) {
+    const size_t off = (b.size() + alignof(T) - 1) & ~(alignof(T) - 1);
+    b.resize(off + sizeof(T));
+    std::memcpy(b.data() + off, &v, sizeof(T));
+}
+template <class... A> inline void record_launch(std::vector<RecLaunch>* rec, const void* fn, unsigned grid, unsigned block, size_t lds, const A&... a) {
+    RecLaunch r;
+    r.hostfn = fn;
+    r.grid = grid;
+    r.block = block;
+    r.lds = (unsigned)lds;
+    (void)std::initializer_list<int>{(pack_arg(r.args, a), 0)...};
+    rec->push_back(std::move(r));
+}
+#define SMR_LAUNCH(kern, grid, block, lds, s, ...)                                                                     \
+    do {                                                                                                               \
+        if (auto* smr_rec_ = ::smr::recorder()) {                                                                      \
+            ::smr::record_launch(smr_rec_, (const void*)(kern), (grid).x, (block).x, (size_t)(lds), __VA_ARGS__);      \
+            break;                                                                                                     \
+        }                                                                                                              \
+        const unsigned smr_lf_ = ::smr::take_launch_flags();                                                           \
+        if (smr_lf_) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)(lds), s, nullptr, nullptr, smr_lf_, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                               \
+    } while (0)
 
 // A failed earlier HIP call (e.g. an attribute query) must not be mistaken for a launch failure.
 inline void clear_sticky_error() { (void)hipGetLastError(); }

@@ -5,6 +5,7 @@
 // The top part (types, ProgD, enums) is also compiled by hiprtc (SMR_JIT, see smr_jit.cpp): device
 // code only there, everything host-side sits behind #ifndef SMR_JIT.
 #ifndef SMR_JIT
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <memory>
@@ -312,6 +313,19 @@ struct JitStats {
     double compile_ms = 0;
 };
 JitStats jit_stats();
+
+// AQL ordering of the next kernel launch of the calling thread (0 or hipExtAnyOrderLaunch), consumed by the first launch that asks
+// (SMR_LAUNCH in smr_dispatch.h, jit_launch): set by the overlap window in smr_api.cpp
+unsigned take_launch_flags();
+
+// Recording (smr_seq.cpp): while a sequence records, SMR_LAUNCH / jit_launch append what they WOULD launch instead of launching it
+struct RecLaunch {
+    const void* hostfn = nullptr;  // host stub of a precompiled kernel; nullptr = runtime-compiled (not replayable as an AQL packet)
+    unsigned grid = 0, block = 0, lds = 0;
+    std::vector<unsigned char> args;  // the explicit kernel arguments in kernarg-segment layout
+};
+std::vector<RecLaunch>* recorder();  // thread-local, nullptr when nothing records
+void set_recorder(std::vector<RecLaunch>* r);
 
 // launchers (one per kernel TU)
 int launch_generic_map(const Plan& plan, void* const* bases, hipStream_t s);

@@ -397,7 +397,7 @@ static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        hipLaunchKernelGGL((k_flat2_map<T, F>), dim3(grid), dim3(256), lds, s, a, f);
+        SMR_LAUNCH((k_flat2_map<T, F>), dim3(grid), dim3(256), lds, s, a, f);
         return check_launch("k_flat2_map");
     }
 }
@@ -420,7 +420,7 @@ static int go3(const Plan& plan, hipStream_t s, F f, const FlatArgs& a, size_t l
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        hipLaunchKernelGGL((k_flat_map<T, F, DIR, VL, VF>), dim3(grid), dim3(256), lds, s, a, f);
+        SMR_LAUNCH((k_flat_map<T, F, DIR, VL, VF>), dim3(grid), dim3(256), lds, s, a, f);
         return check_launch("k_flat_map");
     }
 }

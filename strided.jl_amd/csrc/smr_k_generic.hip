@@ -99,7 +99,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        hipLaunchKernelGGL((k_generic_map<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        SMR_LAUNCH((k_generic_map<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
         return check_launch("k_generic_map");
     }
 }

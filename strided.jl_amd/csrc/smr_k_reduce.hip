@@ -784,7 +784,7 @@ static int launch_all(const Canon& c, const RedArgs& a, int blocks, hipStream_t 
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        hipLaunchKernelGGL((k_reduce_all<T, F, MIXED, V>), dim3(blocks), dim3(256), 0, s, a, f);
+        SMR_LAUNCH((k_reduce_all<T, F, MIXED, V>), dim3(blocks), dim3(256), 0, s, a, f);
         return check_launch("k_reduce_all");
     }
 }
@@ -846,7 +846,7 @@ static int go_all(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     if (rc) return rc;
     if (blocks > 1 && !a.single && !jit_no_launch()) {
         clear_sticky_error();
-    hipLaunchKernelGGL((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
+    SMR_LAUNCH((k_reduce_final<T, MIXED>), dim3(1), dim3(256), 0, s, a);
         rc = check_launch("k_reduce_final");
     }
     return rc;
@@ -871,9 +871,9 @@ static int launch_part(const Canon& c, const RedArgs& a, i64 blocks, hipStream_t
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        if constexpr (KIND == 0) hipLaunchKernelGGL((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
-        if constexpr (KIND == 1) hipLaunchKernelGGL((k_reduce_row<T, F, MIXED, V>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
-        if constexpr (KIND == 2) hipLaunchKernelGGL((k_reduce_col<T, F, MIXED, V>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        if constexpr (KIND == 0) SMR_LAUNCH((k_reduce_part<T, F, MIXED>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        if constexpr (KIND == 1) SMR_LAUNCH((k_reduce_row<T, F, MIXED, V>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
+        if constexpr (KIND == 2) SMR_LAUNCH((k_reduce_col<T, F, MIXED, V>), dim3((unsigned)blocks), dim3(256), 0, s, a, f);
         return check_launch("k_reduce_part");
     }
 }
@@ -968,7 +968,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     while (lpolog < 6 && (4 << lpolog) < nsplit && (c.nout << lpolog) < 256 * 1024) ++lpolog;
     a.trlog = lpolog;
     const i64 fthreads = c.nout << lpolog;
-    hipLaunchKernelGGL((k_reduce_part_final<T, MIXED>), dim3((unsigned)((fthreads + 255) / 256)), dim3(256), 0, s, a);
+    SMR_LAUNCH((k_reduce_part_final<T, MIXED>), dim3((unsigned)((fthreads + 255) / 256)), dim3(256), 0, s, a);
     return check_launch("k_reduce_part_final");
 }
 

@@ -204,9 +204,9 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
         if (a.txlog == 8)
-            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, true>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
+            SMR_LAUNCH((k_stream_map<T, F, MIXED, V, U, true>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
         else
-            hipLaunchKernelGGL((k_stream_map<T, F, MIXED, V, U, false>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
+            SMR_LAUNCH((k_stream_map<T, F, MIXED, V, U, false>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
         return check_launch("k_stream_map");
     }
 }

@@ -752,7 +752,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                         if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
                     }
-                    hipLaunchKernelGGL(kern, dim3(pgrid), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(pgrid, 1u << THRLOG));
+                    SMR_LAUNCH(kern, dim3(pgrid), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(pgrid, 1u << THRLOG));
                     return check_launch("k_tiled_map_pipe");
                 }
             }
@@ -761,7 +761,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
             }
-            hipLaunchKernelGGL(kern, dim3(grid_), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(grid_, 1u << THRLOG));
+            SMR_LAUNCH(kern, dim3(grid_), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(grid_, 1u << THRLOG));
             return check_launch("k_tiled_map");
         }
     };

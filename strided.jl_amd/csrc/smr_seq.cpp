@@ -1,0 +1,596 @@
+// smr_seq.cpp -- recorded sequences of plan executions, replayed as hand-built AQL packets on the library's own HSA queue.
+//
+// Why.  The reference runs independent pieces of work as concurrent tasks and waits only where it must (src/mapreduce.jl:203-223).
+// On MI355X the unit is the LAUNCH, and a stream-ordered launch of 16 MiB is a span of 1.6-3.2 us plus a 1.6-1.9 us boundary (drain,
+// write-back, next dispatch) even when its successor touches none of its data.  What round 4 measured (profiles/r04_overlap.txt):
+//   * HIP accepts hipExtAnyOrderLaunch but ignores it on gfx9 (hip_ext.h says so; the device stamps confirm it): through HIP every
+//     packet of a stream carries the AQL barrier bit;
+//   * two HIP streams do overlap the two kernels of the bench step (8.6 -> 6.2 us per step) -- when two host threads feed them: HIP's
+//     eager launch path costs 3.6-4 us of host time per launch, one thread cannot feed two queues;
+//   * a hipGraph with two branches is executed node by node through that same eager path (8.2-8.8 us per step), only single-chain
+//     graphs get the batched submission.
+// So the library submits its own packets: a sequence is recorded ONCE (every launch's kernel object, grid and kernarg block, resident
+// in device memory), the dependency analysis of the overlap window (smr_api.cpp: byte ranges read / written) decides per launch whether
+// its packet carries the barrier bit, and a replay is N x 64-byte stores into the queue ring plus one doorbell -- ~0.1 us of host time
+// per launch, no host thread in the loop, independent launches in flight together inside ONE hardware queue.
+//
+// Kernel objects come from the code objects HIP itself has loaded: host stub -> kernel name (hipKernelNameRefByPtr) -> "<name>.kd" looked
+// up in the process's HSA executables (loader extension 1.03: hsa_ven_amd_loader_iterate_executables).  Nothing is loaded twice.
+// Ordering against the caller's HIP stream: smr_seq_run waits (on the host) for `stream` to drain when it is busy, and makes it wait for
+// the replay with hipStreamWaitValue64 on the completion signal's value -- "as if the sequence had been launched in order on stream".
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/hsa_ven_amd_loader.h>
+#include <link.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "smr_internal.h"
+
+namespace smr {
+
+static thread_local std::vector<RecLaunch>* tl_recorder = nullptr;
+std::vector<RecLaunch>* recorder() { return tl_recorder; }
+void set_recorder(std::vector<RecLaunch>* r) { tl_recorder = r; }
+
+// smr_api.cpp
+int seq_execute_plan(smr_plan* plan, void* const* bases, hipStream_t s, bool prepare_only);
+void seq_footprint(smr_plan* plan, void* const* bases, std::vector<std::pair<uintptr_t, uintptr_t>>& rd, std::vector<std::pair<uintptr_t, uintptr_t>>& wr);
+int seq_nops(smr_plan* plan);
+
+namespace {
+
+// ---- the HSA runtime HIP already loaded (never a second copy) ------------------------------------------------------------------
+struct Hsa {
+    void* lib = nullptr;
+    decltype(&hsa_init) init = nullptr;
+    decltype(&hsa_iterate_agents) iterate_agents = nullptr;
+    decltype(&hsa_agent_get_info) agent_get_info = nullptr;
+    decltype(&hsa_queue_create) queue_create = nullptr;
+    decltype(&hsa_queue_destroy) queue_destroy = nullptr;
+    decltype(&hsa_queue_load_read_index_scacquire) load_read_index = nullptr;
+    decltype(&hsa_queue_add_write_index_relaxed) add_write_index = nullptr;
+    decltype(&hsa_signal_create) signal_create = nullptr;
+    decltype(&hsa_signal_destroy) signal_destroy = nullptr;
+    decltype(&hsa_signal_store_relaxed) signal_store_relaxed = nullptr;
+    decltype(&hsa_signal_store_screlease) signal_store_screlease = nullptr;
+    decltype(&hsa_signal_load_scacquire) signal_load = nullptr;
+    decltype(&hsa_signal_wait_scacquire) signal_wait = nullptr;
+    decltype(&hsa_amd_signal_value_pointer) signal_value_pointer = nullptr;
+    decltype(&hsa_system_get_major_extension_table) get_ext_table = nullptr;
+    decltype(&hsa_executable_get_symbol_by_name) get_symbol_by_name = nullptr;
+    decltype(&hsa_executable_symbol_get_info) symbol_get_info = nullptr;
+    decltype(&hsa_status_string) status_string = nullptr;
+    hsa_ven_amd_loader_1_03_pfn_t loader;
+    bool ok = false;
+    std::string why;
+};
+
+int find_hsa(struct dl_phdr_info* info, size_t, void* data) {
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "libhsa-runtime64")) {
+        *(std::string*)data = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
+
+Hsa& hsa() {
+    static Hsa* h = [] {
+        Hsa* x = new Hsa();
+        std::string path;
+        dl_iterate_phdr(find_hsa, &path);
+        if (path.empty()) {
+            x->why = "libhsa-runtime64 is not loaded in this process (HIP not initialised?)";
+            return x;
+        }
+        x->lib = dlopen(path.c_str(), RTLD_NOW | RTLD_NOLOAD);
+        if (!x->lib) {
+            x->why = std::string("dlopen(RTLD_NOLOAD) of ") + path + " failed";
+            return x;
+        }
+        bool all = true;
+#define SMR_HSA_SYM(field, name)                                   \
+    x->field = (decltype(x->field))dlsym(x->lib, #name);            \
+    if (!x->field) {                                                \
+        all = false;                                                \
+        x->why += std::string(" missing ") + #name;                 \
+    }
+        SMR_HSA_SYM(init, hsa_init)
+        SMR_HSA_SYM(iterate_agents, hsa_iterate_agents)
+        SMR_HSA_SYM(agent_get_info, hsa_agent_get_info)
+        SMR_HSA_SYM(queue_create, hsa_queue_create)
+        SMR_HSA_SYM(queue_destroy, hsa_queue_destroy)
+        SMR_HSA_SYM(load_read_index, hsa_queue_load_read_index_scacquire)
+        SMR_HSA_SYM(add_write_index, hsa_queue_add_write_index_relaxed)
+        SMR_HSA_SYM(signal_create, hsa_signal_create)
+        SMR_HSA_SYM(signal_destroy, hsa_signal_destroy)
+        SMR_HSA_SYM(signal_store_relaxed, hsa_signal_store_relaxed)
+        SMR_HSA_SYM(signal_store_screlease, hsa_signal_store_screlease)
+        SMR_HSA_SYM(signal_load, hsa_signal_load_scacquire)
+        SMR_HSA_SYM(signal_wait, hsa_signal_wait_scacquire)
+        SMR_HSA_SYM(signal_value_pointer, hsa_amd_signal_value_pointer)
+        SMR_HSA_SYM(get_ext_table, hsa_system_get_major_extension_table)
+        SMR_HSA_SYM(get_symbol_by_name, hsa_executable_get_symbol_by_name)
+        SMR_HSA_SYM(symbol_get_info, hsa_executable_symbol_get_info)
+        SMR_HSA_SYM(status_string, hsa_status_string)
+#undef SMR_HSA_SYM
+        if (!all) return x;
+        if (x->init() != HSA_STATUS_SUCCESS) {  // reference-counted: HIP holds the first reference
+            x->why = "hsa_init failed";
+            return x;
+        }
+        std::memset(&x->loader, 0, sizeof x->loader);
+        if (x->get_ext_table(HSA_EXTENSION_AMD_LOADER, 1, sizeof x->loader, &x->loader) != HSA_STATUS_SUCCESS ||
+            !x->loader.hsa_ven_amd_loader_iterate_executables) {
+            x->why = "HSA loader extension 1.03 (iterate_executables) is unavailable";
+            return x;
+        }
+        x->ok = true;
+        return x;
+    }();
+    return *h;
+}
+
+// ---- per-device direct queue --------------------------------------------------------------------------------------------------
+struct KernelRef {
+    uint64_t object = 0;
+    uint32_t kernarg_size = 0, group_static = 0, private_size = 0;
+    std::string name;
+};
+struct Direct {
+    hsa_agent_t agent{};
+    hsa_queue_t* q = nullptr;
+    hsa_signal_t done{};          // completion signal of the last packet of the replay in flight
+    volatile int64_t* done_ptr = nullptr;
+    std::mutex mu;                // one replay is written at a time
+    std::map<const void*, KernelRef> kernels;
+    bool wait_value_ok = false;
+    bool ok = false;
+    std::string why;
+};
+struct AgentPick {
+    Hsa* h;
+    uint32_t bdf, domain;
+    hsa_agent_t found{};
+    bool have = false;
+    hsa_agent_t first{};
+    int ngpu = 0;
+};
+hsa_status_t pick_agent(hsa_agent_t a, void* data) {
+    AgentPick* p = (AgentPick*)data;
+    hsa_device_type_t t;
+    if (p->h->agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    if (p->ngpu++ == 0) p->first = a;
+    uint32_t bdf = 0, dom = 0;
+    p->h->agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+    p->h->agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
+    if (bdf == p->bdf && dom == p->domain) {
+        p->found = a;
+        p->have = true;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+
+void queue_error(hsa_status_t st, hsa_queue_t*, void*) {
+    std::fprintf(stderr, "libstrided_hip: the direct-dispatch HSA queue reported error 0x%x\n", (unsigned)st);
+}
+
+std::mutex g_direct_mu;
+std::map<int, Direct*> g_direct;
+
+Direct& direct() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(g_direct_mu);
+    auto it = g_direct.find(dev);
+    if (it != g_direct.end()) return *it->second;
+    Direct* d = new Direct();
+    g_direct[dev] = d;
+    Hsa& h = hsa();
+    if (!h.ok) {
+        d->why = h.why;
+        return *d;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        d->why = "hipGetDeviceProperties failed";
+        return *d;
+    }
+    AgentPick pick;
+    pick.h = &h;
+    pick.bdf = ((uint32_t)prop.pciBusID << 8) | ((uint32_t)prop.pciDeviceID << 3);
+    pick.domain = (uint32_t)prop.pciDomainID;
+    h.iterate_agents(pick_agent, &pick);
+    if (!pick.have) {
+        if (pick.ngpu == 1) {
+            pick.found = pick.first;  // one GPU visible: nothing to confuse
+        } else {
+            d->why = "no HSA agent matches the HIP device's PCI address";
+            return *d;
+        }
+    }
+    d->agent = pick.found;
+    hsa_status_t st = h.queue_create(d->agent, 16384, HSA_QUEUE_TYPE_SINGLE, queue_error, nullptr, UINT32_MAX, UINT32_MAX, &d->q);
+    if (st != HSA_STATUS_SUCCESS) {
+        d->why = "hsa_queue_create failed";
+        return *d;
+    }
+    if (h.signal_create(0, 0, nullptr, &d->done) != HSA_STATUS_SUCCESS) {
+        d->why = "hsa_signal_create failed";
+        return *d;
+    }
+    volatile hsa_signal_value_t* vp = nullptr;
+    if (h.signal_value_pointer(d->done, &vp) == HSA_STATUS_SUCCESS) d->done_ptr = (volatile int64_t*)vp;
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can && d->done_ptr) d->wait_value_ok = true;
+    d->ok = true;
+    return *d;
+}
+
+struct Lookup {
+    Hsa* h;
+    hsa_agent_t agent;
+    std::string kd;
+    KernelRef out;
+    bool have = false;
+};
+hsa_status_t lookup_exec(hsa_executable_t ex, void* data) {
+    Lookup* l = (Lookup*)data;
+    hsa_executable_symbol_t sym;
+    if (l->h->get_symbol_by_name(ex, l->kd.c_str(), &l->agent, &sym) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    hsa_symbol_kind_t kind;
+    if (l->h->symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_TYPE, &kind) != HSA_STATUS_SUCCESS || kind != HSA_SYMBOL_KIND_KERNEL) return HSA_STATUS_SUCCESS;
+    l->h->symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &l->out.object);
+    l->h->symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &l->out.kernarg_size);
+    l->h->symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &l->out.group_static);
+    l->h->symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &l->out.private_size);
+    l->have = true;
+    return HSA_STATUS_INFO_BREAK;
+}
+
+// host stub -> kernel descriptor in the code object HIP has loaded
+int resolve_kernel(Direct& d, const void* hostfn, KernelRef& out) {
+    auto it = d.kernels.find(hostfn);
+    if (it != d.kernels.end()) {
+        out = it->second;
+        return SMR_OK;
+    }
+    hipFuncAttributes attr;  // forces HIP to load the code object that holds the kernel (deferred loading)
+    hipError_t e = hipFuncGetAttributes(&attr, hostfn);
+    if (e != hipSuccess) return hip_error(e, "hipFuncGetAttributes (sequence build)");
+    const char* name = hipKernelNameRefByPtr(hostfn, nullptr);
+    if (!name || !*name) return set_error(SMR_EUNSUPPORTED, "direct dispatch: HIP does not know the kernel's name");
+    Lookup l;
+    l.h = &hsa();
+    l.agent = d.agent;
+    l.kd = std::string(name) + ".kd";
+    l.h->loader.hsa_ven_amd_loader_iterate_executables(lookup_exec, &l);
+    if (!l.have) return set_error(SMR_EUNSUPPORTED, std::string("direct dispatch: kernel descriptor not found for ") + name);
+    l.out.name = name;
+    d.kernels[hostfn] = l.out;
+    out = l.out;
+    return SMR_OK;
+}
+
+}  // namespace
+}  // namespace smr
+
+using namespace smr;
+
+// ---- the sequence object ----------------------------------------------------------------------------------------------------------
+struct SeqItem {
+    smr_plan* plan;
+    bool has_bases;
+    void* bases[SMR_MAXM];
+};
+struct SeqPacket {
+    hsa_kernel_dispatch_packet_t pk;  // header / completion signal filled in at replay
+    bool barrier;
+};
+struct smr_seq {
+    std::vector<SeqItem> items;
+    bool built = false;
+    bool aql = false;           // every launch is a precompiled kernel without scratch: replayed as AQL packets
+    std::string why_not_aql;
+    std::vector<SeqPacket> packets;
+    void* d_kernargs = nullptr;
+    int64_t runs = 0;
+    int n_any = 0, n_barrier = 0;
+    int fence_scope_mid = 1;    // acquire / release scope of the packets inside a replay: 1 agent (default), 0 none, 2 system
+    bool inflight = false;      // a replay was submitted and nobody waited for it yet
+    int device = -1;
+};
+
+namespace {
+typedef std::vector<std::pair<uintptr_t, uintptr_t>> Spans;
+bool overlaps(const Spans& v, const std::pair<uintptr_t, uintptr_t>& x) {
+    for (const auto& y : v)
+        if (x.first < y.second && y.first < x.second) return true;
+    return false;
+}
+
+uint16_t header_of(bool barrier, int acq, int rel) {
+    return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                      (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+}
+
+int seq_build(smr_seq* q) {
+    q->packets.clear();
+    q->aql = false;
+    q->n_any = q->n_barrier = 0;
+    Direct& d = direct();
+    if (!d.ok) q->why_not_aql = d.why;
+    // 1. record every launch of every item (tables uploaded / scratch allocated by a prepare pass first)
+    struct Rec {
+        std::vector<RecLaunch> launches;
+        Spans rd, wr;
+    };
+    std::vector<Rec> recs(q->items.size());
+    for (size_t i = 0; i < q->items.size(); ++i) {
+        SeqItem& it = q->items[i];
+        int rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, nullptr, true);
+        if (rc) return rc;
+        set_recorder(&recs[i].launches);
+        rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, nullptr, false);
+        set_recorder(nullptr);
+        if (rc) return rc;
+        if (recs[i].launches.empty()) return set_error(SMR_EINVAL, "smr_seq: a plan recorded no launch");
+        seq_footprint(it.plan, it.has_bases ? it.bases : nullptr, recs[i].rd, recs[i].wr);
+    }
+    bool aql = d.ok;
+    // 2. resolve kernels
+    std::vector<std::vector<KernelRef>> refs(recs.size());
+    for (size_t i = 0; aql && i < recs.size(); ++i)
+        for (const RecLaunch& l : recs[i].launches) {
+            KernelRef k;
+            if (!l.hostfn) {
+                aql = false;
+                q->why_not_aql = "a runtime-compiled kernel takes part";
+                break;
+            }
+            if (resolve_kernel(d, l.hostfn, k) != SMR_OK) {
+                aql = false;
+                q->why_not_aql = smr_last_error();
+                break;
+            }
+            if (k.private_size != 0) {
+                aql = false;
+                q->why_not_aql = "a kernel needs scratch memory: " + k.name;
+                break;
+            }
+            refs[i].push_back(k);
+        }
+    q->aql = aql;
+    q->built = true;
+    if (!aql) return SMR_OK;
+    // 3. kernarg blocks (explicit arguments + the code-object-v5 hidden block), one resident copy in device memory
+    size_t total = 0;
+    std::vector<size_t> offs;
+    for (size_t i = 0; i < recs.size(); ++i)
+        for (size_t j = 0; j < recs[i].launches.size(); ++j) {
+            offs.push_back(total);
+            const size_t need = std::max<size_t>(refs[i][j].kernarg_size, recs[i].launches[j].args.size());
+            total += (need + 255) & ~(size_t)255;
+        }
+    std::vector<unsigned char> host(total, 0);
+    size_t n = 0;
+    for (size_t i = 0; i < recs.size(); ++i)
+        for (size_t j = 0; j < recs[i].launches.size(); ++j, ++n) {
+            const RecLaunch& l = recs[i].launches[j];
+            unsigned char* b = host.data() + offs[n];
+            std::memcpy(b, l.args.data(), l.args.size());
+            const size_t hid = (l.args.size() + 7) & ~(size_t)7;
+            if (refs[i][j].kernarg_size >= hid + 72) {  // hidden_block_count_[xyz], hidden_group_size_[xyz], remainders, global offsets, grid dims
+                uint32_t bc[3] = {l.grid, 1, 1};
+                uint16_t gs[6] = {(uint16_t)l.block, 1, 1, 0, 0, 0};
+                std::memcpy(b + hid, bc, 12);
+                std::memcpy(b + hid + 12, gs, 12);
+                uint16_t gd = 1;
+                std::memcpy(b + hid + 64, &gd, 2);
+                if (refs[i][j].kernarg_size >= hid + 124) {
+                    uint32_t dl = l.lds;
+                    std::memcpy(b + hid + 120, &dl, 4);  // hidden_dynamic_lds_size
+                }
+            }
+        }
+    if (q->d_kernargs) (void)hipFree(q->d_kernargs);
+    q->d_kernargs = nullptr;
+    hipError_t e = hipMalloc(&q->d_kernargs, total ? total : 256);
+    if (e != hipSuccess) return hip_error(e, "hipMalloc(sequence kernargs)");
+    e = hipMemcpy(q->d_kernargs, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_error(e, "hipMemcpy(sequence kernargs)");
+    // 4. packets + ordering: a launch that conflicts with none of the launches since the last ordered one goes out without the
+    //    barrier bit; the first launch of a replay is always ordered (it follows the previous replay's tail)
+    Spans wrd, wwr;
+    n = 0;
+    for (size_t i = 0; i < recs.size(); ++i) {
+        bool free_ = i > 0;
+        for (size_t k = 0; free_ && k < recs[i].wr.size(); ++k) free_ = !overlaps(wrd, recs[i].wr[k]) && !overlaps(wwr, recs[i].wr[k]);
+        for (size_t k = 0; free_ && k < recs[i].rd.size(); ++k) free_ = !overlaps(wwr, recs[i].rd[k]);
+        if (!free_) {
+            wrd.clear();
+            wwr.clear();
+        }
+        wrd.insert(wrd.end(), recs[i].rd.begin(), recs[i].rd.end());
+        wwr.insert(wwr.end(), recs[i].wr.begin(), recs[i].wr.end());
+        for (size_t j = 0; j < recs[i].launches.size(); ++j, ++n) {
+            const RecLaunch& l = recs[i].launches[j];
+            SeqPacket sp;
+            std::memset(&sp, 0, sizeof sp);
+            sp.barrier = j > 0 || !free_;  // later launches of one execution (folding passes) depend on the first
+            (sp.barrier ? q->n_barrier : q->n_any)++;
+            sp.pk.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+            sp.pk.workgroup_size_x = (uint16_t)l.block;
+            sp.pk.workgroup_size_y = 1;
+            sp.pk.workgroup_size_z = 1;
+            sp.pk.grid_size_x = l.grid * l.block;
+            sp.pk.grid_size_y = 1;
+            sp.pk.grid_size_z = 1;
+            sp.pk.private_segment_size = 0;
+            sp.pk.group_segment_size = refs[i][j].group_static + l.lds;
+            sp.pk.kernel_object = refs[i][j].object;
+            sp.pk.kernarg_address = (char*)q->d_kernargs + offs[n];
+            q->packets.push_back(sp);
+        }
+    }
+    return SMR_OK;
+}
+
+// writes `reps` replays into the ring; the last packet signals d.done
+int seq_submit(smr_seq* q, Direct& d, int reps) {
+    Hsa& h = hsa();
+    const uint32_t mask = d.q->size - 1;
+    const size_t np = q->packets.size();
+    const uint64_t totalp = (uint64_t)np * (uint64_t)reps;
+    h.signal_store_relaxed(d.done, 1);
+    const int mid = q->fence_scope_mid;
+    uint64_t written = 0;
+    while (written < totalp) {
+        // as many packets as the ring has room for
+        const uint64_t widx = h.add_write_index(d.q, 0);
+        uint64_t room = d.q->size - (widx - h.load_read_index(d.q));
+        if (room == 0) continue;  // the packet processor is behind: spin (a replay is microseconds per packet)
+        const uint64_t nthis = std::min<uint64_t>(room, totalp - written);
+        const uint64_t base = h.add_write_index(d.q, nthis);
+        for (uint64_t t = 0; t < nthis; ++t) {
+            const uint64_t g = written + t;
+            const SeqPacket& sp = q->packets[g % np];
+            hsa_kernel_dispatch_packet_t* slot = (hsa_kernel_dispatch_packet_t*)d.q->base_address + ((base + t) & mask);
+            const bool first = g == 0, last = g + 1 == totalp;
+            hsa_kernel_dispatch_packet_t pk = sp.pk;
+            pk.completion_signal = last ? d.done : hsa_signal_t{0};
+            // body first, header last (release): the packet processor owns the slot once the header is valid
+            std::memcpy((char*)slot + 4, (const char*)&pk + 4, sizeof pk - 4);
+            const uint16_t hdr = header_of(sp.barrier || first, first ? HSA_FENCE_SCOPE_SYSTEM : mid, last ? HSA_FENCE_SCOPE_SYSTEM : mid);
+            __atomic_store_n((uint32_t*)slot, (uint32_t)hdr | ((uint32_t)pk.setup << 16), __ATOMIC_RELEASE);
+        }
+        h.signal_store_screlease(d.q->doorbell_signal, (hsa_signal_value_t)(base + nthis - 1));
+        written += nthis;
+    }
+    return SMR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int smr_seq_create(smr_seq** out) {
+    if (!out) return set_error(SMR_EINVAL, "null out");
+    *out = new (std::nothrow) smr_seq();
+    return *out ? SMR_OK : set_error(SMR_ENOMEM, "out of host memory");
+}
+
+int smr_seq_add(smr_seq* q, smr_plan* plan, void* const* bases) {
+    if (!q || !plan) return set_error(SMR_EINVAL, "null argument");
+    if (q->inflight) return set_error(SMR_EINVAL, "smr_seq_add: a replay is in flight (smr_seq_wait first)");
+    SeqItem it;
+    std::memset(&it, 0, sizeof it);
+    it.plan = plan;
+    it.has_bases = bases != nullptr;
+    if (bases)
+        for (int k = 0; k < seq_nops(plan); ++k) it.bases[k] = bases[k];
+    q->items.push_back(it);
+    q->built = false;
+    return SMR_OK;
+}
+
+int smr_seq_run(smr_seq* q, int reps, void* stream) {
+    if (!q || reps < 1) return set_error(SMR_EINVAL, "smr_seq_run: null sequence or reps < 1");
+    if (q->items.empty()) return set_error(SMR_EINVAL, "smr_seq_run: empty sequence");
+    hipStream_t s = (hipStream_t)stream;
+    if (!q->built) {
+        int rc = seq_build(q);
+        if (rc) return rc;
+    }
+    if (!q->aql) {  // HIP path: the same launches, in order on the caller's stream
+        for (int r = 0; r < reps; ++r)
+            for (SeqItem& it : q->items) {
+                int rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, s, false);
+                if (rc) return rc;
+            }
+        ++q->runs;
+        return SMR_OK;
+    }
+    Direct& d = direct();
+    std::lock_guard<std::mutex> g(d.mu);
+    Hsa& h = hsa();
+    // the previous replay on this queue must have completed before its completion signal is re-armed
+    if (h.signal_load(d.done) != 0) h.signal_wait(d.done, HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    // whatever the caller queued on `stream` before comes first
+    hipError_t e = hipStreamQuery(s);
+    if (e == hipErrorNotReady) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_error(e, "smr_seq_run: draining the caller's stream");
+    int rc = seq_submit(q, d, reps);
+    if (rc) return rc;
+    q->inflight = true;
+    ++q->runs;
+    // ... and whatever the caller queues on `stream` afterwards comes last
+    if (d.wait_value_ok) {
+        e = hipStreamWaitValue64(s, (void*)d.done_ptr, 0, hipStreamWaitValueEq, 0xFFFFFFFFFFFFFFFFull);
+        if (e == hipSuccess) return SMR_OK;
+        (void)hipGetLastError();
+        d.wait_value_ok = false;
+    }
+    h.signal_wait(d.done, HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);  // no stream-side wait on this system: block here
+    q->inflight = false;
+    return SMR_OK;
+}
+
+int smr_seq_wait(smr_seq* q) {
+    if (!q) return set_error(SMR_EINVAL, "null sequence");
+    if (!q->aql || !q->inflight) return SMR_OK;
+    Direct& d = direct();
+    hsa().signal_wait(d.done, HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    q->inflight = false;
+    return SMR_OK;
+}
+
+int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
+    if (!q || !buf || !buflen) return set_error(SMR_EINVAL, "null argument");
+    if (!q->built) {
+        int rc = seq_build(q);
+        if (rc) return rc;
+    }
+    if (q->aql)
+        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu ordered=%d unordered=%d fence_mid=%d stream_wait=%s", q->items.size(), q->packets.size(),
+                      q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host");
+    else
+        std::snprintf(buf, buflen, "backend=hip items=%zu (%s)", q->items.size(), q->why_not_aql.c_str());
+    return SMR_OK;
+}
+
+int smr_seq_set(smr_seq* q, const char* name, int64_t value) {
+    if (!q || !name) return set_error(SMR_EINVAL, "null argument");
+    if (std::strcmp(name, "fence_scope") == 0 && value >= 0 && value <= 2) {
+        q->fence_scope_mid = (int)value;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "order") == 0) {  // experiments: 0 = every packet ordered, 1 = dependency-aware (default)
+        if (!q->built) {
+            int rc = seq_build(q);
+            if (rc) return rc;
+        }
+        if (value == 0)
+            for (SeqPacket& p : q->packets) p.barrier = true;
+        else
+            q->built = false;
+        return SMR_OK;
+    }
+    return set_error(SMR_EINVAL, "smr_seq_set: unknown name");
+}
+
+int smr_seq_destroy(smr_seq* q) {
+    if (!q) return SMR_OK;
+    (void)smr_seq_wait(q);
+    if (q->d_kernargs) (void)hipFree(q->d_kernargs);
+    delete q;
+    return SMR_OK;
+}
+
+}  // extern "C"
