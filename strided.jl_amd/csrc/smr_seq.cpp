@@ -24,6 +24,7 @@
 #include <hsa/hsa_ven_amd_loader.h>
 #include <link.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -139,6 +140,7 @@ Hsa& hsa() {
 }
 
 // ---- per-device direct queue --------------------------------------------------------------------------------------------------
+constexpr int SEQ_MAXQ = 4;
 struct KernelRef {
     uint64_t object = 0;
     uint32_t kernarg_size = 0, group_static = 0, private_size = 0;
@@ -146,10 +148,15 @@ struct KernelRef {
 };
 struct Direct {
     hsa_agent_t agent{};
-    hsa_queue_t* q = nullptr;
-    hsa_signal_t done{};          // completion signal of the last packet of the replay in flight
-    volatile int64_t* done_ptr = nullptr;
-    std::mutex mu;                // one replay is written at a time
+    // SEQ_MAXQ hardware queues of the library's own (created on first use): launches that belong to different dependency
+    // components of a sequence go to different queues, where neither the barrier bit nor the acquire / release fences of one
+    // chain hold up the other (inside ONE queue the packet processor serialises consecutive dispatches on their fences even
+    // when the barrier bit is clear: profiles/r04_overlap.txt)
+    hsa_queue_t* q[SEQ_MAXQ] = {};
+    hsa_signal_t done[SEQ_MAXQ] = {};   // completion signal of the last packet a replay put on queue k
+    volatile int64_t* done_ptr[SEQ_MAXQ] = {};
+    bool armed[SEQ_MAXQ] = {};          // done[k] belongs to a replay nobody waited for yet
+    std::mutex mu;                      // one replay is written at a time
     std::map<const void*, KernelRef> kernels;
     bool wait_value_ok = false;
     bool ok = false;
@@ -185,6 +192,25 @@ void queue_error(hsa_status_t st, hsa_queue_t*, void*) {
 std::mutex g_direct_mu;
 std::map<int, Direct*> g_direct;
 
+// queue k of the device (created on first use)
+int direct_queue(Direct& d, int k) {
+    if (d.q[k]) return SMR_OK;
+    Hsa& h = hsa();
+    hsa_status_t st = h.queue_create(d.agent, 16384, HSA_QUEUE_TYPE_SINGLE, queue_error, nullptr, UINT32_MAX, UINT32_MAX, &d.q[k]);
+    if (st != HSA_STATUS_SUCCESS) {
+        d.q[k] = nullptr;
+        d.why = "hsa_queue_create failed";
+        return set_error(SMR_EHIP, d.why);
+    }
+    if (h.signal_create(0, 0, nullptr, &d.done[k]) != HSA_STATUS_SUCCESS) {
+        d.why = "hsa_signal_create failed";
+        return set_error(SMR_EHIP, d.why);
+    }
+    volatile hsa_signal_value_t* vp = nullptr;
+    if (h.signal_value_pointer(d.done[k], &vp) == HSA_STATUS_SUCCESS) d.done_ptr[k] = (volatile int64_t*)vp;
+    return SMR_OK;
+}
+
 Direct& direct() {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -217,19 +243,12 @@ Direct& direct() {
         }
     }
     d->agent = pick.found;
-    hsa_status_t st = h.queue_create(d->agent, 16384, HSA_QUEUE_TYPE_SINGLE, queue_error, nullptr, UINT32_MAX, UINT32_MAX, &d->q);
-    if (st != HSA_STATUS_SUCCESS) {
-        d->why = "hsa_queue_create failed";
+    if (int rc = direct_queue(*d, 0)) {
+        (void)rc;
         return *d;
     }
-    if (h.signal_create(0, 0, nullptr, &d->done) != HSA_STATUS_SUCCESS) {
-        d->why = "hsa_signal_create failed";
-        return *d;
-    }
-    volatile hsa_signal_value_t* vp = nullptr;
-    if (h.signal_value_pointer(d->done, &vp) == HSA_STATUS_SUCCESS) d->done_ptr = (volatile int64_t*)vp;
     int can = 0;
-    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can && d->done_ptr) d->wait_value_ok = true;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can && d->done_ptr[0]) d->wait_value_ok = true;
     d->ok = true;
     return *d;
 }
@@ -299,11 +318,15 @@ struct smr_seq {
     bool built = false;
     bool aql = false;           // every launch is a precompiled kernel without scratch: replayed as AQL packets
     std::string why_not_aql;
-    std::vector<SeqPacket> packets;
+    std::vector<SeqPacket> packets[SEQ_MAXQ];  // one replay's packets, per hardware queue
+    int nq = 0;                 // queues in use (= dependency components of the recorded list, at most max_queues)
+    int max_queues = SEQ_MAXQ;
+    int ncomp = 0;
     void* d_kernargs = nullptr;
     int64_t runs = 0;
     int n_any = 0, n_barrier = 0;
     int fence_scope_mid = 1;    // acquire / release scope of the packets inside a replay: 1 agent (default), 0 none, 2 system
+    bool all_ordered = false;   // experiment: every packet carries the barrier bit
     bool inflight = false;      // a replay was submitted and nobody waited for it yet
     int device = -1;
 };
@@ -315,6 +338,11 @@ bool overlaps(const Spans& v, const std::pair<uintptr_t, uintptr_t>& x) {
         if (x.first < y.second && y.first < x.second) return true;
     return false;
 }
+bool overlaps(const Spans& v, const Spans& w) {
+    for (const auto& x : w)
+        if (overlaps(v, x)) return true;
+    return false;
+}
 
 uint16_t header_of(bool barrier, int acq, int rel) {
     return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
@@ -322,15 +350,18 @@ uint16_t header_of(bool barrier, int acq, int rel) {
 }
 
 int seq_build(smr_seq* q) {
-    q->packets.clear();
+    for (auto& v : q->packets) v.clear();
     q->aql = false;
     q->n_any = q->n_barrier = 0;
+    q->nq = 0;
     Direct& d = direct();
     if (!d.ok) q->why_not_aql = d.why;
     // 1. record every launch of every item (tables uploaded / scratch allocated by a prepare pass first)
     struct Rec {
         std::vector<RecLaunch> launches;
         Spans rd, wr;
+        size_t bytes = 0;
+        int comp = 0, queue = 0;
     };
     std::vector<Rec> recs(q->items.size());
     for (size_t i = 0; i < q->items.size(); ++i) {
@@ -343,6 +374,8 @@ int seq_build(smr_seq* q) {
         if (rc) return rc;
         if (recs[i].launches.empty()) return set_error(SMR_EINVAL, "smr_seq: a plan recorded no launch");
         seq_footprint(it.plan, it.has_bases ? it.bases : nullptr, recs[i].rd, recs[i].wr);
+        for (const auto& x : recs[i].rd) recs[i].bytes += x.second - x.first;
+        for (const auto& x : recs[i].wr) recs[i].bytes += x.second - x.first;
     }
     bool aql = d.ok;
     // 2. resolve kernels
@@ -372,19 +405,18 @@ int seq_build(smr_seq* q) {
     if (!aql) return SMR_OK;
     // 3. kernarg blocks (explicit arguments + the code-object-v5 hidden block), one resident copy in device memory
     size_t total = 0;
-    std::vector<size_t> offs;
+    std::vector<std::vector<size_t>> offs(recs.size());
     for (size_t i = 0; i < recs.size(); ++i)
         for (size_t j = 0; j < recs[i].launches.size(); ++j) {
-            offs.push_back(total);
+            offs[i].push_back(total);
             const size_t need = std::max<size_t>(refs[i][j].kernarg_size, recs[i].launches[j].args.size());
             total += (need + 255) & ~(size_t)255;
         }
     std::vector<unsigned char> host(total, 0);
-    size_t n = 0;
     for (size_t i = 0; i < recs.size(); ++i)
-        for (size_t j = 0; j < recs[i].launches.size(); ++j, ++n) {
+        for (size_t j = 0; j < recs[i].launches.size(); ++j) {
             const RecLaunch& l = recs[i].launches[j];
-            unsigned char* b = host.data() + offs[n];
+            unsigned char* b = host.data() + offs[i][j];
             std::memcpy(b, l.args.data(), l.args.size());
             const size_t hid = (l.args.size() + 7) & ~(size_t)7;
             if (refs[i][j].kernarg_size >= hid + 72) {  // hidden_block_count_[xyz], hidden_group_size_[xyz], remainders, global offsets, grid dims
@@ -406,75 +438,146 @@ int seq_build(smr_seq* q) {
     if (e != hipSuccess) return hip_error(e, "hipMalloc(sequence kernargs)");
     e = hipMemcpy(q->d_kernargs, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hip_error(e, "hipMemcpy(sequence kernargs)");
-    // 4. packets + ordering: a launch that conflicts with none of the launches since the last ordered one goes out without the
-    //    barrier bit; the first launch of a replay is always ordered (it follows the previous replay's tail)
-    Spans wrd, wwr;
-    n = 0;
-    for (size_t i = 0; i < recs.size(); ++i) {
-        bool free_ = i > 0;
-        for (size_t k = 0; free_ && k < recs[i].wr.size(); ++k) free_ = !overlaps(wrd, recs[i].wr[k]) && !overlaps(wwr, recs[i].wr[k]);
-        for (size_t k = 0; free_ && k < recs[i].rd.size(); ++k) free_ = !overlaps(wwr, recs[i].rd[k]);
-        if (!free_) {
-            wrd.clear();
-            wwr.clear();
+    // 4. dependency components of the recorded list.  Two executions conflict when one writes bytes the other reads or writes
+    //    (an execution conflicts with its own next replay through its destination).  Executions of one component stay on ONE
+    //    hardware queue, in recorded order -- every ordering the in-order result needs is then an ordering inside a queue, no
+    //    cross-queue signal exists, and replay r+1 follows replay r on every queue by construction.  Different components share
+    //    nothing that is written: they go to different queues (longest-processing-time first over the bytes they touch) and run
+    //    concurrently -- the spawn / wait of src/mapreduce.jl:203-223 at the granularity of whole launches.
+    const size_t ni = recs.size();
+    std::vector<int> parent(ni);
+    for (size_t i = 0; i < ni; ++i) parent[i] = (int)i;
+    auto find = [&](int x) {
+        while (parent[x] != x) x = parent[x] = parent[parent[x]];
+        return x;
+    };
+    for (size_t i = 0; i < ni; ++i)
+        for (size_t j = i + 1; j < ni; ++j)
+            if (overlaps(recs[i].wr, recs[j].wr) || overlaps(recs[i].wr, recs[j].rd) || overlaps(recs[i].rd, recs[j].wr)) parent[find((int)j)] = find((int)i);
+    std::vector<int> roots;
+    std::vector<size_t> cbytes;
+    for (size_t i = 0; i < ni; ++i) {
+        const int r = find((int)i);
+        size_t c = 0;
+        for (; c < roots.size(); ++c)
+            if (roots[c] == r) break;
+        if (c == roots.size()) {
+            roots.push_back(r);
+            cbytes.push_back(0);
         }
-        wrd.insert(wrd.end(), recs[i].rd.begin(), recs[i].rd.end());
-        wwr.insert(wwr.end(), recs[i].wr.begin(), recs[i].wr.end());
-        for (size_t j = 0; j < recs[i].launches.size(); ++j, ++n) {
-            const RecLaunch& l = recs[i].launches[j];
-            SeqPacket sp;
-            std::memset(&sp, 0, sizeof sp);
-            sp.barrier = j > 0 || !free_;  // later launches of one execution (folding passes) depend on the first
-            (sp.barrier ? q->n_barrier : q->n_any)++;
-            sp.pk.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
-            sp.pk.workgroup_size_x = (uint16_t)l.block;
-            sp.pk.workgroup_size_y = 1;
-            sp.pk.workgroup_size_z = 1;
-            sp.pk.grid_size_x = l.grid * l.block;
-            sp.pk.grid_size_y = 1;
-            sp.pk.grid_size_z = 1;
-            sp.pk.private_segment_size = 0;
-            sp.pk.group_segment_size = refs[i][j].group_static + l.lds;
-            sp.pk.kernel_object = refs[i][j].object;
-            sp.pk.kernarg_address = (char*)q->d_kernargs + offs[n];
-            q->packets.push_back(sp);
+        recs[i].comp = (int)c;
+        cbytes[c] += recs[i].bytes;
+    }
+    q->ncomp = (int)roots.size();
+    const int nq = std::max(1, std::min<int>({q->max_queues, SEQ_MAXQ, (int)roots.size()}));
+    std::vector<int> order(roots.size()), cqueue(roots.size(), 0);
+    for (size_t c = 0; c < order.size(); ++c) order[c] = (int)c;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cbytes[a] > cbytes[b]; });
+    std::vector<size_t> load(nq, 0);
+    for (int c : order) {
+        int best = 0;
+        for (int k = 1; k < nq; ++k)
+            if (load[k] < load[best]) best = k;
+        cqueue[c] = best;
+        load[best] += cbytes[c];
+    }
+    for (int k = 0; k < nq; ++k)
+        if (int rc = direct_queue(d, k)) return rc;
+    q->nq = nq;
+    // 5. packets + ordering inside each queue: a launch that conflicts with none of the launches since the queue's last ordered one
+    //    goes out without the barrier bit.  The decisions are those of the SECOND of two simulated replays (steady state: the first
+    //    launch of a replay is judged against the tail of the previous replay on the same queue).
+    for (int k = 0; k < nq; ++k) {
+        Spans wrd, wwr;
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t i = 0; i < ni; ++i) {
+                if (cqueue[recs[i].comp] != k) continue;
+                bool free_ = !(wrd.empty() && wwr.empty()) && !q->all_ordered;
+                if (free_) free_ = !overlaps(wrd, recs[i].wr) && !overlaps(wwr, recs[i].wr) && !overlaps(wwr, recs[i].rd);
+                if (!free_) {
+                    wrd.clear();
+                    wwr.clear();
+                }
+                wrd.insert(wrd.end(), recs[i].rd.begin(), recs[i].rd.end());
+                wwr.insert(wwr.end(), recs[i].wr.begin(), recs[i].wr.end());
+                if (pass == 0) continue;
+                for (size_t j = 0; j < recs[i].launches.size(); ++j) {
+                    const RecLaunch& l = recs[i].launches[j];
+                    SeqPacket sp;
+                    std::memset(&sp, 0, sizeof sp);
+                    sp.barrier = j > 0 || !free_;  // later launches of one execution (folding passes) depend on the first
+                    (sp.barrier ? q->n_barrier : q->n_any)++;
+                    sp.pk.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+                    sp.pk.workgroup_size_x = (uint16_t)l.block;
+                    sp.pk.workgroup_size_y = 1;
+                    sp.pk.workgroup_size_z = 1;
+                    sp.pk.grid_size_x = l.grid * l.block;
+                    sp.pk.grid_size_y = 1;
+                    sp.pk.grid_size_z = 1;
+                    sp.pk.private_segment_size = 0;
+                    sp.pk.group_segment_size = refs[i][j].group_static + l.lds;
+                    sp.pk.kernel_object = refs[i][j].object;
+                    sp.pk.kernarg_address = (char*)q->d_kernargs + offs[i][j];
+                    q->packets[k].push_back(sp);
+                }
+            }
+    }
+    return SMR_OK;
+}
+
+// writes `reps` replays into the rings; the last packet on every queue signals that queue's d.done
+int seq_submit(smr_seq* q, Direct& d, int reps) {
+    Hsa& h = hsa();
+    const int mid = q->fence_scope_mid;
+    uint64_t written[SEQ_MAXQ] = {}, totalp[SEQ_MAXQ] = {};
+    int open_queues = 0;
+    for (int k = 0; k < q->nq; ++k) {
+        totalp[k] = (uint64_t)q->packets[k].size() * (uint64_t)reps;
+        d.armed[k] = totalp[k] > 0;
+        if (totalp[k]) {
+            h.signal_store_relaxed(d.done[k], 1);
+            ++open_queues;
+        }
+    }
+    while (open_queues > 0) {
+        for (int k = 0; k < q->nq; ++k) {
+            if (written[k] >= totalp[k]) continue;
+            hsa_queue_t* hq = d.q[k];
+            const uint32_t mask = hq->size - 1;
+            const size_t np = q->packets[k].size();
+            // as many packets as the ring has room for, at most 256 per visit so that every queue is fed early
+            const uint64_t widx = h.add_write_index(hq, 0);
+            const uint64_t room = hq->size - (widx - h.load_read_index(hq));
+            if (room == 0) continue;  // the packet processor is behind: visit the other queues, come back
+            const uint64_t nthis = std::min<uint64_t>({room, totalp[k] - written[k], (uint64_t)256});
+            const uint64_t base = h.add_write_index(hq, nthis);
+            for (uint64_t t = 0; t < nthis; ++t) {
+                const uint64_t g = written[k] + t;
+                const SeqPacket& sp = q->packets[k][g % np];
+                hsa_kernel_dispatch_packet_t* slot = (hsa_kernel_dispatch_packet_t*)hq->base_address + ((base + t) & mask);
+                const bool first = g == 0, last = g + 1 == totalp[k];
+                hsa_kernel_dispatch_packet_t pk = sp.pk;
+                pk.completion_signal = last ? d.done[k] : hsa_signal_t{0};
+                // body first, header last (release): the packet processor owns the slot once the header is valid
+                std::memcpy((char*)slot + 4, (const char*)&pk + 4, sizeof pk - 4);
+                const uint16_t hdr = header_of(sp.barrier || first, first ? HSA_FENCE_SCOPE_SYSTEM : mid, last ? HSA_FENCE_SCOPE_SYSTEM : mid);
+                __atomic_store_n((uint32_t*)slot, (uint32_t)hdr | ((uint32_t)pk.setup << 16), __ATOMIC_RELEASE);
+            }
+            h.signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)(base + nthis - 1));
+            written[k] += nthis;
+            if (written[k] >= totalp[k]) --open_queues;
         }
     }
     return SMR_OK;
 }
 
-// writes `reps` replays into the ring; the last packet signals d.done
-int seq_submit(smr_seq* q, Direct& d, int reps) {
+void wait_all(Direct& d) {
     Hsa& h = hsa();
-    const uint32_t mask = d.q->size - 1;
-    const size_t np = q->packets.size();
-    const uint64_t totalp = (uint64_t)np * (uint64_t)reps;
-    h.signal_store_relaxed(d.done, 1);
-    const int mid = q->fence_scope_mid;
-    uint64_t written = 0;
-    while (written < totalp) {
-        // as many packets as the ring has room for
-        const uint64_t widx = h.add_write_index(d.q, 0);
-        uint64_t room = d.q->size - (widx - h.load_read_index(d.q));
-        if (room == 0) continue;  // the packet processor is behind: spin (a replay is microseconds per packet)
-        const uint64_t nthis = std::min<uint64_t>(room, totalp - written);
-        const uint64_t base = h.add_write_index(d.q, nthis);
-        for (uint64_t t = 0; t < nthis; ++t) {
-            const uint64_t g = written + t;
-            const SeqPacket& sp = q->packets[g % np];
-            hsa_kernel_dispatch_packet_t* slot = (hsa_kernel_dispatch_packet_t*)d.q->base_address + ((base + t) & mask);
-            const bool first = g == 0, last = g + 1 == totalp;
-            hsa_kernel_dispatch_packet_t pk = sp.pk;
-            pk.completion_signal = last ? d.done : hsa_signal_t{0};
-            // body first, header last (release): the packet processor owns the slot once the header is valid
-            std::memcpy((char*)slot + 4, (const char*)&pk + 4, sizeof pk - 4);
-            const uint16_t hdr = header_of(sp.barrier || first, first ? HSA_FENCE_SCOPE_SYSTEM : mid, last ? HSA_FENCE_SCOPE_SYSTEM : mid);
-            __atomic_store_n((uint32_t*)slot, (uint32_t)hdr | ((uint32_t)pk.setup << 16), __ATOMIC_RELEASE);
+    for (int k = 0; k < SEQ_MAXQ; ++k)
+        if (d.armed[k]) {
+            if (h.signal_load(d.done[k]) != 0) h.signal_wait(d.done[k], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+            d.armed[k] = false;
         }
-        h.signal_store_screlease(d.q->doorbell_signal, (hsa_signal_value_t)(base + nthis - 1));
-        written += nthis;
-    }
-    return SMR_OK;
 }
 }  // namespace
 
@@ -520,8 +623,8 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
     Direct& d = direct();
     std::lock_guard<std::mutex> g(d.mu);
     Hsa& h = hsa();
-    // the previous replay on this queue must have completed before its completion signal is re-armed
-    if (h.signal_load(d.done) != 0) h.signal_wait(d.done, HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    // the previous replay on these queues must have completed before the completion signals are re-armed
+    wait_all(d);
     // whatever the caller queued on `stream` before comes first
     hipError_t e = hipStreamQuery(s);
     if (e == hipErrorNotReady) e = hipStreamSynchronize(s);
@@ -532,13 +635,16 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
     ++q->runs;
     // ... and whatever the caller queues on `stream` afterwards comes last
     if (d.wait_value_ok) {
-        e = hipStreamWaitValue64(s, (void*)d.done_ptr, 0, hipStreamWaitValueEq, 0xFFFFFFFFFFFFFFFFull);
+        e = hipSuccess;
+        for (int k = 0; k < q->nq && e == hipSuccess; ++k)
+            if (d.armed[k]) e = hipStreamWaitValue64(s, (void*)d.done_ptr[k], 0, hipStreamWaitValueEq, 0xFFFFFFFFFFFFFFFFull);
         if (e == hipSuccess) return SMR_OK;
         (void)hipGetLastError();
         d.wait_value_ok = false;
     }
-    h.signal_wait(d.done, HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);  // no stream-side wait on this system: block here
+    wait_all(d);  // no stream-side wait on this system: block here
     q->inflight = false;
+    (void)h;
     return SMR_OK;
 }
 
@@ -546,7 +652,10 @@ int smr_seq_wait(smr_seq* q) {
     if (!q) return set_error(SMR_EINVAL, "null sequence");
     if (!q->aql || !q->inflight) return SMR_OK;
     Direct& d = direct();
-    hsa().signal_wait(d.done, HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    {
+        std::lock_guard<std::mutex> g(d.mu);
+        wait_all(d);
+    }
     q->inflight = false;
     return SMR_OK;
 }
@@ -557,9 +666,12 @@ int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
         int rc = seq_build(q);
         if (rc) return rc;
     }
-    if (q->aql)
-        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu ordered=%d unordered=%d fence_mid=%d stream_wait=%s", q->items.size(), q->packets.size(),
-                      q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host");
+    if (q->aql) {
+        size_t np = 0;
+        for (const auto& v : q->packets) np += v.size();
+        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d queues=%d ordered=%d unordered=%d fence_mid=%d stream_wait=%s", q->items.size(), np,
+                      q->ncomp, q->nq, q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host");
+    }
     else
         std::snprintf(buf, buflen, "backend=hip items=%zu (%s)", q->items.size(), q->why_not_aql.c_str());
     return SMR_OK;
@@ -571,15 +683,15 @@ int smr_seq_set(smr_seq* q, const char* name, int64_t value) {
         q->fence_scope_mid = (int)value;
         return SMR_OK;
     }
+    if (q->inflight) return set_error(SMR_EINVAL, "smr_seq_set: a replay is in flight (smr_seq_wait first)");
     if (std::strcmp(name, "order") == 0) {  // experiments: 0 = every packet ordered, 1 = dependency-aware (default)
-        if (!q->built) {
-            int rc = seq_build(q);
-            if (rc) return rc;
-        }
-        if (value == 0)
-            for (SeqPacket& p : q->packets) p.barrier = true;
-        else
-            q->built = false;
+        q->all_ordered = value == 0;
+        q->built = false;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "queues") == 0 && value >= 1 && value <= SEQ_MAXQ) {  // hardware queues a replay may spread over
+        q->max_queues = (int)value;
+        q->built = false;
         return SMR_OK;
     }
     return set_error(SMR_EINVAL, "smr_seq_set: unknown name");

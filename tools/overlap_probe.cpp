@@ -401,7 +401,7 @@ int main(int argc, char** argv) {
         words2 = regions[0].b - regions[0].a;
         words3 = regions[1].b - regions[1].a;
     }
-    auto run_seq = [&](const char* name, int order, int fence, int steps_in_seq, int reps) {
+    auto run_seq = [&](const char* name, int order, int fence, int steps_in_seq, int reps, int queues = 4) {
         HC(hipMemset(dB, 0, hB.size() * 8));
         HC(hipMemset(dC, 0, hC.size() * 8));
         smr_seq* q = nullptr;
@@ -413,9 +413,10 @@ int main(int argc, char** argv) {
         if (stamped) SC(p_set_option("stamp_used", 0));
         regions.clear();
         char info[512];
-        SC(p_seq_info(q, info, sizeof info));  // builds
         if (order == 0) SC(p_seq_set(q, "order", 0));
         SC(p_seq_set(q, "fence_scope", fence));
+        SC(p_seq_set(q, "queues", queues));
+        SC(p_seq_info(q, info, sizeof info));  // builds
         if (stamped) {
             long u = 0;
             for (int i = 0; i < steps_in_seq; ++i) {
@@ -458,12 +459,16 @@ int main(int argc, char** argv) {
         HC(hipEventDestroy(e0));
         HC(hipEventDestroy(e1));
     };
-    run_seq("seq AQL, dependency-aware", 1, 1, 50, R / 50 > 0 ? R / 50 : 1);
-    run_seq("seq AQL, every packet ordered", 0, 1, 50, R / 50 > 0 ? R / 50 : 1);
-    run_seq("seq AQL, dep-aware, fence none", 1, 0, 50, R / 50 > 0 ? R / 50 : 1);
-    run_seq("seq AQL, dep-aware, fence system", 1, 2, 50, R / 50 > 0 ? R / 50 : 1);
-    run_seq("seq AQL, dep-aware, 1 step x 20", 1, 1, 1, 20);
-    run_seq("seq AQL, ordered, 1 step x 20", 0, 1, 1, 20);
+    const int RR = R / 50 > 0 ? R / 50 : 1;
+    run_seq("seq AQL 1 queue, dependency-aware", 1, 1, 50, RR, 1);
+    run_seq("seq AQL 1 queue, all ordered", 0, 1, 50, RR, 1);
+    run_seq("seq AQL 1 queue, dep-aware, fence none", 1, 0, 50, RR, 1);
+    run_seq("seq AQL 1 queue, fence system", 1, 2, 50, RR, 1);
+    run_seq("seq AQL, queue per component", 1, 1, 50, RR);
+    run_seq("seq AQL, queue per comp, 1 step x R", 1, 1, 1, R);
+    run_seq("seq AQL, queue per comp, all ordered", 0, 1, 50, RR);
+    run_seq("seq AQL, queue per comp, 1 step x 20", 1, 1, 1, 20);
+    run_seq("seq AQL 1 queue, 1 step x 20", 1, 1, 1, 20, 1);
     run_graph("graph, in order", inorder, s1);
     run_graph("graph, overlap window", window, s1);
     run_graph("graph, two chains (fork/join once)", two_chains_captured, s1);
