@@ -235,9 +235,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
-    ap.add_argument("--step-mode", choices=("inorder", "chains"), default="inorder",
-                    help="inorder: the step's two launches on one stream; chains: one stream-ordered chain per output array "
-                         "inside the graph (the two operations of a step are independent: both only read A)")
+    ap.add_argument("--step-mode", choices=("seq", "seq1", "inorder", "chains"), default="seq",
+                    help="seq: the library's own replay of the recorded step (smr_seq: AQL packets on its HSA queues, one queue per "
+                         "dependency component -- the step's two operations are independent, both only read A -- results of in-order "
+                         "execution); seq1: the same replay on ONE queue, in order; inorder: hipGraph, the step's two launches on one "
+                         "stream; chains: hipGraph, one stream-ordered chain per output array")
     ap.add_argument("--dry", action="store_true", help="rendezvous only (gloo, no GPU): checks that --gpus N yields N ranks")
     args = ap.parse_args()
 
@@ -290,20 +292,37 @@ def main():
         plan3.execute(s)
 
     # correctness guard inside the bench: outputs must equal the torch permutes exactly
-    step()
-    torch.cuda.synchronize()
     a4 = tA.reshape((n,) * 4)  # row-major view of the same memory: index order reversed
     # column-major (i1,i2,i3,i4) <-> torch index [i4,i3,i2,i1]
     ref2 = a4.permute(3, 2, 1, 0).contiguous().reshape(-1)
-    assert torch.equal(tB, ref2), "permutedims! result is wrong"
     cm = lambda p: a4.permute(*[3 - p[3 - i] for i in range(4)])  # noqa: E731
-    ref3 = ((cm(perms[0]) + cm(perms[1])) + cm(perms[2])) + cm(perms[3])
-    assert torch.equal(tC, ref3.contiguous().reshape(-1)), "fused 4-way broadcast result is wrong"
+    ref3 = (((cm(perms[0]) + cm(perms[1])) + cm(perms[2])) + cm(perms[3])).contiguous().reshape(-1)
+
+    def check_outputs(when):
+        torch.cuda.synchronize()
+        assert torch.equal(tB, ref2), "permutedims! result is wrong (%s)" % when
+        assert torch.equal(tC, ref3), "fused 4-way broadcast result is wrong (%s)" % when
+
+    step()
+    check_outputs("first step")
 
     K, W = args.steps, args.warmup
     for _ in range(W):
         step()
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and args.step_mode in ("inorder", "chains")
+    use_seq = not args.no_graph and args.step_mode in ("seq", "seq1")
+    seq_info = None
+    if use_seq:
+        # the recorded step, replayed by the library (csrc/smr_seq.cpp).  One smr_seq_run(K) = K steps; it returns when the
+        # replay has completed on devices without stream-side waits, smr_seq_wait covers the others.
+        seq = S.Sequence().add(plan2).add(plan3)
+        if args.step_mode == "seq1":
+            seq.set("queues", 1)
+        tB.zero_(); tC.zero_()
+        torch.cuda.synchronize()
+        seq.run(max(1, W), cur())  # untimed: builds the packets, creates the queues
+        seq.wait()
+        check_outputs("sequence warm-up")
     if use_graph:
         chunk = min(K, 500)
         while K % chunk:
@@ -314,9 +333,16 @@ def main():
             gstep = graph_of(torch, step, chunk)
         nrep = K // chunk
         gstep.replay()  # untimed: first replay uploads the graph
+    if use_seq:  # untimed rehearsal of exactly the timed call (host code paths, queue doorbells and signals warm)
+        seq.run(K, cur())
+        seq.wait()
+    tB.zero_(); tC.zero_()  # the timed region must (re)produce both outputs
     barrier()
     t0 = time.perf_counter()
-    if use_graph:
+    if use_seq:
+        seq.run(K, cur())
+        seq.wait()
+    elif use_graph:
         for _ in range(nrep):
             gstep.replay()
     else:
@@ -324,6 +350,10 @@ def main():
             step()
     barrier()
     dt = time.perf_counter() - t0
+    check_outputs("after the timed region")  # bit-exact, AFTER timing: the overlapped replay has in-order results
+    if use_seq:
+        seq_info = seq.info()
+        replay_us = float(seq_info.split("last_replay_us=")[1].split()[0])
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -351,6 +381,24 @@ def main():
     step_us = {"inorder": round(min(event_time_ms(torch, gi.replay, 2) for _ in range(7)) / reps * 1e3, 3),
                "chains": round(min(event_time_ms(torch, gc.replay, 2) for _ in range(7)) / reps * 1e3, 3)}
     del gi, gc
+
+    def seq_us(queues, nsteps):
+        """wall clock (run + wait) per step of `nsteps` replays of the recorded step; best of 7"""
+        q = S.Sequence().add(plan2).add(plan3)
+        q.set("queues", queues)
+        q.run(5, cur()); q.wait()
+        best = 1e30
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            q.run(nsteps, cur()); q.wait()
+            best = min(best, time.perf_counter() - t)
+        return round(best / nsteps * 1e6, 3), q.info()
+    step_us["seq_one_queue"], _ = seq_us(1, 2 * reps)
+    step_us["seq_queue_per_component"], sinfo = seq_us(4, 2 * reps)
+    step_us["note"] = ("inorder/chains: hipGraph replay, HIP events; seq_*: smr_seq replay of 1000 steps, host wall clock around "
+                       "smr_seq_run + smr_seq_wait (the replay does not run on a HIP stream)")
+    check_outputs("after the long replays")
     dom = ("broadcast4", ms3, bytes3, plan3) if ms3 >= ms2 else ("permutedims", ms2, bytes2, plan2)
     achieved = dom[2] / (dom[1] * 1e-3) / 1e9
     traffic = None
@@ -385,13 +433,20 @@ def main():
         out = {
             "metric": "GB/s effective HBM for @strided permutedims!+broadcast, 32^4 fp64",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / K * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / K * 1e3, 6),
+            # the library's own clock around the same K steps: first doorbell -> completion signals observed (no Python, no torch sync)
+            "ms_per_step_replay": round(replay_us / K * 1e-3, 6) if use_seq else None,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]+configs[2]: permutedims!(B,A,(4,3,2,1)) then B .= sum of 4 permuted views, "
                                    "32x32x32x32 Float64, one pair of arrays per GPU",
                        "algorithmic_bytes_per_step": bytes2 + bytes3,
-                       "launch": ("hipGraph, " + ("two stream-ordered chains (one per output array; both operations only read A), one fork / one join per graph"
-                                                 if args.step_mode == "chains" else "in order on one stream")) if use_graph else "eager",
+                       "launch": ("smr_seq replay (AQL packets on the library's HSA queues), " +
+                                  ("one queue per dependency component: the step's two operations only share the read-only input A and overlap; "
+                                   "results of in-order execution, verified bit-exactly after the timed region" if args.step_mode == "seq"
+                                   else "one queue, in recorded order") + " | " + str(seq_info)) if use_seq else
+                                 ("hipGraph, " + ("two stream-ordered chains (one per output array; both operations only read A), one fork / one join per graph"
+                                                  if args.step_mode == "chains" else "in order on one stream")) if use_graph else "eager",
                        "step_us_long_graph": step_us,
                        "parallelism": "replicas x%d (independent arrays per rank)" % world},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),

@@ -229,25 +229,34 @@ int smr_stream_destroy(void* stream);
  * smr_seq_run(seq, reps, stream) performs the recorded list `reps` times with the results of in-order
  * execution on `stream`.  On MI355X the replay does not go through HIP's launch path: every launch
  * becomes a pre-built AQL dispatch packet (kernel object of the code object HIP loaded, kernarg block
- * resident in device memory) on the library's own HSA queue, and only launches that conflict with an
- * earlier launch still in flight (read-after-write, write-after-write, write-after-read on any operand
- * or on a plan's partials) carry the AQL barrier bit -- independent launches of a step overlap on the
- * device (src/mapreduce.jl:203-223: spawn what is independent, wait where it must), and a replay costs
- * ~0.1 us of host time per launch instead of HIP's 3.6-4 us.  Work queued on `stream` before the call
- * completes first (the call waits for it on the host when the stream is busy); work queued on `stream`
- * afterwards waits for the replay (hipStreamWaitValue64 on the completion signal); smr_seq_wait blocks
- * the host until the last replay has completed (active wait on the signal: microseconds sooner than
- * hipStreamSynchronize).  A sequence holding a runtime-compiled kernel or a kernel that needs scratch
- * memory is replayed through HIP, in order (smr_seq_info tells which).  One replay per device is in
- * flight at a time.  The recorded base pointers / plans must stay alive while the sequence exists.    */
+ * resident in device memory) on HSA queues the library owns.  The recorded executions are split into
+ * dependency components -- two executions belong together when one writes bytes the other reads or
+ * writes (operand footprints and the plans' own partials) -- and every component keeps its recorded
+ * order on ONE queue, while different components run on different queues (up to 4), concurrently: the
+ * device form of src/mapreduce.jl:203-223 (spawn what is independent, wait where it must).  Inside one
+ * queue MI355X runs consecutive dispatches one after the other whatever the barrier bit says, and a
+ * kernel boundary costs 1.6-1.9 us there (profiles/r04_overlap.txt); two queues overlap one chain's
+ * boundary with the other chain's kernel.  A replay costs ~0.1 us of host time per launch instead of
+ * HIP's 3.6-4 us.  Work queued on `stream` before the call completes first (the call waits for it on
+ * the host when the stream is busy); work queued on `stream` afterwards waits for the replay
+ * (hipStreamWaitValue64 on the completion signals where the device supports it, else smr_seq_run itself
+ * returns only when the replay has completed); smr_seq_wait blocks the host until the last replay has
+ * completed (active wait on the signals: microseconds sooner than hipStreamSynchronize).  Runtime-
+ * compiled kernels take part like precompiled ones (their entry points carry a per-program name; the
+ * sequence co-owns the loaded program).  A sequence holding a kernel that needs scratch memory is
+ * replayed through HIP, in order (smr_seq_info tells which, and reports "last_replay_us": first
+ * doorbell -> completion observed).
+ * One replay per device is in flight at a time.  The recorded base pointers / plans must stay alive
+ * while the sequence exists.                                                                         */
 typedef struct smr_seq smr_seq;
 int smr_seq_create(smr_seq** out);
 int smr_seq_add(smr_seq* seq, smr_plan* plan, void* const* bases);
 int smr_seq_run(smr_seq* seq, int reps, void* stream);
 int smr_seq_wait(smr_seq* seq);
 int smr_seq_info(smr_seq* seq, char* buf, size_t buflen);
-/* experiments: "fence_scope" (acquire/release scope of the packets inside a replay: 0 none, 1 agent, 2 system),
- * "order" (0: every packet ordered, 1: dependency-aware)                                              */
+/* "queues" (1..4: hardware queues a replay may spread over; 1 = everything in recorded order on one queue).
+ * Experiments: "fence_scope" (acquire/release scope of the packets inside a replay: 0 none, 1 agent, 2 system),
+ * "order" (0: every packet carries the barrier bit, 1: only those that conflict with an earlier one in flight) */
 int smr_seq_set(smr_seq* seq, const char* name, int64_t value);
 int smr_seq_destroy(smr_seq* seq);
 

@@ -320,7 +320,9 @@ unsigned take_launch_flags();
 
 // Recording (smr_seq.cpp): while a sequence records, SMR_LAUNCH / jit_launch append what they WOULD launch instead of launching it
 struct RecLaunch {
-    const void* hostfn = nullptr;  // host stub of a precompiled kernel; nullptr = runtime-compiled (not replayable as an AQL packet)
+    const void* hostfn = nullptr;  // host stub of a precompiled kernel; nullptr = runtime-compiled: found by `kname`
+    std::string kname;             // runtime-compiled: the (per-program unique) entry point of the loaded code object
+    std::shared_ptr<void> keep;    // runtime-compiled: owner of the loaded module (it must outlive the packets that name its code)
     unsigned grid = 0, block = 0, lds = 0;
     std::vector<unsigned char> args;  // the explicit kernel arguments in kernarg-segment layout
 };

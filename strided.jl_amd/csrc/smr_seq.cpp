@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -156,6 +157,7 @@ struct Direct {
     hsa_signal_t done[SEQ_MAXQ] = {};   // completion signal of the last packet a replay put on queue k
     volatile int64_t* done_ptr[SEQ_MAXQ] = {};
     bool armed[SEQ_MAXQ] = {};          // done[k] belongs to a replay nobody waited for yet
+    double t_submit = 0, last_us = 0;   // host clock at the first doorbell of the replay in flight; doorbell -> completion observed
     std::mutex mu;                      // one replay is written at a time
     std::map<const void*, KernelRef> kernels;
     bool wait_value_ok = false;
@@ -274,6 +276,19 @@ hsa_status_t lookup_exec(hsa_executable_t ex, void* data) {
     return HSA_STATUS_INFO_BREAK;
 }
 
+// kernel name -> kernel descriptor among the executables loaded in this process
+int resolve_name(Direct& d, const std::string& name, KernelRef& out) {
+    Lookup l;
+    l.h = &hsa();
+    l.agent = d.agent;
+    l.kd = name + ".kd";
+    l.h->loader.hsa_ven_amd_loader_iterate_executables(lookup_exec, &l);
+    if (!l.have) return set_error(SMR_EUNSUPPORTED, std::string("direct dispatch: kernel descriptor not found for ") + name);
+    l.out.name = name;
+    out = l.out;
+    return SMR_OK;
+}
+
 // host stub -> kernel descriptor in the code object HIP has loaded
 int resolve_kernel(Direct& d, const void* hostfn, KernelRef& out) {
     auto it = d.kernels.find(hostfn);
@@ -286,15 +301,9 @@ int resolve_kernel(Direct& d, const void* hostfn, KernelRef& out) {
     if (e != hipSuccess) return hip_error(e, "hipFuncGetAttributes (sequence build)");
     const char* name = hipKernelNameRefByPtr(hostfn, nullptr);
     if (!name || !*name) return set_error(SMR_EUNSUPPORTED, "direct dispatch: HIP does not know the kernel's name");
-    Lookup l;
-    l.h = &hsa();
-    l.agent = d.agent;
-    l.kd = std::string(name) + ".kd";
-    l.h->loader.hsa_ven_amd_loader_iterate_executables(lookup_exec, &l);
-    if (!l.have) return set_error(SMR_EUNSUPPORTED, std::string("direct dispatch: kernel descriptor not found for ") + name);
-    l.out.name = name;
-    d.kernels[hostfn] = l.out;
-    out = l.out;
+    const int rc = resolve_name(d, name, out);
+    if (rc) return rc;
+    d.kernels[hostfn] = out;
     return SMR_OK;
 }
 
@@ -323,6 +332,7 @@ struct smr_seq {
     int max_queues = SEQ_MAXQ;
     int ncomp = 0;
     void* d_kernargs = nullptr;
+    std::vector<std::shared_ptr<void>> keep;  // runtime-compiled programs the packets name
     int64_t runs = 0;
     int n_any = 0, n_barrier = 0;
     int fence_scope_mid = 1;    // acquire / release scope of the packets inside a replay: 1 agent (default), 0 none, 2 system
@@ -344,6 +354,8 @@ bool overlaps(const Spans& v, const Spans& w) {
     return false;
 }
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 uint16_t header_of(bool barrier, int acq, int rel) {
     return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                       (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
@@ -351,6 +363,7 @@ uint16_t header_of(bool barrier, int acq, int rel) {
 
 int seq_build(smr_seq* q) {
     for (auto& v : q->packets) v.clear();
+    q->keep.clear();
     q->aql = false;
     q->n_any = q->n_barrier = 0;
     q->nq = 0;
@@ -383,12 +396,13 @@ int seq_build(smr_seq* q) {
     for (size_t i = 0; aql && i < recs.size(); ++i)
         for (const RecLaunch& l : recs[i].launches) {
             KernelRef k;
-            if (!l.hostfn) {
+            if (!l.hostfn && l.kname.empty()) {
                 aql = false;
-                q->why_not_aql = "a runtime-compiled kernel takes part";
+                q->why_not_aql = "a launch without a kernel identity takes part";
                 break;
             }
-            if (resolve_kernel(d, l.hostfn, k) != SMR_OK) {
+            if (l.keep) q->keep.push_back(l.keep);
+            if ((l.hostfn ? resolve_kernel(d, l.hostfn, k) : resolve_name(d, l.kname, k)) != SMR_OK) {
                 aql = false;
                 q->why_not_aql = smr_last_error();
                 break;
@@ -539,6 +553,7 @@ int seq_submit(smr_seq* q, Direct& d, int reps) {
             ++open_queues;
         }
     }
+    d.t_submit = now_s();
     while (open_queues > 0) {
         for (int k = 0; k < q->nq; ++k) {
             if (written[k] >= totalp[k]) continue;
@@ -573,11 +588,14 @@ int seq_submit(smr_seq* q, Direct& d, int reps) {
 
 void wait_all(Direct& d) {
     Hsa& h = hsa();
+    bool any = false;
     for (int k = 0; k < SEQ_MAXQ; ++k)
         if (d.armed[k]) {
             if (h.signal_load(d.done[k]) != 0) h.signal_wait(d.done[k], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
             d.armed[k] = false;
+            any = true;
         }
+    if (any) d.last_us = (now_s() - d.t_submit) * 1e6;
 }
 }  // namespace
 
@@ -669,8 +687,9 @@ int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
     if (q->aql) {
         size_t np = 0;
         for (const auto& v : q->packets) np += v.size();
-        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d queues=%d ordered=%d unordered=%d fence_mid=%d stream_wait=%s", q->items.size(), np,
-                      q->ncomp, q->nq, q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host");
+        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d queues=%d ordered=%d unordered=%d fence_mid=%d stream_wait=%s last_replay_us=%.3f",
+                      q->items.size(), np, q->ncomp, q->nq, q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host",
+                      direct().last_us);
     }
     else
         std::snprintf(buf, buflen, "backend=hip items=%zu (%s)", q->items.size(), q->why_not_aql.c_str());
