@@ -112,6 +112,11 @@ struct Prog {
     uint8_t code[2 * SMR_MAXPROG];
     int nconst = 0;
     double consts[2 * SMR_MAXCONST];
+    // integer class only (julia_int_types below): the width Julia's type of the value produced at pc has when it is narrower than
+    // 64 bits (0: no wrap), and its signedness.  Julia types every operation by its operands -- Int32 * Int32 is an Int32 and wraps
+    // at 32 bits, Int8(1) - Int8(2) compared as UInt8 is 255 -- and the oracle follows it operation by operation.
+    uint8_t wrap_bits[SMR_MAXPROG] = {};
+    bool wrap_signed[SMR_MAXPROG] = {};
 };
 
 template <class T> struct ops;  // scalar math per compute type
@@ -258,6 +263,13 @@ inline T eval_prog(const Prog& p, const T* args /* args[k] = value of input k (1
             T c = st[--sp];
             T b = st[--sp];
             st[sp - 1] = ops<T>::truthy(st[sp - 1]) ? b : c;
+        }
+        if constexpr (std::is_same<T, ix64>::value) {  // the value in Julia's (narrower) type of this operation
+            const int w = p.wrap_bits[pc];
+            if (w) {
+                const unsigned long long m = (1ull << w) - 1, u = (unsigned long long)st[sp - 1] & m;
+                st[sp - 1] = (p.wrap_signed[pc] && (u >> (w - 1))) ? (ix64)(u | ~m) : (ix64)u;
+            }
         }
     }
     return st[0];
@@ -941,6 +953,67 @@ int run_typed(const smr_problem* p, const Lowered& L, const Prog& prog, int nthr
     return SMR_OK;
 }
 
+// Julia's integer typing of the f-program, operation by operation (Base promotion rules: the wider type wins, equal widths of
+// mixed signedness give the unsigned type, Bool yields to every integer type and Bool (+,-,*) Bool is an Int, an integer literal is
+// an Int64).  Fills prog.wrap_bits / wrap_signed for every operation whose Julia type is narrower than 64 bits.
+void julia_int_types(const smr_problem* p, Prog& prog) {
+    struct Ty {
+        int bits;  // 1 = Bool, 8, 16, 32, 64
+        bool sgn;
+    };
+    auto of_dtype = [](int dt) {
+        Ty t;
+        t.bits = 8 << ((dt - SMR_I8) & 3);
+        t.sgn = dt < SMR_U8;
+        return t;
+    };
+    auto promote = [](Ty a, Ty b) {
+        if (a.bits == 1) return b;
+        if (b.bits == 1) return a;
+        if (a.bits != b.bits) return a.bits > b.bits ? a : b;
+        Ty t = a;
+        t.sgn = a.sgn && b.sgn;
+        return t;
+    };
+    Ty st[SMR_MAXPROG];
+    int sp = 0;
+    for (int pc = 0; pc < prog.len; ++pc) {
+        const int op = prog.code[2 * pc], imm = prog.code[2 * pc + 1];
+        bool arith = false;
+        if (op == SMR_OP_ARG) {
+            st[sp++] = of_dtype(p->ops[imm].dtype);
+        } else if (op == SMR_OP_CONST) {
+            st[sp++] = Ty{64, true};
+        } else if (op < 32) {
+            Ty& a = st[sp - 1];
+            if (op == SMR_OP_WIDEN) a = Ty{64, true};
+            if (op == SMR_OP_NEG || op == SMR_OP_ABS || op == SMR_OP_ABS2) {
+                if (a.bits == 1 && op == SMR_OP_NEG) a = Ty{64, true};  // -true is an Int
+                arith = true;
+            }
+        } else if (op < 64) {
+            const Ty b = st[--sp];
+            Ty& a = st[sp - 1];
+            if (op >= SMR_OP_LT && op <= SMR_OP_NE) {
+                a = Ty{1, false};
+            } else {
+                const bool bools = a.bits == 1 && b.bits == 1;
+                a = promote(a, b);
+                if (op == SMR_OP_ADD || op == SMR_OP_SUB || op == SMR_OP_MUL) {
+                    if (bools) a = Ty{64, true};
+                    arith = true;
+                }
+            }
+        } else {
+            const Ty c = st[--sp], b = st[--sp];
+            st[sp - 1] = promote(b, c);
+        }
+        const Ty r = st[sp - 1];
+        prog.wrap_bits[pc] = (uint8_t)((arith && r.bits > 1 && r.bits < 64) ? r.bits : 0);
+        prog.wrap_signed[pc] = r.sgn;
+    }
+}
+
 // the integer class applies when every operand is an integer type and f is closed over the integers (the same rule as
 // the device planner, csrc/smr_plan.cpp: canonicalise)
 bool integer_class(const smr_problem* p, const Prog& prog) {
@@ -954,8 +1027,11 @@ bool integer_class(const smr_problem* p, const Prog& prog) {
         const int op = prog.code[2 * pc];
         switch (op) {
             case SMR_OP_ARG: case SMR_OP_NEG: case SMR_OP_ABS2: case SMR_OP_CONJ: case SMR_OP_REAL: case SMR_OP_IMAG:
-            case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_EQ: case SMR_OP_NE: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
-            case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: ordered = true; break;
+            case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
+            // == and != belong here too: Julia compares UInt64 with signed values mathematically, a 64-bit signed domain compares bit patterns
+            case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: case SMR_OP_EQ: case SMR_OP_NE:
+                ordered = true;
+                break;
             case SMR_OP_CONST: {
                 const double re = prog.consts[2 * prog.code[2 * pc + 1]], im = prog.consts[2 * prog.code[2 * pc + 1] + 1];
                 if (im != 0.0 || !(re == std::floor(re) || std::isinf(re)) || (std::fabs(re) > 9223372036854775808.0 && !std::isinf(re))) return false;
@@ -1056,7 +1132,10 @@ int oracle_mapreduce(const smr_problem* p, int nthreads) {
     if (anyint && p->redop == SMR_RED_NONE && p->M == 2 && p->ops[0].dtype == p->ops[1].dtype &&
         prog.len == 1 && prog.code[0] == SMR_OP_ARG)
         return run_bitcopy(p, L);
-    if (integer_class(p, prog)) return run_typed<ix64>(p, L, prog, nthreads);
+    if (integer_class(p, prog)) {
+        julia_int_types(p, prog);
+        return run_typed<ix64>(p, L, prog, nthreads);
+    }
     switch (compute_class(p)) {
         case SMR_F32: return run_typed<float>(p, L, prog, nthreads);
         case SMR_F64: return run_typed<double>(p, L, prog, nthreads);

@@ -56,6 +56,7 @@ class Ref:
 # result back as a plain host array (same values, same result type as the reference; round 3: this became the
 # default, rounds 1-2 raised).  "error" is the strict mode for callers who want to see accidental host arrays.
 _PLAIN_RULE = "upload"
+_WARNED_UPLOAD = False
 
 
 def set_plain_array_rule(rule: str) -> str:
@@ -91,6 +92,13 @@ def _lower_plain(bc, like: StridedView):
 
     def up(a):
         found[0] = True
+        global _WARNED_UPLOAD
+        if not _WARNED_UPLOAD and like._device is not None:  # once per process: the copy is correct but not free
+            _WARNED_UPLOAD = True
+            import warnings
+            warnings.warn("strided_jl_amd: a broadcast mixes a StridedView with a plain host array; the array is uploaded for this call "
+                          "and the result comes back as a host array (set_plain_array_rule('error') makes this a TypeError)",
+                          RuntimeWarning, stacklevel=4)
         host = a.detach().cpu().numpy() if type(a).__module__.startswith("torch") else a
         if host.ndim == 0:
             return host.reshape(()).item()

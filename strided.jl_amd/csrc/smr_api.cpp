@@ -234,7 +234,44 @@ struct smr_plan {
     int nops = 0;  // M of the originating problem (length of a `bases` rebinding array)
     void* stream = nullptr;
     void* obase[SMR_MAXM] = {nullptr};  // the base pointers the plan was created with (aliasing pattern)
+    // plans with reduction scratch (partials + arrival counters) must not run twice at once: executions on different streams are
+    // chained through an event
+    std::mutex scratch_mu;
+    bool ran = false;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t order_ev = nullptr;
 };
+
+// Executes a plan that may own reduction scratch.  The one-launch fold (smr_k_reduce.hip: arrive_last) relies on the arrival
+// counters being zero when a launch starts and on the partials belonging to ONE execution at a time:
+//   * an execution on another stream than the previous one first waits (on the device) for that one -- two streams never run
+//     the same plan's launches concurrently (skipped while either stream is being captured: a capture cannot wait for foreign work;
+//     captured graphs replay in the order their streams impose);
+//   * an execution that failed to launch leaves nothing half-done on the device, but the counters are re-zeroed on the stream all the
+//     same, so that no earlier, aborted launch can leave a later one waiting for arrivals that never come.
+static int execute_owned(smr_plan* h, void* const* bases, hipStream_t s) {
+    if (!h->plan.scratch || jit_no_launch() || recorder()) return execute(h->plan, bases, s);
+    std::lock_guard<std::mutex> g(h->scratch_mu);
+    if (h->ran && h->last_stream != s) {
+        hipStreamCaptureStatus c1 = hipStreamCaptureStatusNone, c2 = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &c1);
+        (void)hipStreamIsCapturing(h->last_stream, &c2);
+        if (c1 == hipStreamCaptureStatusNone && c2 == hipStreamCaptureStatusNone) {
+            if (!h->order_ev) (void)hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming);
+            if (h->order_ev && hipEventRecord(h->order_ev, h->last_stream) == hipSuccess) (void)hipStreamWaitEvent(s, h->order_ev, 0);
+        }
+        (void)hipGetLastError();
+    }
+    const int rc = execute(h->plan, bases, s);
+    h->ran = true;
+    h->last_stream = s;
+    if (rc != SMR_OK) {
+        (void)hipGetLastError();
+        (void)hipMemsetAsync((char*)h->plan.scratch + h->plan.counter_off, 0, RED_COUNTERS * sizeof(unsigned), s);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
 
 static int plan_build(const smr_problem* p, smr_plan** out) {
     if (!p || !out) return set_error(SMR_EINVAL, "null argument");
@@ -279,6 +316,7 @@ static void plan_free(smr_plan* h) {
             p = nullptr;
         }
     if (h->plan.ordtab) (void)hipFree(h->plan.ordtab);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     delete h;
 }
 
@@ -520,7 +558,7 @@ int smr_plan_execute(smr_plan* plan, void* const* bases, void* stream) {
     rc = ensure_scratch(plan);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)(stream ? stream : plan->stream);
-    return execute(plan->plan, bases, s);
+    return execute_owned(plan, bases, s);
 }
 
 int smr_plan_prepare(smr_plan* plan) {
@@ -672,7 +710,7 @@ int smr_mapreduce(const smr_problem* problem) {
     // caller's at launch
     void* bases[SMR_MAXM];
     for (int k = 0; k < problem->M; ++k) bases[k] = problem->ops[k].base;
-    return execute(h->plan, bases, (hipStream_t)problem->stream);
+    return execute_owned(h.get(), bases, (hipStream_t)problem->stream);
 }
 
 int smr_shard(const smr_problem* p, int nshards, int shard, smr_problem* out, int* needs_allreduce) {

@@ -101,6 +101,12 @@ SMR_DEV void decompose(const RedArgs& a, i64 i, int d0, int d1, i64* off) {
 // relaxed atomic stores (global_store ... sc1, at most 8 bytes each) and agent-scope loads in the folding workgroup, ordered
 // by "every wave waits for its stores' acknowledgements -> barrier -> one relaxed agent-scope ticket".  No release /
 // acquire fences: buffer_wbl2 / buffer_inv cost 1.7 us each on this part, as much as the launch they would save.
+// The ordering above is a property of the gfx9 memory pipeline (vmcnt counts stores as well as loads, sc1 stores write through the
+// per-XCD L2): on targets that count stores separately (vscnt, gfx10+) the last workgroup could read stale partials.  This file is
+// built for gfx950 only (csrc/Makefile); a port must turn reduce_single off or replace the protocol by release / acquire.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "smr_k_reduce.hip: the one-launch fold relies on gfx942 / gfx950 store ordering (s_waitcnt vmcnt covers stores, sc1 write-through)"
+#endif
 template <class T>
 SMR_DEV void put_partial(const RedArgs& a, i64 idx, T v) {
     T* p = (T*)a.partials + idx;

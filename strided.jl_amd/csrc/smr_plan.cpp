@@ -69,6 +69,71 @@ static int check_prog(const ProgD& p, int M, int& maxdepth) {
     return sp == 1 ? 0 : -1;
 }
 
+// Julia types every integer operation by its operands (Int32 * Int32 wraps at 32 bits, Int8 - Int8 at 8, a literal is Int64), the
+// integer class computes everything in one 64-bit domain.  The two agree exactly when no value that Julia would have wrapped at a
+// narrower width is ever OBSERVED at a wider one.  Per stack slot: `bits` = width of Julia's type of the value, `cong` = the device
+// value is congruent to Julia's modulo 2^cong (64: identical).  Ring operations (+ - * neg abs2) keep congruences, order and equality
+// (min max abs < <= == select's condition ...) need identical operands, and the destination (width wd) observes the low wd bits.
+// UInt8 min(a - b, c) and Int32 a * b into an Int64 destination are refused here instead of returning 64-bit answers.
+static bool int_class_matches_julia(const smr_problem* p, const ProgD& prog) {
+    auto width = [](int dt) { return 8 << ((dt - SMR_I8) & 3); };  // I8 I16 I32 I64 U8 U16 U32 U64
+    struct Slot {
+        int bits, cong;
+    };
+    Slot st[STACK + 4];
+    int sp = 0;
+    for (int pc = 0; pc < prog.len; ++pc) {
+        const int op = prog.code[2 * pc], imm = prog.code[2 * pc + 1];
+        switch (op) {
+            case SMR_OP_ARG: st[sp++] = {width(p->ops[imm].dtype), 64}; break;
+            case SMR_OP_CONST: st[sp++] = {64, 64}; break;
+            case SMR_OP_CONJ: case SMR_OP_REAL: break;
+            case SMR_OP_IMAG: st[sp - 1] = {64, 64}; break;
+            case SMR_OP_WIDEN: st[sp - 1].bits = 64; break;
+            case SMR_OP_NEG: case SMR_OP_ABS2:
+                if (st[sp - 1].bits == 1) {  // Bool: -true is an Int, abs2(true) is true
+                    if (op == SMR_OP_NEG) st[sp - 1].bits = 64;
+                    break;
+                }
+                st[sp - 1].cong = std::min(st[sp - 1].cong, st[sp - 1].bits);
+                break;
+            case SMR_OP_ABS:
+                if (st[sp - 1].cong != 64) return false;
+                if (st[sp - 1].bits > 1) st[sp - 1].cong = st[sp - 1].bits;  // abs(typemin) wraps at the operand's width
+                break;
+            case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: {
+                const Slot b = st[--sp], a = st[sp - 1];
+                int w = std::max(a.bits, b.bits);  // Bool (1) yields to every integer type ...
+                if (w == 1) w = 64;                // ... and Bool (+,-,*) Bool is an Int
+                st[sp - 1] = {w, std::min({a.cong, b.cong, w})};
+                break;
+            }
+            case SMR_OP_MIN: case SMR_OP_MAX: {
+                const Slot b = st[--sp], a = st[sp - 1];
+                if (a.cong != 64 || b.cong != 64) return false;
+                st[sp - 1] = {std::max(a.bits, b.bits), 64};
+                break;
+            }
+            case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: case SMR_OP_EQ: case SMR_OP_NE: {
+                const Slot b = st[--sp], a = st[sp - 1];
+                if (a.cong != 64 || b.cong != 64) return false;
+                st[sp - 1] = {1, 64};  // Bool
+                break;
+            }
+            case SMR_OP_SELECT: {
+                const Slot c = st[--sp], b = st[--sp], a = st[sp - 1];
+                if (a.cong != 64) return false;
+                st[sp - 1] = {std::max(b.bits, c.bits), std::min(b.cong, c.cong)};
+                break;
+            }
+            default: return false;
+        }
+    }
+    const int wd = width(p->ops[0].dtype);
+    const bool ring = p->redop == SMR_RED_NONE || p->redop == SMR_RED_ADD || p->redop == SMR_RED_MUL;
+    return ring ? st[0].cong >= wd : st[0].cong == 64;
+}
+
 static void recognise(Canon& c) {
     const ProgD& p = c.prog;
     auto op = [&](int i) { return (int)p.code[2 * i]; };
@@ -179,8 +244,11 @@ int canonicalise(const smr_problem* p, Canon& c) {
             const int op = prog.code[2 * pc];
             switch (op) {
                 case SMR_OP_ARG: case SMR_OP_NEG: case SMR_OP_ABS2: case SMR_OP_CONJ: case SMR_OP_REAL: case SMR_OP_IMAG:
-                case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_EQ: case SMR_OP_NE: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
-                case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: ordered = true; break;
+                case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
+                // == and != belong here too: Julia compares UInt64 with signed values mathematically, a 64-bit signed domain compares bit patterns
+                case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: case SMR_OP_EQ: case SMR_OP_NE:
+                    ordered = true;
+                    break;
                 case SMR_OP_CONST: {
                     const double re = prog.consts[2 * prog.code[2 * pc + 1]], im = prog.consts[2 * prog.code[2 * pc + 1] + 1];
                     // integer-valued (or a +-Inf seed of a min / max reduction, which saturates to typemax / typemin)
@@ -194,7 +262,13 @@ int canonicalise(const smr_problem* p, Canon& c) {
             const double re = p->initarg[0], im = p->initarg[1];
             if (im != 0.0 || re != std::floor(re) || std::fabs(re) > 9223372036854775808.0) closed = false;
         }
-        if (allint && closed && !(has_u64 && ordered)) c.ct = SMR_I64;
+        if (allint && closed && !(has_u64 && ordered)) {
+            if (!int_class_matches_julia(p, prog))
+                return set_error(SMR_EUNSUPPORTED,
+                                 "integer operands narrower than 64 bits whose intermediate results Julia would wrap at their own width are observed "
+                                 "at a wider one (an order / equality test on them, or a wider destination): 64-bit arithmetic would differ on overflow");
+            c.ct = SMR_I64;
+        }
     }
     c.redop = p->redop;
     c.initop = p->initop;

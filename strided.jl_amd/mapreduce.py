@@ -9,6 +9,7 @@ argument checking happens before the funnel, with the reference's error types
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import operator
 
@@ -210,7 +211,7 @@ def build_problem(f, op, initop, dims, arrays, stream=None):
     return p, (codebuf, constbuf, arrays)
 
 
-_PROBLEM_CACHE: dict = {}
+_PROBLEM_CACHE: "collections.OrderedDict" = collections.OrderedDict()  # least recently used first
 _SMR_MAPREDUCE = None
 
 
@@ -257,16 +258,27 @@ def _mapreduce_fuse_(f, op, initop, dims, arrays):
         except TypeError:
             key = None
     if hit is not None:
-        p = hit[0]
+        # a private copy per call: ctypes releases the GIL inside smr_mapreduce, so two threads issuing the same keyed call on
+        # different streams must not share the struct whose `stream` field they set; the pointers inside (program,
+        # constants) stay owned by the cache entry
+        p = L.smr_problem()
+        C.memmove(C.byref(p), C.byref(hit[0]), C.sizeof(L.smr_problem))
         p.stream = _current_stream()
+        try:
+            _PROBLEM_CACHE.move_to_end(key)
+        except KeyError:  # evicted by another thread in between: `hit` keeps the buffers alive for this call
+            pass
     else:
         p, keep = build_problem(f, op, initop, dims, arrays)
         if key is not None:
-            if len(_PROBLEM_CACHE) > 1024:
-                _PROBLEM_CACHE.clear()
             # the operand parents are NOT kept alive by the cache entry: the key holds their addresses, and a new
             # array at a recycled address with the same layout and type is the same problem
-            _PROBLEM_CACHE[key] = (p, keep[:2])
+            _PROBLEM_CACHE[key] = hit = (p, keep[:2])
+            while len(_PROBLEM_CACHE) > 1024:  # least recently used first; no wholesale clear in the hot path
+                try:
+                    _PROBLEM_CACHE.popitem(last=False)
+                except KeyError:
+                    break
     L.check(_SMR_MAPREDUCE(C.byref(p)))
     return arrays[0]
 
