@@ -351,7 +351,12 @@ int smr_init_reduction(const smr_problem* problem);
  * With nranks == 1 everything degenerates to smr_mapreduce and RCCL is never loaded.       */
 int smr_comm_unique_id(void* out, size_t len);
 int smr_comm_init(int nranks, int rank, const void* unique_id, size_t len);
+/* (rank, nranks) as the COMMUNICATOR reports them (ncclCommUserRank / ncclCommCount); (0, 1) without one. */
 int smr_comm_rank(int* rank, int* nranks);
+/* Path of the RCCL library in use.  Choice: $SMR_RCCL_LIB when set; else a librccl the process has already
+ * loaded (a host that ships its own, e.g. torch/lib/librccl.so: never two copies in one process); else the
+ * system's librccl.so.1.                                                                                   */
+int smr_comm_library(char* buf, size_t buflen);
 int smr_comm_destroy(void);
 int smr_mapreduce_sharded(const smr_problem* problem);
 /* ... with block-partitioned operands (see smr_shard_ex).                                   */

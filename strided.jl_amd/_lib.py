@@ -74,7 +74,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank", "smr_comm_library",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option", "smr_overlap_begin", "smr_overlap_end", "smr_overlap_fence", "smr_stream_create", "smr_stream_destroy",
     "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_set", "smr_seq_destroy",
@@ -153,6 +153,7 @@ def load():
     lib.smr_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
     lib.smr_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.smr_comm_rank.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.smr_comm_library.argtypes = [C.c_char_p, C.c_size_t]
     lib.smr_set_option.argtypes = [C.c_char_p, C.c_int64]
     lib.smr_get_option.argtypes = [C.c_char_p]
     lib.smr_get_option.restype = C.c_int64

@@ -12,10 +12,14 @@
 //
 // RCCL is loaded lazily with dlopen (no link-time dependency; a single-GPU user never needs it).
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "smr_internal.h"
 
@@ -30,6 +34,9 @@ struct Rccl {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
+    std::string path;  // what was loaded (smr_comm_library)
 };
 
 struct CommState {
@@ -45,13 +52,42 @@ CommState& st() {
     return s;
 }
 
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) {
+        *(std::string*)data = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
+
+// Which RCCL: (1) $SMR_RCCL_LIB when set (a path; the multi-process tests point it at a shared-memory stand-in, an operator
+// at a specific build); (2) a librccl the process has ALREADY loaded -- a host that brought its own (torch ships
+// torch/lib/librccl.so) must not end up with two RCCL copies and two sets of bootstrap state in one process; (3) the
+// system library.
 int load_rccl() {
     Rccl& r = st().r;
     if (r.tried) return r.lib ? SMR_OK : set_error(SMR_EUNSUPPORTED, "librccl.so is not available");
     r.tried = true;
-    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
+    const char* forced = std::getenv("SMR_RCCL_LIB");
+    if (forced && *forced) {
+        r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) return set_error(SMR_EUNSUPPORTED, std::string("$SMR_RCCL_LIB could not be loaded: ") + dlerror());
+        r.path = forced;
+    } else {
+        std::string loaded;
+        dl_iterate_phdr(find_loaded_rccl, &loaded);
+        if (!loaded.empty()) {
+            r.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+            if (r.lib) r.path = loaded;
+        }
+        if (!r.lib)
+            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) {
+                    r.path = n;
+                    break;
+                }
+            }
     }
     if (!r.lib) return set_error(SMR_EUNSUPPORTED, "librccl.so is not available");
     r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.lib, "ncclGetUniqueId");
@@ -59,6 +95,8 @@ int load_rccl() {
     r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.lib, "ncclCommDestroy");
     r.all_reduce = (decltype(r.all_reduce))dlsym(r.lib, "ncclAllReduce");
     r.error_string = (decltype(r.error_string))dlsym(r.lib, "ncclGetErrorString");
+    r.comm_count = (decltype(r.comm_count))dlsym(r.lib, "ncclCommCount");
+    r.comm_user_rank = (decltype(r.comm_user_rank))dlsym(r.lib, "ncclCommUserRank");
     if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce) {
         dlclose(r.lib);
         r.lib = nullptr;
@@ -72,10 +110,15 @@ int nccl_error(ncclResult_t e, const char* what) {
     return set_error(SMR_EHIP, std::string(what) + ": " + (r.error_string ? r.error_string(e) : "RCCL error"));
 }
 
-// element type / count as RCCL sees a destination of `n` elements of `dtype`
-bool nccl_type(int dtype, int redop, ncclDataType_t* t, size_t* mult) {
+// element type / count as RCCL sees a destination of `n` elements of `dtype`; *stage = the element type of the dense staging
+// buffer (RCCL has no 16-bit integers: Int16 / UInt16 destinations are gathered into 32-bit staging elements -- exact -- and
+// scattered back with the truncation of a narrowing store, which is the wrapped sum / product and the exact min / max)
+bool nccl_type(int dtype, int redop, ncclDataType_t* t, size_t* mult, int* stage) {
     *mult = 1;
+    *stage = dtype;
     switch (dtype) {
+        case SMR_I16: *t = ncclInt32; *stage = SMR_I32; return true;
+        case SMR_U16: *t = ncclUint32; *stage = SMR_U32; return true;
         case SMR_F32: *t = ncclFloat32; return true;
         case SMR_F64: *t = ncclFloat64; return true;
         case SMR_C32: *t = ncclFloat32; *mult = 2; return redop == SMR_RED_ADD;  // sums are component-wise
@@ -134,7 +177,7 @@ int fill_neutral(const smr_problem* p) {
 }
 
 // dense <-> strided copy of the kept destination elements (dir 0: gather into staging, 1: scatter back)
-int copy_kept(const smr_problem* p, void* dense, int dir) {
+int copy_kept(const smr_problem* p, void* dense, int stage_dtype, int dir) {
     smr_problem c;
     std::memset(&c, 0, sizeof c);
     int64_t cnt;
@@ -146,7 +189,7 @@ int copy_kept(const smr_problem* p, void* dense, int dir) {
     smr_operand flat;
     std::memset(&flat, 0, sizeof flat);
     flat.base = dense;
-    flat.dtype = p->ops[0].dtype;
+    flat.dtype = stage_dtype;
     int64_t s = 1;
     for (int i = 0; i < c.N; ++i) {
         flat.strides[i] = s;
@@ -202,10 +245,29 @@ int smr_comm_init(int nranks, int rank, const void* unique_id, size_t len) {
     return SMR_OK;
 }
 
+// What the COMMUNICATOR says (ncclCommUserRank / ncclCommCount), not what smr_comm_init was told: a launcher that disagrees with
+// its RCCL bootstrap shows up here.  Without a communicator (single rank) the answer is (0, 1).
 int smr_comm_rank(int* rank, int* nranks) {
     std::lock_guard<std::mutex> g(st().mu);
-    if (rank) *rank = st().rank;
-    if (nranks) *nranks = st().nranks;
+    CommState& s = st();
+    int r = s.rank, n = s.nranks;
+    if (s.comm) {
+        if (!s.r.comm_count || !s.r.comm_user_rank) return set_error(SMR_EUNSUPPORTED, "this RCCL exports no ncclCommCount / ncclCommUserRank");
+        ncclResult_t e = s.r.comm_count(s.comm, &n);
+        if (e == ncclSuccess) e = s.r.comm_user_rank(s.comm, &r);
+        if (e != ncclSuccess) return nccl_error(e, "ncclCommCount / ncclCommUserRank");
+    }
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    return SMR_OK;
+}
+
+int smr_comm_library(char* buf, size_t buflen) {
+    if (!buf || !buflen) return set_error(SMR_EINVAL, "null argument");
+    std::lock_guard<std::mutex> g(st().mu);
+    int rc = load_rccl();
+    if (rc) return rc;
+    std::snprintf(buf, buflen, "%s", st().r.path.c_str());
     return SMR_OK;
 }
 
@@ -258,7 +320,8 @@ int smr_mapreduce_sharded_ex(const smr_problem* p, uint32_t local_ops) {
     if (!need) return smr_mapreduce(&sub);
     ncclDataType_t t;
     size_t mult;
-    if (!nccl_type(p->ops[0].dtype, p->redop, &t, &mult))
+    int stage = 0;
+    if (!nccl_type(p->ops[0].dtype, p->redop, &t, &mult, &stage))
         return set_error(SMR_EUNSUPPORTED, "this destination type / reduction has no RCCL all-reduce");
     if (rank != 0) {
         rc = fill_neutral(p);
@@ -268,7 +331,7 @@ int smr_mapreduce_sharded_ex(const smr_problem* p, uint32_t local_ops) {
     if (rc) return rc;
     int64_t kd[SMR_MAXN], count;
     kept_box(p, kd, &count);
-    const size_t bytes = (size_t)count * (size_t)dtype_size(p->ops[0].dtype);
+    const size_t bytes = (size_t)count * (size_t)dtype_size(stage);
     std::lock_guard<std::mutex> g(s.mu);
     if (!s.comm) return set_error(SMR_EINVAL, "smr_comm_init has not been called");
     if (bytes > s.staging_bytes) {
@@ -281,10 +344,10 @@ int smr_mapreduce_sharded_ex(const smr_problem* p, uint32_t local_ops) {
         if (e != hipSuccess) return hip_error(e, "hipMalloc(all-reduce staging)");
         s.staging_bytes = bytes;
     }
-    rc = copy_kept(p, s.staging, 0);
+    rc = copy_kept(p, s.staging, stage, 0);
     if (rc) return rc;
     static const ncclRedOp_t ops[] = {ncclSum, ncclSum, ncclProd, ncclMin, ncclMax, ncclMin /* & on 0/1 */, ncclMax /* | on 0/1 */};
     ncclResult_t e = s.r.all_reduce(s.staging, s.staging, (size_t)count * mult, t, ops[p->redop], s.comm, (hipStream_t)p->stream);
     if (e != ncclSuccess) return nccl_error(e, "ncclAllReduce");
-    return copy_kept(p, s.staging, 1);
+    return copy_kept(p, s.staging, stage, 1);
 }

@@ -154,6 +154,13 @@ def comm_rank():
     return int(r.value), int(n.value)
 
 
+def comm_library() -> str:
+    """Path of the RCCL library the C layer uses ($SMR_RCCL_LIB, else an already loaded librccl, else the system's)."""
+    buf = C.create_string_buffer(1024)
+    L.check(L.load().smr_comm_library(buf, 1024))
+    return buf.value.decode()
+
+
 def comm_destroy():
     L.check(L.load().smr_comm_destroy())
 
