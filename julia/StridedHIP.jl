@@ -19,11 +19,13 @@ import Strided: _mapreduce_fuse!
 const lib = get(ENV, "STRIDED_HIP_LIB", "libstrided_hip.so")
 const MAXN, MAXM = 8, 8
 
-# The reference is synchronous (tasks are `wait`ed, src/mapreduce.jl:214-223), so by default every funnel call ends
-# with a stream synchronisation -- which costs more than a 3 us kernel.  `StridedHIP.async!(true)` drops it: calls
-# are then only ORDERED on the library's stream (results are complete once `synchronize()` returns; `download` /
-# `copyto!(::Array, ::HipBuffer)` always synchronise, so reading a result back is safe either way).
-const ASYNC = Ref(false)
+# Calls are ORDERED on the library's stream and return as soon as they are queued (round 4; rounds 1-3 ended every funnel call
+# with a stream synchronisation, which costs more than a 3 us kernel).  That is indistinguishable from the reference's synchronous
+# behaviour (tasks are `wait`ed, src/mapreduce.jl:214-223) for a Julia program: a HipBuffer cannot be indexed on the host, and every
+# way of observing its content -- `download`, `copyto!(::Array, ::HipBuffer)`, the CPU fallback below -- synchronises first; `hipFree`
+# in the finaliser drains the device too.  `StridedHIP.async!(false)` restores a synchronisation after every call (timing with
+# `@time`, debugging); `StridedHIP.synchronize()` waits explicitly.
+const ASYNC = Ref(true)
 async!(on::Bool=true) = (ASYNC[] = on; nothing)
 synchronize() = check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))
 
@@ -131,6 +133,10 @@ function emit!(p::Prog, ::Arg)
     push!(p.code, OP_ARG, UInt8(p.nextarg))
     return p.eltypes[p.nextarg]
 end
+struct ArgK                                    # argument k of a traced closure (explicit index; `Arg` counts occurrences)
+    k::Int
+end
+emit!(p::Prog, a::ArgK) = (push!(p.code, OP_ARG, UInt8(a.k)); p.eltypes[a.k])
 function emit!(p::Prog, x::Number)
     push!(p.consts, real(x), imag(x))
     push!(p.code, OP_CONST, UInt8(length(p.consts) ÷ 2 - 1))
@@ -162,7 +168,7 @@ function emit!(p::Prog, c::CaptureArgs)
     throw(Unsupported("function $f"))
 end
 emit!(p::Prog, x) = throw(Unsupported("captured $(typeof(x))"))
-function fprogram(c::CaptureArgs, eltypes, desttype)
+function fprogram(c::Union{CaptureArgs,ArgK,Number}, eltypes, desttype)
     p = Prog(UInt8[], Float64[], 0, collect(eltypes), false)
     T = emit!(p, c)                            # dry pass: does a 64-bit type occur anywhere?
     arrays64 = any(t -> t in WIDE || t <: Integer, (desttype, eltypes...))
@@ -172,6 +178,39 @@ function fprogram(c::CaptureArgs, eltypes, desttype)
         arrays64 || push!(p.code, OP_WIDEN, 0x00)   # the 64-bit class comes from a scalar (`A32 .* 0.1`)
     end
     return p
+end
+
+# ---- plain closures: map!((x, y, z) -> sin(x) + y / exp(-abs(z)), ...) (test/othertests.jl:22-24), mapreduce(f, op, ...) ----------
+# A closure is opaque to dispatch, so it is TRACED: called once on tracer values that record every operation of the UNARY /
+# BINARY tables (and ifelse) as the same CaptureArgs tree a broadcast would have produced, with explicit argument indices.
+# `Traced{T}` carries the Julia type T the value would have, so that Base.promote_op types the trace operation by operation
+# exactly as it types a CaptureArgs tree.  Anything else the closure does with its arguments -- control flow on a comparison,
+# an untabulated function, indexing -- throws while tracing and the call falls back to the CPU method (Unsupported).
+struct Traced{T} <: Number
+    node::Any                                  # ArgK | Number | CaptureArgs
+end
+node(x::Traced) = x.node
+node(x::Number) = x
+jltype(::Traced{T}) where {T} = T
+jltype(x::Number) = typeof(x)
+traced(f, args...) = Traced{Base.promote_op(f, map(jltype, args)...)}(CaptureArgs(f, map(node, args)))
+for f in keys(UNARY)
+    @eval (::typeof($f))(x::Traced) = traced($f, x)
+end
+for f in keys(BINARY)
+    @eval (::typeof($f))(x::Traced, y::Traced) = traced($f, x, y)
+    @eval (::typeof($f))(x::Traced, y::Number) = traced($f, x, y)
+    @eval (::typeof($f))(x::Number, y::Traced) = traced($f, x, y)
+end
+Base.ifelse(c::Traced{Bool}, x::Number, y::Number) = Traced{promote_type(jltype(x), jltype(y))}(CaptureArgs(ifelse, (node(c), node(x), node(y))))
+function fprogram(f, eltypes, desttype)
+    tree = try
+        node(f(ntuple(k -> Traced{eltypes[k]}(ArgK(k)), length(eltypes))...))
+    catch e
+        throw(Unsupported("closure $(typeof(f)) could not be traced: $(typeof(e))"))   # stays on the CPU
+    end
+    tree isa Union{CaptureArgs,ArgK,Number} || throw(Unsupported("closure $(typeof(f)) returns $(typeof(tree))"))
+    return fprogram(tree, eltypes, desttype)
 end
 # map!'s plain functions: identity / conj / a few arities of + and *
 fprogram(::typeof(identity), eltypes, desttype) = Prog(UInt8[OP_ARG, 1], Float64[], 1, DataType[], false)
@@ -183,7 +222,6 @@ function fprogram(f::Union{typeof(+),typeof(*)}, eltypes, desttype)
     end
     return p
 end
-fprogram(f, eltypes, desttype) = throw(Unsupported("closure $(typeof(f))"))   # arbitrary closures stay on the CPU
 
 const REDOPS = Dict(nothing => 0, (+) => 1, Base.add_sum => 1, (*) => 2, Base.mul_prod => 2, min => 3, max => 4, (&) => 5, (|) => 6)
 redcode(op) = get(() -> throw(Unsupported("reduction $op")), REDOPS, op)
@@ -210,7 +248,7 @@ function _mapreduce_fuse!(f, op, initop, dims::Dims, arrays::Tuple{HipView,Varar
             # ranks and all-reduces a split reduced dim; with a single rank it is plain smr_mapreduce.  An `f`
             # without a precompiled functor is compiled for gfx950 on first use (library-side, cached).
             check(ccall((:smr_mapreduce_sharded, lib), Cint, (Ptr{SmrProblem},), p))
-            ASYNC[] || synchronize()          # the reference is synchronous; async!(true): ordered on the stream only
+            ASYNC[] || synchronize()          # async!(false): wait for the result before returning
         end
     catch e
         e isa Unsupported || rethrow()

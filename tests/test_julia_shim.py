@@ -99,4 +99,11 @@ def test_shim_surface_required_by_the_reference():
     # every ccall names a function the header declares
     for fn in set(re.findall(r"ccall\(\(:(\w+), lib\)", SRC)):
         assert re.search(r"\b" + fn + r"\(", HDR), fn
-    assert len(SRC.splitlines()) <= 230
+    assert len(SRC.splitlines()) <= 270
+    # plain closures are traced (map!((x, y, z) -> sin(x) + y / exp(-abs(z)), ...) stayed on the CPU): tracer methods are
+    # generated for EVERY entry of the UNARY / BINARY tables and for ifelse, typed with Base.promote_op like the CaptureArgs walk
+    assert "struct Traced{T} <: Number" in SRC and "for f in keys(UNARY)" in SRC and "for f in keys(BINARY)" in SRC
+    assert re.search(r"@eval \(::typeof\(\$f\)\)\(x::Traced, y::Number\)", SRC) and re.search(r"@eval \(::typeof\(\$f\)\)\(x::Number, y::Traced\)", SRC)
+    assert "Base.ifelse(c::Traced{Bool}" in SRC and "Base.promote_op(f, map(jltype, args)...)" in SRC
+    assert "could not be traced" in SRC                      # a closure that cannot be traced still falls back to the CPU
+    assert SRC.index("struct ArgK") < SRC.index("function fprogram(c::Union{CaptureArgs,ArgK,Number}")
