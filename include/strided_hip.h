@@ -254,7 +254,9 @@ int smr_seq_add(smr_seq* seq, smr_plan* plan, void* const* bases);
 int smr_seq_run(smr_seq* seq, int reps, void* stream);
 int smr_seq_wait(smr_seq* seq);
 int smr_seq_info(smr_seq* seq, char* buf, size_t buflen);
-/* "queues" (1..4: hardware queues a replay may spread over; 1 = everything in recorded order on one queue).
+/* "queues" (1..8, default 4: hardware queues a replay may spread over; 1 = everything in recorded order on one queue; more than 4
+ * are time-multiplexed by the hardware scheduler), "slices" (1..8, default 1: a component that consists of ONE launch of independent
+ * workgroups is cut into that many contiguous block ranges, one queue each -- the device form of _mapreduce_threaded!'s bisection).
  * Experiments: "fence_scope" (acquire/release scope of the packets inside a replay: 0 none, 1 agent, 2 system),
  * "order" (0: every packet carries the barrier bit, 1: only those that conflict with an earlier one in flight) */
 int smr_seq_set(smr_seq* seq, const char* name, int64_t value);
@@ -371,7 +373,8 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * "reduce_blocks", "reduce_part_kind" (-1 auto, 0 general, 1 row, 2 col), "reduce_col_txlog",
  * "reduce_part_wgs" (partial reductions with fewer workgroups are split until about this many run), "reduce_col_narrow",
  * "reduce_single" (split reductions of at most this many chunks fold their partials inside the same launch; 0 = always a
- * second launch; a plan that owns partials must not run concurrently with itself on two streams),
+ * second launch; a plan that owns partials must not run concurrently with itself on two streams), "reduce_tree" (up to this many
+ * chunks fold inside the launch through two levels of arrival counters; 0 = off),
  * "jit" (runtime compilation of f on/off), "orbit" (ORBIT family on/off),
  * "orbit_lg" / "orbit_min" / "orbit_few" (orbit tile edge and thresholds), "orbit_pipe" (persistent
  * pipelined orbits: -1 auto, 0, 1), "nt_store" (non-temporal stores: -1 auto, 0 never, 1 always),
@@ -379,7 +382,7 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * leading dims that are not powers of two, on/off), "flat2" (its two-sided form: 0 off, 1 planner's rule, 2 wherever it applies) /
  * "flat2_bytes" / "flat2_lead_bytes", "reduce_row_floor", "reduce_row_dense", "tile_block" (block tile order for distinct arrays with several unit
  * axes: -1 auto, 0 off, n), "tile_block_xcd", "orbit_group", "orbit_minrun", "orbit_wgs".  Experiment
- * switches: "stream_u", "orbit_lds_min", "orbit_skew", "tile_block_min_axes"; "stamp_base" / "stamp_cap" / "stamp_used" (debug build
+ * switches: "stream_u", "stream_pack_rows", "orbit_lds_min", "orbit_skew", "tile_block_min_axes"; "stamp_base" / "stamp_cap" / "stamp_used" (debug build
  * with device-side wall-clock stamps, csrc/smr_device.h).  Read-only counters through
  * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms", "overlap_any" / "overlap_ordered" /
  * "overlap_fences" (launches dispatched without / with the barrier bit inside overlap windows, fences issued).      */

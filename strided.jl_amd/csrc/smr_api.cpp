@@ -799,6 +799,8 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "jit") o.jit = value;
     else if (n == "tiled_persist") o.tiled_persist = value;
     else if (n == "stream_u") o.stream_u = value;
+    else if (n == "stream_pack_rows") o.stream_pack_rows = value;
+    else if (n == "reduce_tree") o.reduce_tree = value;
     else if (n == "tiled_persist_wpc") o.tiled_persist_wpc = value;
     else if (n == "tiled_persist_min") o.tiled_persist_min = value;
     else if (n == "reduce_part_kind") o.reduce_part_kind = value;
@@ -858,6 +860,8 @@ int64_t smr_get_option(const char* name) {
     if (n == "jit") return o.jit;
     if (n == "tiled_persist") return o.tiled_persist;
     if (n == "stream_u") return o.stream_u;
+    if (n == "stream_pack_rows") return o.stream_pack_rows;
+    if (n == "reduce_tree") return o.reduce_tree;
     if (n == "tiled_persist_wpc") return o.tiled_persist_wpc;
     if (n == "tiled_persist_min") return o.tiled_persist_min;
     if (n == "reduce_part_kind") return o.reduce_part_kind;

@@ -138,6 +138,7 @@ template <class... A> inline void record_launch(std::vector<RecLaunch>* rec, con
     r.block = block;
     r.lds = (unsigned)lds;
     (void)std::initializer_list<int>{(pack_arg(r.args, a), 0)...};
+    take_slice_mark(r);
     rec->push_back(std::move(r));
 }
 #define SMR_LAUNCH(kern, grid, block, lds, s, ...)                                                                     \

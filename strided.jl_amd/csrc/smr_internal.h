@@ -219,6 +219,7 @@ struct Plan {
 };
 
 // Options (smr_set_option)
+constexpr int RED_SHARDS = 16;       // shard partials per output of the two-level in-launch fold
 constexpr int RED_COUNTERS = 16384;  // arrival counters per reduction plan (one per output group of a split reduction)
 struct Options {
     i64 force_family = 0;
@@ -248,6 +249,9 @@ struct Options {
     i64 tiled_persist_min = 32; // ... used when the work list holds at least this many rounds (measured: 64^4 / 4000^2
                                 // problems with ~16 rounds are 2-12 % faster in the classic form, 128^4 / 8192^2 ones 6-18 % slower)
     i64 stream_u = 0;           // experiment: vectors per lane of the STREAM family (runtime-compiled functors only)
+    i64 reduce_tree = 0;        // split reductions of up to this many chunks (beyond reduce_single) fold inside the launch through TWO levels of arrival
+                                // counters (shards of ~sqrt(chunks)); 0: a second launch folds, as in rounds 1-3
+    i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
@@ -324,9 +328,17 @@ struct RecLaunch {
     std::string kname;             // runtime-compiled: the (per-program unique) entry point of the loaded code object
     std::shared_ptr<void> keep;    // runtime-compiled: owner of the loaded module (it must outlive the packets that name its code)
     unsigned grid = 0, block = 0, lds = 0;
+    // The launcher's statement that the workgroups of this launch are independent and that a contiguous block range [lo, hi) can be
+    // launched on its own (smr_seq.cpp cuts single-launch components into such ranges, one hardware queue each):
+    //   1: the 32-bit field at byte `slice_off` of the argument block is added to blockIdx.x by the kernel (set it to lo);
+    //   2: the pointer at byte `slice_off` addresses a table with one row of `slice_row` bytes per workgroup (advance it by lo rows).
+    int slice_kind = 0;
+    unsigned slice_off = 0, slice_row = 0;
     std::vector<unsigned char> args;  // the explicit kernel arguments in kernarg-segment layout
 };
 std::vector<RecLaunch>* recorder();  // thread-local, nullptr when nothing records
+void mark_sliceable(int kind, unsigned off, unsigned row);  // applies to the NEXT recorded launch of the calling thread (no-op when nothing records)
+void take_slice_mark(RecLaunch& r);
 void set_recorder(std::vector<RecLaunch>* r);
 
 // launchers (one per kernel TU)

@@ -531,6 +531,7 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
         }
+        if (!PIPE) mark_sliceable(2, (unsigned)offsetof(OrbitArgs, list), (unsigned)(NG * sizeof(uint32_t)));  // one table row per workgroup
         SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, a, f SMR_STAMP_ARG(grid, block));
         return check_launch("k_orbit_map");
     }

@@ -40,6 +40,14 @@ struct RedArgs {
     i64 nkb0;         // COL: workgroups along kept dim 0
     unsigned* counters;  // one-launch split reductions: arrival counter per output group (zero between launches)
     int32_t single;      // 1: the last workgroup to arrive folds the partials; 0: a second launch does
+    // two-level arrival (round 4): a device-scope ticket costs ~12 ns and tickets on ONE counter serialise -- 512 chunks on one
+    // counter are 6 us.  With nshard > 0 chunk sp arrives at counter [group * nshard + sp % nshard]; the last arrival of a shard
+    // folds that shard's partials into ONE shard partial (partials2[o * nshard + shard]) and arrives at the group's second-level
+    // counter [ngroups * nshard + group]; the last of the nshard shards folds the shard partials and writes the destination.
+    // Fold order is fixed by the lane layout, not by who arrives when: results are reproducible run to run.
+    int32_t nshard;
+    int32_t cpad;        // counter stride in the two-level form: 32 (one counter per 128-byte line) whenever the counters fit that way
+    void* partials2;
 };
 
 template <class T>
@@ -126,8 +134,14 @@ SMR_DEV void put_partial(const RedArgs& a, i64 idx, T v) {
     }
 }
 template <class T>
-SMR_DEV T get_partial(const RedArgs& a, i64 idx) {
-    const T* p = (const T*)a.partials + idx;
+SMR_DEV void put_shard_partial(const RedArgs& a, i64 idx, T v) {  // always write-through: only the one-launch form has shards
+    RedArgs b = a;
+    b.partials = a.partials2;
+    put_partial<T>(b, idx, v);
+}
+template <class T>
+SMR_DEV T get_partial_from(const RedArgs& a, const void* base, i64 idx) {
+    const T* p = (const T*)base + idx;
     if (!a.single) return *p;
     T v;
     if constexpr (sizeof(T) == 4) {
@@ -141,11 +155,14 @@ SMR_DEV T get_partial(const RedArgs& a, i64 idx) {
     }
     return v;
 }
+template <class T>
+SMR_DEV T get_partial(const RedArgs& a, i64 idx) { return get_partial_from<T>(a, a.partials, idx); }
 // Called by every thread of a workgroup after its partials were stored; true in the workgroup that arrived last of the
 // `nparts` sharing counter `group` (it may then read all their partials).  The last one also zeroes the counter for the
 // next launch of this plan.
 SMR_DEV bool arrive_last(const RedArgs& a, i64 group, int nparts) {
     __shared__ int s_last;
+    __syncthreads();  // s_last may still be read by a previous arrival of this workgroup (two-level form)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -318,10 +335,13 @@ __global__ void __launch_bounds__(256) k_reduce_final(RedArgs a) {
 // fold of the nsplit partials of outputs [obase, obase + ocount) by one workgroup: 2^lpolog consecutive lanes per output
 // walk its partials (slot order fixed by the lane layout), wave butterfly, epilogue.  Used by the workgroup that arrived
 // last (one-launch form) and, one output group per workgroup, by nothing else: the two-launch form has its own kernel.
-template <class T, bool MIXED>
-SMR_DEV void fold_part(const RedArgs& a, int redop, i64 obase, int ocount) {
+// MODE 0: all nsplit partials of every output -> destination.  MODE 1: the partials of shard `sh` (chunks sh, sh + nshard, ...) ->
+// the output's shard partial.  MODE 2: the nshard shard partials -> destination.
+template <class T, bool MIXED, int MODE = 0>
+SMR_DEV void fold_part(const RedArgs& a, int redop, i64 obase, int ocount, int sh = 0) {
+    const int n = MODE == 0 ? a.nsplit : (MODE == 1 ? (a.nsplit - sh + a.nshard - 1) / a.nshard : a.nshard);
     int lpolog = 0;
-    while (lpolog < 6 && (ocount << (lpolog + 1)) <= 256 && (2 << lpolog) <= a.nsplit) ++lpolog;
+    while (lpolog < 6 && (ocount << (lpolog + 1)) <= 256 && (2 << lpolog) <= n) ++lpolog;
     const int lpo = 1 << lpolog;
     const int l = threadIdx.x & (lpo - 1);
     const int per = 256 >> lpolog;
@@ -333,23 +353,50 @@ SMR_DEV void fold_part(const RedArgs& a, int redop, i64 obase, int ocount) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = neutral<T>(redop);
         if (live) {
-            const i64 p = o * a.nsplit;
-            for (int i = l; i < a.nsplit; i += 4 * lpo) {
+            for (int i = l; i < n; i += 4 * lpo) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (i + j * lpo < a.nsplit) acc[j] = red_apply<T>(redop, acc[j], get_partial<T>(a, p + i + j * lpo));
+                for (int j = 0; j < 4; ++j) {
+                    const int ii = i + j * lpo;
+                    if (ii < n) {
+                        T x;
+                        if constexpr (MODE == 0) x = get_partial<T>(a, o * a.nsplit + ii);
+                        else if constexpr (MODE == 1) x = get_partial<T>(a, o * a.nsplit + sh + (i64)ii * a.nshard);
+                        else x = get_partial_from<T>(a, a.partials2, o * a.nshard + ii);
+                        acc[j] = red_apply<T>(redop, acc[j], x);
+                    }
+                }
             }
         }
         T v = red_apply<T>(redop, red_apply<T>(redop, acc[0], acc[1]), red_apply<T>(redop, acc[2], acc[3]));
         v = wave_reduce(v, redop, lpo);
         if (live && l == 0) {
-            i64 ooff[MAXM];
+            if constexpr (MODE == 1) {
+                put_shard_partial<T>(a, o * a.nshard + sh, v);
+            } else {
+                i64 ooff[MAXM];
 #pragma unroll
-            for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
-            decompose(a, o, 0, a.NK, ooff);
-            epilogue<T, MIXED>(a, ooff[0], v);
+                for (int k = 0; k < MAXM; ++k) ooff[k] = 0;
+                decompose(a, o, 0, a.NK, ooff);
+                epilogue<T, MIXED>(a, ooff[0], v);
+            }
         }
     }
+}
+// The in-launch fold of output group `group` (outputs [obase, obase + ocount)) after this workgroup -- chunk `sp` -- has stored its
+// partials: one level of tickets, or two (RedArgs::nshard).
+template <class T, bool MIXED>
+SMR_DEV void fold_in_launch(const RedArgs& a, int redop, i64 group, i64 sp, i64 obase, int ocount) {
+    if (a.nshard <= 0) {
+        if (!arrive_last(a, group, a.nsplit)) return;
+        fold_part<T, MIXED, 0>(a, redop, obase, ocount);
+        return;
+    }
+    const int sh = (int)(sp % a.nshard);
+    const int members = (a.nsplit - sh + a.nshard - 1) / a.nshard;
+    if (!arrive_last(a, (group * a.nshard + sh) * a.cpad, members)) return;
+    fold_part<T, MIXED, 1>(a, redop, obase, ocount, sh);
+    if (!arrive_last(a, ((i64)a.ngroups * a.nshard + group) * a.cpad, a.nshard)) return;
+    fold_part<T, MIXED, 2>(a, redop, obase, ocount);
 }
 
 // ---- partial reduction ----------------------------------------------------------------------------
@@ -409,9 +456,8 @@ SMR_DEV void reduce_part_impl(const RedArgs& a, F f) {
             put_partial<T>(a, o * a.nsplit + sp, acc);
     }
     if (a.nsplit > 1 && a.single) {
-        if (!arrive_last(a, og, a.nsplit)) return;
         const i64 left = a.nout - og * ob;
-        fold_part<T, MIXED>(a, redop, og * ob, (int)(left < ob ? left : ob));
+        fold_in_launch<T, MIXED>(a, redop, og, sp, og * ob, (int)(left < ob ? left : ob));
     }
 }
 template <class T, class F, bool MIXED>
@@ -557,9 +603,8 @@ SMR_DEV void reduce_row_impl(const RedArgs& a, F f) {
             put_partial<T>(a, o * a.nsplit + sp, v);
     }
     if (a.nsplit > 1 && a.single) {
-        if (!arrive_last(a, og, a.nsplit)) return;
         const i64 ob = 256 >> glog, left = a.nout - og * ob;
-        fold_part<T, MIXED>(a, redop, og * ob, (int)(left < ob ? left : ob));
+        fold_in_launch<T, MIXED>(a, redop, og, sp, og * ob, (int)(left < ob ? left : ob));
     }
 }
 template <class T, class F, bool MIXED, int V>
@@ -710,9 +755,8 @@ SMR_DEV void reduce_col_impl(const RedArgs& a, F f) {
         }
     }
     if (a.nsplit > 1 && a.single) {
-        if (!arrive_last(a, kb, a.nsplit)) return;
         const i64 per = (i64)TX * V, ibeg = c0 * per, left = a.dims[0] - ibeg;
-        fold_part<T, MIXED>(a, redop, krest * a.dims[0] + ibeg, (int)(left < per ? left : per));
+        fold_in_launch<T, MIXED>(a, redop, kb, sp, krest * a.dims[0] + ibeg, (int)(left < per ? left : per));
     }
 }
 template <class T, class F, bool MIXED, int V>
@@ -893,6 +937,24 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     int nsplit = (plan.part_split > 1 && have_scratch) ? plan.part_split : 1;
     a.nsplit = nsplit;
     a.single = (nsplit > 1 && nsplit <= options().reduce_single) ? 1 : 0;
+    a.nshard = 0;
+    a.partials2 = nullptr;
+    // more chunks than one counter takes cheaply: two levels of tickets (shards of about sqrt(nsplit), at most RED_SHARDS -- the
+    // plan's scratch holds RED_SHARDS shard partials per output behind the chunk partials)
+    const bool tree = nsplit > options().reduce_single && options().reduce_tree > 0 && nsplit <= options().reduce_tree;
+    if (tree) {
+        int ns = 2;
+        while (ns < RED_SHARDS && ns * ns < nsplit) ns <<= 1;
+        a.single = 1;
+        a.nshard = ns;
+        a.partials2 = (char*)plan.scratch + (size_t)c.nout * (size_t)plan.part_split * sizeof(T);
+    }
+    a.cpad = 1;
+    auto counters_fit = [&](i64 groups) {
+        const i64 n = groups * (a.nshard > 0 ? a.nshard + 1 : 1);
+        if (a.nshard > 0 && n * 32 <= RED_COUNTERS) a.cpad = 32;
+        return n <= RED_COUNTERS;
+    };
     a.xsplit = a.qsplit = 1;
     i64 blocks = 0;
     int rc;
@@ -904,7 +966,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         const int ob = 256 / a.tr;
         const i64 groups = (c.nout + ob - 1) / ob;
         a.ngroups = (int32_t)groups;
-        if (groups > RED_COUNTERS) a.single = 0;
+        if (!counters_fit(groups)) a.single = a.nshard = 0;
         a.chunk = ((a.nred + nsplit - 1) / nsplit + a.tr - 1) / a.tr * a.tr;
         blocks = groups * nsplit;
         if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
@@ -935,7 +997,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             a.xchunk = ((a.L0 + a.xsplit - 1) / a.xsplit + unit - 1) / unit * unit;
             const i64 groups = (c.nout + (256 >> (a.g0log + a.g1log)) - 1) / (256 >> (a.g0log + a.g1log));
             a.ngroups = (int32_t)groups;
-        if (groups > RED_COUNTERS) a.single = 0;
+            if (!counters_fit(groups)) a.single = a.nshard = 0;
             blocks = groups * nsplit;
             if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
             rc = SMR_OK;
@@ -953,7 +1015,7 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             a.nkb0 = (c.dims[0] + per - 1) / per;
             const i64 groups = a.nkb0 * (c.nout / c.dims[0]);
             a.ngroups = (int32_t)groups;
-        if (groups > RED_COUNTERS) a.single = 0;
+            if (!counters_fit(groups)) a.single = a.nshard = 0;
             blocks = groups * nsplit;
             if (blocks > 0x7fffffffLL || groups > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "reduce grid too large");
             rc = SMR_OK;

@@ -18,6 +18,8 @@ struct StreamArgs {
     i64 bpr;   // workgroups per row
     int32_t txlog, nts;   // nts: non-temporal stores (big streaming outputs, Options::nt_store); txlog 8: a workgroup covers U x 256 vectors of ONE row; < 8 (short rows): 2^txlog lanes
                           // along dim 0 x (256 >> txlog) x U entries of dim 1 -- then `rows` counts dims >= 2
+    int32_t ncc, packed;  // packed (round 4): rows of 129 .. 128*U vectors -- the packed form with 256 lanes along dim 0, ncc column chunks per row and U / ncc entries
+                          // of dim 1 per workgroup (the one-row form leaves (U - ncc) / U of every lane's slots empty: rows of 257 Float64 moved 2 KiB per workgroup)
     i64 dims[MAXN];
     i64 strides[MAXM][MAXN];
 };
@@ -27,7 +29,7 @@ struct alignas(sizeof(T) * V) Vec {
     T v[V];
 };
 
-template <class T, class F, bool MIXED, int V, int U, bool FLAT>
+template <class T, class F, bool MIXED, int V, int U, int FORM>  // FORM 0: one row segment per workgroup; 1: packed short rows; 2: packed rows of several column chunks
 SMR_DEV void stream_map_body(const StreamArgs a, F f) {
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     i64 row = 0, cb = blockIdx.x;
@@ -35,8 +37,9 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
         row = cb / a.bpr;
         cb -= row * a.bpr;
     }
-    const int txlog = FLAT ? 8 : a.txlog;
-    constexpr bool flat = FLAT;            // one row segment per workgroup (compile-time: the classic form stays lean)
+    constexpr bool flat = FORM == 0;       // one row segment per workgroup (compile-time: the classic form stays lean)
+    const int txlog = (FORM != 1) ? 8 : a.txlog;
+    const int ncc = (FORM == 2) ? a.ncc : 1, rpw = (FORM == 2) ? U / ncc : U;  // packed form: column chunks per row, rows per lane
     const int dfirst = flat ? 1 : 2;       // first dim resolved per workgroup (scalar arithmetic)
     const int tx = threadIdx.x & ((1 << txlog) - 1), ty = threadIdx.x >> txlog, TY = 256 >> txlog;
     i64 roff[MAXM];
@@ -68,9 +71,16 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
             col[u] = (cb * U + u) * 256 + threadIdx.x;
             live[u] = col[u] < a.n0v;
         } else {
-            col[u] = tx;
-            j = (cb * U + u) * TY + ty;
-            live[u] = tx < a.n0v && j < a.dims[1];
+            if constexpr (FORM == 2) {
+                const int cc = u % ncc, jj = u / ncc;
+                col[u] = tx + ((i64)cc << 8);
+                j = cb * rpw + jj;
+                live[u] = col[u] < a.n0v && j < a.dims[1] && jj < rpw;
+            } else {
+                col[u] = tx;
+                j = (cb * U + u) * TY + ty;
+                live[u] = tx < a.n0v && j < a.dims[1];
+            }
         }
 #pragma unroll
         for (int k = 0; k < MAXM; ++k) joff[u][k] = (k < a.M) ? (flat ? roff[k] : roff[k] + j * a.strides[k][1]) : 0;
@@ -141,10 +151,10 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
 }
 
 #ifndef SMR_JIT
-template <class T, class F, bool MIXED, int V, int U, bool FLAT>
+template <class T, class F, bool MIXED, int V, int U, int FORM>
 __global__ void __launch_bounds__(256) k_stream_map(StreamArgs a, F f SMR_STAMP_PARAM) {
     SMR_STAMP_BEGIN
-    stream_map_body<T, F, MIXED, V, U, FLAT>(a, f);
+    stream_map_body<T, F, MIXED, V, U, FORM>(a, f);
     SMR_STAMP_END
 }
 
@@ -176,25 +186,41 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     // short rows (sub-boxes): pack (256 >> txlog) entries of dim 1 into a workgroup instead of leaving
     // most of its lanes idle (measured on 100-element rows: 0.93 -> TB/s below)
     a.txlog = 8;
+    a.ncc = 1;
+    a.packed = 0;
     if (c.N >= 2 && a.n0v <= 128) {
         a.txlog = 0;
         while ((1 << a.txlog) < a.n0v) ++a.txlog;
+        a.packed = 1;
+    } else if (c.N >= 2 && U >= 2 && a.n0v <= 128 * U && options().stream_pack_rows) {
+        // measured (tools/stream_pack_ab.py, profiles/r04_stream_pack_ab.txt): one or two column chunks per row win (rows of 257 Float64
+        // 13.5 -> 12.0 us, 300 / 400 11.5 -> 8.4 us, Float32 rows of 700 / 1000 11.9 -> 8.7 / 12.2 -> 10.7 us), three lose
+        // (513, 561: 15.3 -> 18.0 us), and so do problems that are left with fewer than ~1000 workgroups ((257,33,31): 3.3 -> 4.4 us)
+        const int ncc = (int)((a.n0v + 255) / 256);
+        i64 nrows = 1;
+        for (int i = 1; i < c.N; ++i) nrows *= c.dims[i];
+        if (ncc <= 2 && nrows / (U / ncc) >= 1024) {
+            a.ncc = ncc;
+            a.packed = 1;
+        }
     }
     a.rows = 1;
-    for (int i = (a.txlog == 8 ? 1 : 2); i < c.N; ++i) a.rows *= c.dims[i];
-    a.bpr = (a.txlog == 8) ? (a.n0v + 256 * U - 1) / (256 * U) : (c.dims[1] + (256 >> a.txlog) * U - 1) / ((256 >> a.txlog) * U);
+    for (int i = (a.packed ? 2 : 1); i < c.N; ++i) a.rows *= c.dims[i];
+    const i64 rows_per_wg = (i64)(256 >> a.txlog) * (U / a.ncc);
+    a.bpr = !a.packed ? (a.n0v + 256 * U - 1) / (256 * U) : (c.dims[1] + rows_per_wg - 1) / rows_per_wg;
     for (int i = 0; i < MAXN; ++i) a.dims[i] = (i < c.N) ? c.dims[i] : 1;
     for (int k = 0; k < MAXM; ++k)
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
     const i64 grid = a.bpr * a.rows;
     if (grid > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "stream grid too large");
+    const int form = !a.packed ? 0 : (a.txlog < 8 ? 1 : 2);
     if constexpr (is_jit<F>::value) {
         JitLaunch l;
         l.family = "stream";
         l.tname = tname<T>();
         l.argtype = "smr::StreamArgs";
         l.entry = std::string("smr::stream_map_body<") + tname<T>() + ", smr::FJit, " + (MIXED ? "true" : "false") + ", " +
-                  std::to_string(V) + ", " + std::to_string(U) + ", " + (a.txlog == 8 ? "true" : "false") + ">(a, smr::FJit{kc});";
+                  std::to_string(V) + ", " + std::to_string(U) + ", " + std::to_string(form) + ">(a, smr::FJit{kc});";
         l.grid = (unsigned)grid;
         l.block = 256;
         l.args = &a;
@@ -203,10 +229,12 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        if (a.txlog == 8)
-            SMR_LAUNCH((k_stream_map<T, F, MIXED, V, U, true>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
+        if (form == 0)
+            SMR_LAUNCH((k_stream_map<T, F, MIXED, V, U, 0>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
+        else if (form == 1)
+            SMR_LAUNCH((k_stream_map<T, F, MIXED, V, U, 1>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
         else
-            SMR_LAUNCH((k_stream_map<T, F, MIXED, V, U, false>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
+            SMR_LAUNCH((k_stream_map<T, F, MIXED, V, U, 2>), dim3((unsigned)grid), dim3(256), 0, s, a, f SMR_STAMP_ARG(grid, 256));
         return check_launch("k_stream_map");
     }
 }

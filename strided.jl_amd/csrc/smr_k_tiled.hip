@@ -89,7 +89,9 @@ template <bool WIDE>
 struct TiledArgs {
     // header + tile decode first: they arrive with the first batch of scalar loads
     int32_t M, ng, tilelog, nstaged, base32, nt, ordmode, nwork;  // nwork: entries of the work list (persistent form)
-    int32_t nts, pad_[3];  // nts: non-temporal stores (small destinations: see Options::nt_store)
+    int32_t nts;           // nts: non-temporal stores (small destinations: see Options::nt_store)
+    uint32_t blk0;         // first workgroup of a block-range slice (smr_seq.cpp); 0 for a whole launch.  One-shot form only
+    int32_t pad_[2];
     int32_t staged[MAXM];  // [1 + i]: LDS slot of input i or -1 ([0] unused)
     uint32_t ntiles[MAXN], div_m[MAXN], div_s[MAXN], last_ragged[MAXN];
     const LaneRow<WIDE>* lanetab;  // [(operand k) * T + tid], k = 0 destination
@@ -190,7 +192,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     }
 
     // ---- which tile ---------------------------------------------------------------------------------
-    uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x + a.blk0;
     if constexpr (ORD) {
         // locality-aware tile order (smr_plan.cpp: plan_tile_order).  The in-kernarg lookup is
         // issued unconditionally so that it travels with the first batch of scalar loads.
@@ -761,6 +763,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
             }
+            mark_sliceable(1, (unsigned)offsetof(TiledArgs<WIDE>, blk0), 0);  // a workgroup owns its tile: block ranges are independent
             SMR_LAUNCH(kern, dim3(grid_), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(grid_, 1u << THRLOG));
             return check_launch("k_tiled_map");
         }

@@ -910,6 +910,23 @@ static bool short_dim0_transposition(const Canon& c, int k, int es) {
     return d0 > 0 && dk > 0 && d0 != dk;
 }
 
+// The dim along which operand k's memory advances least: its unit-stride dim, or -- a stepped range, A[1:3:end, :] seen through a
+// permutation -- a dim whose step is 2..4 elements: lanes laid along it still share cache lines (a third of each at step 3), where
+// lanes laid along the destination's dim 0 would touch one line each (round 4; `step-3 cols transpose-add` 0.6 TB/s in r2 / r3).
+static int near_axis(const Canon& c, int k) {
+    int q = fast_axis(c, k);
+    if (q >= 0) return q;
+    i64 best = 5;
+    for (int i = 0; i < c.N; ++i) {
+        const i64 s = std::llabs(c.strides[k][i]);
+        if (c.dims[i] > 1 && s >= 2 && s < best) {
+            best = s;
+            q = i;
+        }
+    }
+    return q;
+}
+
 static bool plan_tiles(const Canon& c, TilePlan& t) {
     if (c.redop != SMR_RED_NONE) return false;
     if (c.N < 2 || c.strides[0][0] != 1) return false;
@@ -920,7 +937,7 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     int nst = 0;
     t.staged[0] = -1;
     for (int k = 1; k < c.M; ++k) {
-        int q = fast_axis(c, k);
+        int q = near_axis(c, k);
         t.staged[k] = -1;
         if (q > 0 && c.strides[k][0] != 0 && std::llabs(c.strides[k][0]) != 1) {
             t.staged[k] = nst++;
@@ -1567,7 +1584,8 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 plan.part_split = (int)split;
             }
             if (plan.part_split > 1) {
-                plan.scratch_bytes = (size_t)c.nout * (size_t)plan.part_split * es;
+                // chunk partials, then RED_SHARDS shard partials per output (two-level in-launch fold, smr_k_reduce.hip)
+                plan.scratch_bytes = (size_t)c.nout * ((size_t)plan.part_split + RED_SHARDS) * es;
                 plan.red_blocks = plan.part_split;  // > 1: the API allocates the partials buffer
             }
         }

@@ -28,6 +28,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -41,6 +42,20 @@ namespace smr {
 static thread_local std::vector<RecLaunch>* tl_recorder = nullptr;
 std::vector<RecLaunch>* recorder() { return tl_recorder; }
 void set_recorder(std::vector<RecLaunch>* r) { tl_recorder = r; }
+static thread_local int tl_slice_kind = 0;
+static thread_local unsigned tl_slice_off = 0, tl_slice_row = 0;
+void mark_sliceable(int kind, unsigned off, unsigned row) {
+    if (!tl_recorder) return;
+    tl_slice_kind = kind;
+    tl_slice_off = off;
+    tl_slice_row = row;
+}
+void take_slice_mark(RecLaunch& r) {
+    r.slice_kind = tl_slice_kind;
+    r.slice_off = tl_slice_off;
+    r.slice_row = tl_slice_row;
+    tl_slice_kind = 0;
+}
 
 // smr_api.cpp
 int seq_execute_plan(smr_plan* plan, void* const* bases, hipStream_t s, bool prepare_only);
@@ -86,6 +101,20 @@ int find_hsa(struct dl_phdr_info* info, size_t, void* data) {
 Hsa& hsa() {
     static Hsa* h = [] {
         Hsa* x = new Hsa();
+        // A profiler (rocprofv3, HSA_TOOLS_LIB) intercepts queue creation and hands out proxy queues whose rings are not meant to be
+        // written by the application directly (measured: rocprofv3 --kernel-trace crashes inside the first ring write).  Under such a
+        // tool -- or with SMR_SEQ_DIRECT=0 -- sequences replay through HIP, in recorded order, and the profiler sees ordinary launches.
+        {
+            const char* force = std::getenv("SMR_SEQ_DIRECT");
+            bool tool = false;
+            for (const char* v : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH"})
+                if (const char* e = std::getenv(v)) tool = tool || *e;
+            if (const char* e = std::getenv("LD_PRELOAD")) tool = tool || std::strstr(e, "rocprof") != nullptr;
+            if ((force && force[0] == '0') || (tool && !(force && force[0] == '1'))) {
+                x->why = force && force[0] == '0' ? "SMR_SEQ_DIRECT=0" : "an HSA tools library (profiler) intercepts the queues";
+                return x;
+            }
+        }
         std::string path;
         dl_iterate_phdr(find_hsa, &path);
         if (path.empty()) {
@@ -141,7 +170,7 @@ Hsa& hsa() {
 }
 
 // ---- per-device direct queue --------------------------------------------------------------------------------------------------
-constexpr int SEQ_MAXQ = 4;
+constexpr int SEQ_MAXQ = 8;
 struct KernelRef {
     uint64_t object = 0;
     uint32_t kernarg_size = 0, group_static = 0, private_size = 0;
@@ -329,7 +358,10 @@ struct smr_seq {
     std::string why_not_aql;
     std::vector<SeqPacket> packets[SEQ_MAXQ];  // one replay's packets, per hardware queue
     int nq = 0;                 // queues in use (= dependency components of the recorded list, at most max_queues)
-    int max_queues = SEQ_MAXQ;
+    int max_queues = 4;         // measured: beyond 4 queues of its own a process is time-multiplexed by the hardware scheduler (6 queues: 6.0 -> 11.1 us per step)
+    int slices = 1;             // a component that is ONE independent-workgroup launch is cut into this many block ranges, one queue each
+                                // (off by default: 2 slices x 2 components = 4 queues bought 3.5 % on the bench step, profiles/r04_overlap.txt)
+    int nsliced = 0;            // components that were
     int ncomp = 0;
     void* d_kernargs = nullptr;
     std::vector<std::shared_ptr<void>> keep;  // runtime-compiled programs the packets name
@@ -367,6 +399,7 @@ int seq_build(smr_seq* q) {
     q->aql = false;
     q->n_any = q->n_barrier = 0;
     q->nq = 0;
+    q->nsliced = 0;
     Direct& d = direct();
     if (!d.ok) q->why_not_aql = d.why;
     // 1. record every launch of every item (tables uploaded / scratch allocated by a prepare pass first)
@@ -374,7 +407,7 @@ int seq_build(smr_seq* q) {
         std::vector<RecLaunch> launches;
         Spans rd, wr;
         size_t bytes = 0;
-        int comp = 0, queue = 0;
+        int comp = 0;
     };
     std::vector<Rec> recs(q->items.size());
     for (size_t i = 0; i < q->items.size(); ++i) {
@@ -417,42 +450,7 @@ int seq_build(smr_seq* q) {
     q->aql = aql;
     q->built = true;
     if (!aql) return SMR_OK;
-    // 3. kernarg blocks (explicit arguments + the code-object-v5 hidden block), one resident copy in device memory
-    size_t total = 0;
-    std::vector<std::vector<size_t>> offs(recs.size());
-    for (size_t i = 0; i < recs.size(); ++i)
-        for (size_t j = 0; j < recs[i].launches.size(); ++j) {
-            offs[i].push_back(total);
-            const size_t need = std::max<size_t>(refs[i][j].kernarg_size, recs[i].launches[j].args.size());
-            total += (need + 255) & ~(size_t)255;
-        }
-    std::vector<unsigned char> host(total, 0);
-    for (size_t i = 0; i < recs.size(); ++i)
-        for (size_t j = 0; j < recs[i].launches.size(); ++j) {
-            const RecLaunch& l = recs[i].launches[j];
-            unsigned char* b = host.data() + offs[i][j];
-            std::memcpy(b, l.args.data(), l.args.size());
-            const size_t hid = (l.args.size() + 7) & ~(size_t)7;
-            if (refs[i][j].kernarg_size >= hid + 72) {  // hidden_block_count_[xyz], hidden_group_size_[xyz], remainders, global offsets, grid dims
-                uint32_t bc[3] = {l.grid, 1, 1};
-                uint16_t gs[6] = {(uint16_t)l.block, 1, 1, 0, 0, 0};
-                std::memcpy(b + hid, bc, 12);
-                std::memcpy(b + hid + 12, gs, 12);
-                uint16_t gd = 1;
-                std::memcpy(b + hid + 64, &gd, 2);
-                if (refs[i][j].kernarg_size >= hid + 124) {
-                    uint32_t dl = l.lds;
-                    std::memcpy(b + hid + 120, &dl, 4);  // hidden_dynamic_lds_size
-                }
-            }
-        }
-    if (q->d_kernargs) (void)hipFree(q->d_kernargs);
-    q->d_kernargs = nullptr;
-    hipError_t e = hipMalloc(&q->d_kernargs, total ? total : 256);
-    if (e != hipSuccess) return hip_error(e, "hipMalloc(sequence kernargs)");
-    e = hipMemcpy(q->d_kernargs, host.data(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return hip_error(e, "hipMemcpy(sequence kernargs)");
-    // 4. dependency components of the recorded list.  Two executions conflict when one writes bytes the other reads or writes
+    // 3. dependency components of the recorded list.  Two executions conflict when one writes bytes the other reads or writes
     //    (an execution conflicts with its own next replay through its destination).  Executions of one component stay on ONE
     //    hardware queue, in recorded order -- every ordering the in-order result needs is then an ordering inside a queue, no
     //    cross-queue signal exists, and replay r+1 follows replay r on every queue by construction.  Different components share
@@ -468,7 +466,7 @@ int seq_build(smr_seq* q) {
     for (size_t i = 0; i < ni; ++i)
         for (size_t j = i + 1; j < ni; ++j)
             if (overlaps(recs[i].wr, recs[j].wr) || overlaps(recs[i].wr, recs[j].rd) || overlaps(recs[i].rd, recs[j].wr)) parent[find((int)j)] = find((int)i);
-    std::vector<int> roots;
+    std::vector<int> roots, csize, cfirst;
     std::vector<size_t> cbytes;
     for (size_t i = 0; i < ni; ++i) {
         const int r = find((int)i);
@@ -478,26 +476,123 @@ int seq_build(smr_seq* q) {
         if (c == roots.size()) {
             roots.push_back(r);
             cbytes.push_back(0);
+            csize.push_back(0);
+            cfirst.push_back((int)i);
         }
         recs[i].comp = (int)c;
         cbytes[c] += recs[i].bytes;
+        ++csize[c];
     }
-    q->ncomp = (int)roots.size();
-    const int nq = std::max(1, std::min<int>({q->max_queues, SEQ_MAXQ, (int)roots.size()}));
-    std::vector<int> order(roots.size()), cqueue(roots.size(), 0);
-    for (size_t c = 0; c < order.size(); ++c) order[c] = (int)c;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cbytes[a] > cbytes[b]; });
-    std::vector<size_t> load(nq, 0);
-    for (int c : order) {
-        int best = 0;
-        for (int k = 1; k < nq; ++k)
-            if (load[k] < load[best]) best = k;
-        cqueue[c] = best;
-        load[best] += cbytes[c];
+    const int ncomp = (int)roots.size();
+    q->ncomp = ncomp;
+    const int maxq = std::max(1, std::min(q->max_queues, SEQ_MAXQ));
+    // 3b. slices.  A component that consists of ONE execution with ONE launch whose workgroups are independent (the launcher says so:
+    //     RecLaunch::slice_kind) is cut into `slices` contiguous block ranges, each on a queue of its own: slice k of replay r+1 follows
+    //     slice k of replay r in its queue, the slices of one replay write disjoint parts of the destination (a workgroup owns its
+    //     tiles) and nothing else belongs to the component -- still no cross-queue ordering to express.  This is the device form of
+    //     _mapreduce_threaded! (src/mapreduce.jl:195-227: the box is bisected and the halves run as concurrent tasks): while one
+    //     slice drains and releases, the next replay's other slice is already running.
+    std::vector<int> cslices(ncomp, 1);
+    if (q->slices > 1 && ncomp * q->slices <= maxq)
+        for (int c = 0; c < ncomp; ++c) {
+            const Rec& r = recs[cfirst[c]];
+            if (csize[c] == 1 && r.launches.size() == 1 && r.launches[0].slice_kind != 0 && r.launches[0].grid >= (unsigned)(64 * q->slices)) {
+                cslices[c] = q->slices;
+                ++q->nsliced;
+            }
+        }
+    // queues: sliced components own cslices[c] queues each; the others share what is left, longest-processing-time first
+    std::vector<int> cqueue(ncomp, 0);
+    int nextq = 0;
+    for (int c = 0; c < ncomp; ++c)
+        if (cslices[c] > 1) {
+            cqueue[c] = nextq;
+            nextq += cslices[c];
+        }
+    {
+        std::vector<int> order;
+        for (int c = 0; c < ncomp; ++c)
+            if (cslices[c] == 1) order.push_back(c);
+        if (!order.empty()) {
+            const int nshared = std::max(1, std::min<int>(maxq - nextq, (int)order.size()));
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cbytes[a] > cbytes[b]; });
+            std::vector<size_t> load(nshared, 0);
+            for (int c : order) {
+                int best = 0;
+                for (int k = 1; k < nshared; ++k)
+                    if (load[k] < load[best]) best = k;
+                cqueue[c] = nextq + best;
+                load[best] += cbytes[c];
+            }
+            nextq += nshared;
+        }
     }
+    const int nq = nextq;
     for (int k = 0; k < nq; ++k)
         if (int rc = direct_queue(d, k)) return rc;
     q->nq = nq;
+    // 4. kernarg blocks (explicit arguments + the code-object-v5 hidden block), one resident copy in device memory; a sliced launch
+    //    has one block per slice (its block-offset field / list pointer patched)
+    size_t total = 0;
+    std::vector<std::vector<size_t>> offs(recs.size());
+    auto blocksize = [&](size_t i, size_t j) {
+        const size_t need = std::max<size_t>(refs[i][j].kernarg_size, recs[i].launches[j].args.size());
+        return (need + 255) & ~(size_t)255;
+    };
+    for (size_t i = 0; i < recs.size(); ++i)
+        for (size_t j = 0; j < recs[i].launches.size(); ++j) {
+            offs[i].push_back(total);
+            total += blocksize(i, j) * (size_t)cslices[recs[i].comp];
+        }
+    // slice s of a launch of `grid` workgroups: [lo, hi), cut at multiples of 8 (workgroup b runs on XCD b mod 8: the planners' tile
+    // orders rely on it, and a slice that starts at a multiple of 8 keeps every workgroup on the XCD it had in the whole launch)
+    auto slice_range = [&](unsigned grid, int ns, int s2, unsigned& lo, unsigned& hi) {
+        const unsigned per = ((grid + ns - 1) / ns + 7u) & ~7u;
+        lo = std::min<unsigned>(grid, per * (unsigned)s2);
+        hi = std::min<unsigned>(grid, lo + per);
+    };
+    std::vector<unsigned char> host(total, 0);
+    for (size_t i = 0; i < recs.size(); ++i)
+        for (size_t j = 0; j < recs[i].launches.size(); ++j) {
+            const RecLaunch& l = recs[i].launches[j];
+            const int ns = cslices[recs[i].comp];
+            for (int s2 = 0; s2 < ns; ++s2) {
+                unsigned lo = 0, hi = l.grid;
+                if (ns > 1) slice_range(l.grid, ns, s2, lo, hi);
+                unsigned char* b = host.data() + offs[i][j] + (size_t)s2 * blocksize(i, j);
+                std::memcpy(b, l.args.data(), l.args.size());
+                if (ns > 1 && l.slice_kind == 1) {  // a 32-bit "first block" field inside the argument block
+                    uint32_t v;
+                    std::memcpy(&v, b + l.slice_off, 4);
+                    v += lo;
+                    std::memcpy(b + l.slice_off, &v, 4);
+                } else if (ns > 1 && l.slice_kind == 2) {  // a pointer to a per-workgroup table: advanced by `lo` rows
+                    uint64_t v;
+                    std::memcpy(&v, b + l.slice_off, 8);
+                    v += (uint64_t)lo * l.slice_row;
+                    std::memcpy(b + l.slice_off, &v, 8);
+                }
+                const size_t hid = (l.args.size() + 7) & ~(size_t)7;
+                if (refs[i][j].kernarg_size >= hid + 72) {  // hidden_block_count_[xyz], hidden_group_size_[xyz], remainders, global offsets, grid dims
+                    uint32_t bc[3] = {hi - lo, 1, 1};
+                    uint16_t gs[6] = {(uint16_t)l.block, 1, 1, 0, 0, 0};
+                    std::memcpy(b + hid, bc, 12);
+                    std::memcpy(b + hid + 12, gs, 12);
+                    uint16_t gd = 1;
+                    std::memcpy(b + hid + 64, &gd, 2);
+                    if (refs[i][j].kernarg_size >= hid + 124) {
+                        uint32_t dl = l.lds;
+                        std::memcpy(b + hid + 120, &dl, 4);  // hidden_dynamic_lds_size
+                    }
+                }
+            }
+        }
+    if (q->d_kernargs) (void)hipFree(q->d_kernargs);
+    q->d_kernargs = nullptr;
+    hipError_t e = hipMalloc(&q->d_kernargs, total ? total : 256);
+    if (e != hipSuccess) return hip_error(e, "hipMalloc(sequence kernargs)");
+    e = hipMemcpy(q->d_kernargs, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_error(e, "hipMemcpy(sequence kernargs)");
     // 5. packets + ordering inside each queue: a launch that conflicts with none of the launches since the queue's last ordered one
     //    goes out without the barrier bit.  The decisions are those of the SECOND of two simulated replays (steady state: the first
     //    launch of a replay is judged against the tail of the previous replay on the same queue).
@@ -505,7 +600,9 @@ int seq_build(smr_seq* q) {
         Spans wrd, wwr;
         for (int pass = 0; pass < 2; ++pass)
             for (size_t i = 0; i < ni; ++i) {
-                if (cqueue[recs[i].comp] != k) continue;
+                const int c = recs[i].comp;
+                if (k < cqueue[c] || k >= cqueue[c] + cslices[c]) continue;
+                const int ns = cslices[c], s2 = k - cqueue[c];
                 bool free_ = !(wrd.empty() && wwr.empty()) && !q->all_ordered;
                 if (free_) free_ = !overlaps(wrd, recs[i].wr) && !overlaps(wwr, recs[i].wr) && !overlaps(wwr, recs[i].rd);
                 if (!free_) {
@@ -517,6 +614,9 @@ int seq_build(smr_seq* q) {
                 if (pass == 0) continue;
                 for (size_t j = 0; j < recs[i].launches.size(); ++j) {
                     const RecLaunch& l = recs[i].launches[j];
+                    unsigned lo = 0, hi = l.grid;
+                    if (ns > 1) slice_range(l.grid, ns, s2, lo, hi);
+                    if (hi <= lo) continue;  // an empty slice (tiny grid)
                     SeqPacket sp;
                     std::memset(&sp, 0, sizeof sp);
                     sp.barrier = j > 0 || !free_;  // later launches of one execution (folding passes) depend on the first
@@ -525,13 +625,13 @@ int seq_build(smr_seq* q) {
                     sp.pk.workgroup_size_x = (uint16_t)l.block;
                     sp.pk.workgroup_size_y = 1;
                     sp.pk.workgroup_size_z = 1;
-                    sp.pk.grid_size_x = l.grid * l.block;
+                    sp.pk.grid_size_x = (hi - lo) * l.block;
                     sp.pk.grid_size_y = 1;
                     sp.pk.grid_size_z = 1;
                     sp.pk.private_segment_size = 0;
                     sp.pk.group_segment_size = refs[i][j].group_static + l.lds;
                     sp.pk.kernel_object = refs[i][j].object;
-                    sp.pk.kernarg_address = (char*)q->d_kernargs + offs[i][j];
+                    sp.pk.kernarg_address = (char*)q->d_kernargs + offs[i][j] + (size_t)s2 * blocksize(i, j);
                     q->packets[k].push_back(sp);
                 }
             }
@@ -687,8 +787,8 @@ int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
     if (q->aql) {
         size_t np = 0;
         for (const auto& v : q->packets) np += v.size();
-        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d queues=%d ordered=%d unordered=%d fence_mid=%d stream_wait=%s last_replay_us=%.3f",
-                      q->items.size(), np, q->ncomp, q->nq, q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host",
+        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d sliced=%d queues=%d ordered=%d unordered=%d fence_mid=%d stream_wait=%s last_replay_us=%.3f",
+                      q->items.size(), np, q->ncomp, q->nsliced, q->nq, q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host",
                       direct().last_us);
     }
     else
@@ -710,6 +810,11 @@ int smr_seq_set(smr_seq* q, const char* name, int64_t value) {
     }
     if (std::strcmp(name, "queues") == 0 && value >= 1 && value <= SEQ_MAXQ) {  // hardware queues a replay may spread over
         q->max_queues = (int)value;
+        q->built = false;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "slices") == 0 && value >= 1 && value <= SEQ_MAXQ) {  // block ranges per single-launch component
+        q->slices = (int)value;
         q->built = false;
         return SMR_OK;
     }

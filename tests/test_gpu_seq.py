@@ -217,3 +217,44 @@ def test_stream_work_before_and_after_is_ordered():
     q.wait()
     sync()
     assert np.array_equal(out.cpu().numpy().reshape(128, 128, order="F"), a.T)
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 48])
+@pytest.mark.parametrize("slices", [2, 3, 4])
+def test_single_launch_components_cut_into_block_ranges(n, slices):
+    """A component that is ONE launch of independent workgroups is cut into contiguous block ranges, one hardware queue each (the
+    device form of _mapreduce_threaded!, src/mapreduce.jl:195-227); the step must come out bit-identical, replay after replay."""
+    rng = np.random.default_rng(100 + n)
+    a = rng.standard_normal((n,) * 4)
+    A, B, C = dview(a), dview(np.zeros_like(a)), dview(np.zeros_like(a))
+    p2 = S.make_plan(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))))
+    p3 = S.make_plan(lambda w, x, y, z: w + x + y + z, None, None, A.size, (C,) + tuple(A.permutedims(p) for p in PERMS))
+    q = S.Sequence().add(p2).add(p3)
+    q.set("queues", 8)            # (the default of 4 leaves room for 2 slices x 2 components only)
+    q.set("slices", slices)
+    q.run(5, stream())
+    q.wait()
+    sync()
+    info = q.info()
+    assert field(info, "backend") == "aql", info
+    if n == 32:  # both launches are one-shot forms there (the persistent forms of bigger problems are not sliceable)
+        assert field(info, "sliced") == "2" and field(info, "queues") == str(2 * slices), info
+    assert np.array_equal(B.toarray(), np.transpose(a, (3, 2, 1, 0)))
+    want = ((np.transpose(a, PERMS[0]) + np.transpose(a, PERMS[1])) + np.transpose(a, PERMS[2])) + np.transpose(a, PERMS[3])
+    assert np.array_equal(C.toarray(), want)
+
+
+def test_components_with_several_executions_are_not_sliced():
+    rng = np.random.default_rng(77)
+    a = rng.standard_normal((64, 64, 32))
+    A, B, C = dview(a), dview(np.zeros((32, 64, 64))), dview(np.zeros((32, 64, 64)))
+    p1 = S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims((2, 1, 0))))
+    p2 = S.make_plan(lambda x: x * 2, None, None, C.size, (C, B))                   # reads what p1 wrote: one component of two
+    q = S.Sequence().add(p1).add(p2)
+    q.set("slices", 4)
+    q.run(3, stream())
+    q.wait()
+    sync()
+    info = q.info()
+    assert field(info, "components") == "1" and field(info, "sliced") == "0" and field(info, "queues") == "1", info
+    assert np.array_equal(C.toarray(), np.transpose(a, (2, 1, 0)) * 2)

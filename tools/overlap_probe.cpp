@@ -401,7 +401,7 @@ int main(int argc, char** argv) {
         words2 = regions[0].b - regions[0].a;
         words3 = regions[1].b - regions[1].a;
     }
-    auto run_seq = [&](const char* name, int order, int fence, int steps_in_seq, int reps, int queues = 4) {
+    auto run_seq = [&](const char* name, int order, int fence, int steps_in_seq, int reps, int queues = 8, int slices = 1) {
         HC(hipMemset(dB, 0, hB.size() * 8));
         HC(hipMemset(dC, 0, hC.size() * 8));
         smr_seq* q = nullptr;
@@ -416,6 +416,7 @@ int main(int argc, char** argv) {
         if (order == 0) SC(p_seq_set(q, "order", 0));
         SC(p_seq_set(q, "fence_scope", fence));
         SC(p_seq_set(q, "queues", queues));
+        SC(p_seq_set(q, "slices", slices));
         SC(p_seq_info(q, info, sizeof info));  // builds
         if (stamped) {
             long u = 0;
@@ -468,6 +469,11 @@ int main(int argc, char** argv) {
     run_seq("seq AQL, queue per comp, 1 step x R", 1, 1, 1, R);
     run_seq("seq AQL, queue per comp, all ordered", 0, 1, 50, RR);
     run_seq("seq AQL, queue per comp, 1 step x 20", 1, 1, 1, 20);
+    run_seq("seq AQL, 2 slices per component", 1, 1, 1, R, 8, 2);
+    run_seq("seq AQL, 3 slices per component", 1, 1, 1, R, 8, 3);
+    run_seq("seq AQL, 4 slices per component", 1, 1, 1, R, 8, 4);
+    run_seq("seq AQL, 2 slices, 1 step x 20", 1, 1, 1, 20, 8, 2);
+    run_seq("seq AQL, 4 slices, 1 step x 20", 1, 1, 1, 20, 8, 4);
     run_seq("seq AQL 1 queue, 1 step x 20", 1, 1, 1, 20, 1);
     run_graph("graph, in order", inorder, s1);
     run_graph("graph, overlap window", window, s1);
