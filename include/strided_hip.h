@@ -214,10 +214,17 @@ int smr_stream_sync(void* stream);
  * needed, so that work the caller queues afterwards -- kernels, copies, events, synchronisation -- is
  * ordered after everything in the window.  Inside an open window the caller must not put work of its
  * own on `stream` (or must call smr_overlap_fence(stream) first).  Windows nest; they survive stream
- * capture into a hipGraph.  smr_stream_create returns a stream whose window is permanently open and
- * that the library fences by itself before every copy / synchronisation it performs on it
- * (smr_memcpy_*, smr_stream_sync, smr_mapreduce_scalar): the stream of a host (the Julia shim) that
- * routes ALL its device work through this library.                                                  */
+ * capture into a hipGraph.
+ * smr_stream_create returns a stream of the library's own -- the stream of a host (the Julia shim) that routes ALL its device work
+ * through this library.  On MI355X its launches do not go through HIP at all: the library submits every launch itself as an AQL
+ * packet on one of four HSA queues it owns, choosing the queue by the data -- a launch that conflicts with nothing in flight goes to
+ * the least loaded queue and runs concurrently with its predecessors, one that conflicts with launches on one queue follows them
+ * there, one that conflicts with several queues waits for them through a barrier-AND packet; completion signals retire the ranges
+ * (csrc/smr_seq.cpp: eager direct dispatch; ~1 us of host time per launch instead of HIP's 3.6-4 us).  Results are those of in-order
+ * execution.  The library fences by itself (waits for its queues) before every copy / synchronisation / sequence replay it performs on
+ * such a stream (smr_memcpy_*, smr_stream_sync, smr_mapreduce_scalar, smr_seq_run, smr_free, smr_plan_destroy) and drains the HIP
+ * work it queued there before the next direct launch.  Option "eager_direct" = 0 sends the launches through HIP instead (the window
+ * of such a stream is then permanently open).                                                                                      */
 int smr_overlap_begin(void* stream);
 int smr_overlap_end(void* stream);
 int smr_overlap_fence(void* stream);
@@ -385,7 +392,9 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * switches: "stream_u", "stream_pack_rows", "orbit_lds_min", "orbit_skew", "tile_block_min_axes"; "stamp_base" / "stamp_cap" / "stamp_used" (debug build
  * with device-side wall-clock stamps, csrc/smr_device.h).  Read-only counters through
  * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms", "overlap_any" / "overlap_ordered" /
- * "overlap_fences" (launches dispatched without / with the barrier bit inside overlap windows, fences issued).      */
+ * "overlap_fences" (launches dispatched without / with the barrier bit inside overlap windows, fences issued); "eager_launches",
+ * "eager_free" / "eager_same" / "eager_cross" (direct launches; executions that conflicted with nothing / one queue / several),
+ * "eager_fallback" (executions sent through HIP).      */
 int smr_set_option(const char* name, int64_t value);
 int64_t smr_get_option(const char* name);
 

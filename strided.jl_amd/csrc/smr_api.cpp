@@ -156,11 +156,21 @@ int window_fence_locked(Windows& W, Window& w, hipStream_t s) {
     return e == hipSuccess ? SMR_OK : hip_error(e, "overlap window fence");
 }
 int window_fence(hipStream_t s) {
-    Windows& W = windows();
-    std::lock_guard<std::mutex> g(W.mu);
-    auto it = W.map.find((void*)s);
-    if (it == W.map.end()) return SMR_OK;
-    return window_fence_locked(W, it->second, s);
+    bool owned = false;
+    int rc = SMR_OK;
+    {
+        Windows& W = windows();
+        std::lock_guard<std::mutex> g(W.mu);
+        auto it = W.map.find((void*)s);
+        if (it == W.map.end()) return SMR_OK;
+        owned = it->second.owned;
+        rc = window_fence_locked(W, it->second, s);
+    }
+    if (owned && eager_available()) {  // what the library submitted directly completes before whatever follows on the stream through HIP ...
+        eager_fence_all();
+        eager_note_hip_work();         // ... and that HIP work completes before the next direct launch
+    }
+    return rc;
 }
 }  // namespace
 
@@ -172,8 +182,41 @@ unsigned take_launch_flags() {
 
 static int execute_family(const Plan& plan, void* const* bases, hipStream_t s);
 
+static bool stream_is_owned(hipStream_t s) {
+    Windows& W = windows();
+    std::lock_guard<std::mutex> g(W.mu);
+    if (W.map.empty()) return false;
+    auto it = W.map.find((void*)s);
+    return it != W.map.end() && it->second.owned;
+}
+
 static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
-    if (!jit_no_launch()) window_admit(plan, bases, s);
+    if (!jit_no_launch() && !recorder()) {
+        // a library-owned stream: the library submits the launch itself (smr_seq.cpp: eager direct dispatch), on the hardware queue its
+        // data dependencies select -- independent executions run concurrently, host cost ~1 us instead of HIP's 3.6-4 us
+        if (options().eager_direct && stream_is_owned(s) && eager_available()) {
+            std::vector<Span> rd, wr;
+            footprint(plan, bases, rd, wr);
+            std::vector<RecLaunch> rec;
+            set_recorder(&rec);
+            int rc = execute_family(plan, bases, s);
+            set_recorder(nullptr);
+            if (rc) return rc;
+            if (!plan.eager_seen) {
+                plan.eager_seen = true;
+                eager_request_sys_acquire();
+            }
+            std::vector<std::pair<uintptr_t, uintptr_t>> r2, w2;
+            for (const Span& x : rd) r2.emplace_back(x.lo, x.hi);
+            for (const Span& x : wr) w2.emplace_back(x.lo, x.hi);
+            rc = rec.empty() ? SMR_EUNSUPPORTED : eager_submit(plan, rec, r2, w2, s);
+            if (rc != SMR_EUNSUPPORTED) return rc;
+            // this execution goes through HIP (a kernel that needs scratch memory, ...): everything submitted directly comes first
+            eager_fence_all();
+            eager_note_hip_work();
+        }
+        window_admit(plan, bases, s);
+    }
     const int rc = execute_family(plan, bases, s);
     tl_launch_flags = 0;  // an execution that launched nothing must not leak its flag to the next one
     return rc;
@@ -309,6 +352,7 @@ static int ensure_scratch(smr_plan* h) {
 
 static void plan_free(smr_plan* h) {
     if (!h) return;
+    eager_fence_if_active();  // launches submitted directly may still read the plan's tables
     if (h->plan.scratch) (void)hipFree(h->plan.scratch);
     for (void*& p : h->plan.lanetab)
         if (p) {
@@ -459,6 +503,7 @@ int smr_malloc(size_t bytes, void** out) {
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipMalloc");
 }
 int smr_free(void* p) {
+    eager_fence_if_active();  // hipFree waits for HIP's queues only
     hipError_t e = hipFree(p);
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipFree");
 }
@@ -532,6 +577,7 @@ int smr_stream_destroy(void* stream) {
         (void)window_fence_locked(W, it->second, (hipStream_t)stream);
         W.map.erase(it);
     }
+    eager_fence_if_active();
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamDestroy((hipStream_t)stream);
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipStreamDestroy");
@@ -800,6 +846,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "tiled_persist") o.tiled_persist = value;
     else if (n == "stream_u") o.stream_u = value;
     else if (n == "stream_pack_rows") o.stream_pack_rows = value;
+    else if (n == "eager_direct") o.eager_direct = value;
     else if (n == "reduce_tree") o.reduce_tree = value;
     else if (n == "tiled_persist_wpc") o.tiled_persist_wpc = value;
     else if (n == "tiled_persist_min") o.tiled_persist_min = value;
@@ -861,6 +908,15 @@ int64_t smr_get_option(const char* name) {
     if (n == "tiled_persist") return o.tiled_persist;
     if (n == "stream_u") return o.stream_u;
     if (n == "stream_pack_rows") return o.stream_pack_rows;
+    if (n == "eager_direct") return o.eager_direct;
+    if (n == "eager_launches") return eager_stat(0);
+    if (n == "eager_free") return eager_stat(1);
+    if (n == "eager_same") return eager_stat(2);
+    if (n == "eager_cross") return eager_stat(3);
+    if (n == "eager_fallback") return eager_stat(4);
+    if (n == "eager_kernarg_device") return eager_stat(5);
+    if (n == "eager_arg_hits") return eager_stat(7);
+    if (n == "eager_gpu_only_signals") return eager_stat(6);
     if (n == "reduce_tree") return o.reduce_tree;
     if (n == "tiled_persist_wpc") return o.tiled_persist_wpc;
     if (n == "tiled_persist_min") return o.tiled_persist_min;

@@ -195,6 +195,7 @@ struct Plan {
     // STREAM
     int vec = 1;        // elements per vector access
     // reductions
+    mutable bool eager_seen = false;  // the plan's device tables (uploaded by hipMemcpy on its first execution) have been made visible to the direct queues
     void* scratch = nullptr;  // partials (owned), followed by RED_COUNTERS arrival counters (zero between launches)
     size_t scratch_bytes = 0;
     size_t counter_off = 0;   // byte offset of the counters inside `scratch` (set when it is allocated)
@@ -215,6 +216,15 @@ struct Plan {
     mutable std::shared_ptr<std::mutex> build_mu = std::make_shared<std::mutex>();
     mutable void* ordtab = nullptr;  // TILED: tile-order table in device memory (large grids)
     mutable std::vector<unsigned char> tiled_args[4];  // fully built kernel arguments per variant
+    // eager direct dispatch (smr_seq.cpp): argument blocks of this plan's launches that are resident in device memory, keyed by their
+    // bytes -- a repeated execution (same base pointers) reuses the block: no write through the BAR, no read-back round trip
+    struct ArgBlock {
+        int launch = 0;
+        std::vector<unsigned char> bytes;  // explicit arguments (the key)
+        void* dev = nullptr;
+        unsigned long long epoch = 0;      // arena generation the block belongs to
+    };
+    mutable std::vector<ArgBlock> eager_args;
     std::string desc;
 };
 
@@ -251,6 +261,8 @@ struct Options {
     i64 stream_u = 0;           // experiment: vectors per lane of the STREAM family (runtime-compiled functors only)
     i64 reduce_tree = 0;        // split reductions of up to this many chunks (beyond reduce_single) fold inside the launch through TWO levels of arrival
                                 // counters (shards of ~sqrt(chunks)); 0: a second launch folds, as in rounds 1-3
+    i64 eager_direct = 1;       // launches on a library-owned stream (smr_stream_create) are submitted by the library itself (AQL packets on its HSA queues,
+                                // queue chosen by the data dependencies); 0: through HIP, in stream order
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
@@ -337,6 +349,16 @@ struct RecLaunch {
     std::vector<unsigned char> args;  // the explicit kernel arguments in kernarg-segment layout
 };
 std::vector<RecLaunch>* recorder();  // thread-local, nullptr when nothing records
+// eager direct dispatch on library-owned streams (smr_seq.cpp)
+struct Plan;
+int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::vector<std::pair<uintptr_t, uintptr_t>>& rd,
+                 const std::vector<std::pair<uintptr_t, uintptr_t>>& wr, hipStream_t s);
+void eager_fence_all();
+void eager_note_hip_work();
+void eager_request_sys_acquire();
+long eager_stat(int which);
+bool eager_available();
+void eager_fence_if_active();
 void mark_sliceable(int kind, unsigned off, unsigned row);  // applies to the NEXT recorded launch of the calling thread (no-op when nothing records)
 void take_slice_mark(RecLaunch& r);
 void set_recorder(std::vector<RecLaunch>* r);

@@ -85,6 +85,13 @@ struct Hsa {
     decltype(&hsa_executable_get_symbol_by_name) get_symbol_by_name = nullptr;
     decltype(&hsa_executable_symbol_get_info) symbol_get_info = nullptr;
     decltype(&hsa_status_string) status_string = nullptr;
+    // optional (eager dispatch): signals without an interrupt, argument blocks in device memory written through the BAR
+    decltype(&hsa_amd_signal_create) amd_signal_create = nullptr;
+    decltype(&hsa_amd_agent_iterate_memory_pools) iterate_pools = nullptr;
+    decltype(&hsa_amd_memory_pool_get_info) pool_get_info = nullptr;
+    decltype(&hsa_amd_agent_memory_pool_get_info) agent_pool_get_info = nullptr;
+    decltype(&hsa_amd_memory_pool_allocate) pool_allocate = nullptr;
+    decltype(&hsa_amd_agents_allow_access) allow_access = nullptr;
     hsa_ven_amd_loader_1_03_pfn_t loader;
     bool ok = false;
     std::string why;
@@ -152,6 +159,12 @@ Hsa& hsa() {
         SMR_HSA_SYM(symbol_get_info, hsa_executable_symbol_get_info)
         SMR_HSA_SYM(status_string, hsa_status_string)
 #undef SMR_HSA_SYM
+        x->amd_signal_create = (decltype(x->amd_signal_create))dlsym(x->lib, "hsa_amd_signal_create");
+        x->iterate_pools = (decltype(x->iterate_pools))dlsym(x->lib, "hsa_amd_agent_iterate_memory_pools");
+        x->pool_get_info = (decltype(x->pool_get_info))dlsym(x->lib, "hsa_amd_memory_pool_get_info");
+        x->agent_pool_get_info = (decltype(x->agent_pool_get_info))dlsym(x->lib, "hsa_amd_agent_memory_pool_get_info");
+        x->pool_allocate = (decltype(x->pool_allocate))dlsym(x->lib, "hsa_amd_memory_pool_allocate");
+        x->allow_access = (decltype(x->allow_access))dlsym(x->lib, "hsa_amd_agents_allow_access");
         if (!all) return x;
         if (x->init() != HSA_STATUS_SUCCESS) {  // reference-counted: HIP holds the first reference
             x->why = "hsa_init failed";
@@ -339,6 +352,480 @@ int resolve_kernel(Direct& d, const void* hostfn, KernelRef& out) {
 }  // namespace
 }  // namespace smr
 
+
+// ---- eager direct dispatch: the launches of a library-owned stream (smr_stream_create) ---------------------------------------------
+// A host that routes ALL its device work through this library (the Julia shim) pays HIP's 3.6-4 us of host time per launch for kernels
+// that last 2-5 us, and HIP orders every launch behind its predecessor.  On a library-owned stream the library submits the launch
+// itself: the launchers run in recording mode (SMR_LAUNCH appends instead of launching), the kernel descriptor comes from the code
+// object HIP loaded, the argument block goes into a ring of host-coherent slots, and ONE 64-byte packet + a doorbell go to one of up
+// to four HSA queues.  Which queue is decided by the data: the bounding byte ranges of the operands (and the plan's partials) are
+// compared with what is still in flight on every queue --
+//   * no conflict anywhere  -> the queue with the least in flight: the launch runs CONCURRENTLY with its predecessors;
+//   * conflicts on one queue -> that queue (the barrier bit orders it behind them);
+//   * conflicts on several   -> one of them, behind a barrier-AND packet that waits for the last packet of each of the others.
+// Every packet carries a completion signal from a per-queue ring; a signal that has reached 0 retires its launch's ranges.  Results
+// are those of in-order execution on the stream (src/mapreduce.jl:203-223: spawn what is independent, wait where it must).
+// The library fences by itself -- waits for every queue -- before anything it does on the stream through HIP (copies, synchronisation,
+// sequence replays, the scalar result of a complete reduction), and drains HIP work it queued itself before the next direct launch.
+namespace smr {
+namespace {
+typedef std::vector<std::pair<uintptr_t, uintptr_t>> Spans;
+bool overlaps(const Spans& v, const std::pair<uintptr_t, uintptr_t>& x) {
+    for (const auto& y : v)
+        if (x.first < y.second && y.first < x.second) return true;
+    return false;
+}
+bool overlaps(const Spans& v, const Spans& w) {
+    for (const auto& x : w)
+        if (overlaps(v, x)) return true;
+    return false;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+uint16_t header_of(bool barrier, int acq, int rel) {
+    return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                      (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+}
+
+constexpr int EAGER_Q = 4;          // hardware queues of the eager path (the first EAGER_Q of the device's direct queues)
+constexpr int EAGER_SIGS = 256;     // launches in flight per queue
+constexpr size_t EAGER_SLOT = 8192; // bytes of argument block per launch (TiledArgs<true> + hidden block fit)
+struct Inflight {
+    int sig;  // index into EagerQueue::sigs
+    Spans rd, wr;
+};
+struct EagerQueue {
+    std::vector<hsa_signal_t> sigs;
+    std::vector<signed char> dep_user;  // queue (1-based) whose barrier-AND packet names this signal, 0: none
+    std::vector<Inflight> inflight;  // oldest first
+    unsigned next = 0;               // next signal / argument slot
+    int tail = -1;                   // signal index of the last packet submitted when it carries one (-1: it does not, or nothing was submitted since the last fence)
+    int unsignaled = 0;              // packets at the tail without a completion signal (0 with tail == -1: the queue is idle as far as we know)
+    unsigned char* kargs = nullptr;  // EAGER_SIGS slots of EAGER_SLOT bytes, host-coherent
+};
+struct Eager {
+    EagerQueue q[EAGER_Q];
+    bool ready = false, failed = false;
+    bool kargs_device = false, gpu_only_signals = false;
+    // resident argument blocks (device memory only): a bump arena behind the per-queue rings; when it is full everything in flight is
+    // waited for and the arena starts over (blocks of an older epoch are stale)
+    unsigned char* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    unsigned long long epoch = 1;
+    long n_arg_hits = 0;
+    bool hip_pending = false;  // the library queued HIP work on an owned stream since the last drain
+    unsigned sys_acquire = ~0u; // bit k: the next direct launch on queue k follows work of another agent (a copy, a table upload): acquire at system scope
+    std::map<std::string, std::pair<KernelRef, std::shared_ptr<void>>> jit;  // runtime-compiled kernels by entry-point name (module pinned)
+    long n_launch = 0, n_free = 0, n_same = 0, n_cross = 0, n_fallback = 0;
+};
+Eager& eager() {
+    static Eager* e = new Eager();
+    return *e;
+}
+
+// a CPU agent (for hsa_amd_agents_allow_access) and a device-local pool the CPU may be given access to (large BAR)
+struct PoolPick {
+    Hsa* h;
+    hsa_agent_t cpu{};
+    bool have_cpu = false;
+    hsa_amd_memory_pool_t pool{};
+    bool have_pool = false;
+};
+hsa_status_t pick_cpu(hsa_agent_t a, void* data) {
+    PoolPick* p = (PoolPick*)data;
+    hsa_device_type_t t;
+    if (!p->have_cpu && p->h->agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) == HSA_STATUS_SUCCESS && t == HSA_DEVICE_TYPE_CPU) {
+        p->cpu = a;
+        p->have_cpu = true;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+hsa_status_t pick_pool(hsa_amd_memory_pool_t pool, void* data) {
+    PoolPick* p = (PoolPick*)data;
+    hsa_amd_segment_t seg;
+    uint32_t flags = 0;
+    bool alloc = false;
+    if (p->h->pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+    p->h->pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    p->h->pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+    if (!alloc || !(flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED)) return HSA_STATUS_SUCCESS;
+    hsa_amd_memory_pool_access_t acc = HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED;
+    if (p->h->agent_pool_get_info(p->cpu, pool, HSA_AMD_AGENT_MEMORY_POOL_INFO_ACCESS, &acc) != HSA_STATUS_SUCCESS || acc == HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED)
+        return HSA_STATUS_SUCCESS;
+    p->pool = pool;
+    p->have_pool = true;
+    return HSA_STATUS_INFO_BREAK;
+}
+
+// Argument blocks: device memory the host writes through the BAR (what HIP itself does on this part: a kernel that fetches its
+// arguments from host memory starts a PCIe round trip later), when the device-local pool can be mapped for the CPU; else pinned
+// host memory.  $SMR_EAGER_KERNARG = host | device forces one.
+unsigned char* eager_kernarg_ring(Direct& d, Eager& e, size_t bytes) {
+    Hsa& h = hsa();
+    const char* force = std::getenv("SMR_EAGER_KERNARG");
+    const bool want_dev = !(force && std::strcmp(force, "host") == 0);
+    if (want_dev && h.iterate_pools && h.pool_get_info && h.agent_pool_get_info && h.pool_allocate && h.allow_access) {
+        PoolPick pp;
+        pp.h = &h;
+        h.iterate_agents(pick_cpu, &pp);
+        if (pp.have_cpu) h.iterate_pools(d.agent, pick_pool, &pp);
+        void* p = nullptr;
+        if (pp.have_pool && h.pool_allocate(pp.pool, bytes, 0, &p) == HSA_STATUS_SUCCESS && p) {
+            hsa_agent_t both[2] = {pp.cpu, d.agent};
+            if (h.allow_access(2, both, nullptr, p) == HSA_STATUS_SUCCESS) {
+                e.kargs_device = true;
+                return (unsigned char*)p;
+            }
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (unsigned char*)p;
+}
+
+int eager_init(Direct& d, Eager& e) {
+    if (e.ready) return SMR_OK;
+    if (e.failed) return SMR_EUNSUPPORTED;
+    Hsa& h = hsa();
+    const char* sg = std::getenv("SMR_EAGER_SIGNALS");  // "interrupt": ordinary signals (experiments)
+    const bool gpu_only = h.amd_signal_create && !(sg && std::strcmp(sg, "interrupt") == 0);
+    e.gpu_only_signals = gpu_only;
+    constexpr size_t ARENA = (size_t)16 << 20;
+    unsigned char* ring = eager_kernarg_ring(d, e, (size_t)EAGER_Q * EAGER_SIGS * EAGER_SLOT + ARENA);
+    if (!ring) {
+        e.failed = true;
+        return SMR_EUNSUPPORTED;
+    }
+    if (e.kargs_device) {
+        e.arena = ring + (size_t)EAGER_Q * EAGER_SIGS * EAGER_SLOT;
+        e.arena_bytes = ARENA;
+    }
+    for (int k = 0; k < EAGER_Q; ++k) {
+        if (direct_queue(d, k) != SMR_OK) {
+            e.failed = true;
+            return SMR_EUNSUPPORTED;
+        }
+        EagerQueue& q = e.q[k];
+        q.sigs.resize(EAGER_SIGS);
+        q.dep_user.assign(EAGER_SIGS, 0);
+        for (int i = 0; i < EAGER_SIGS; ++i) {
+            // completion signals are polled by the host and consumed by barrier-AND packets: no interrupt, no event mailbox write
+            const hsa_status_t st = gpu_only ? h.amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &q.sigs[i]) : h.signal_create(0, 0, nullptr, &q.sigs[i]);
+            if (st != HSA_STATUS_SUCCESS) {
+                e.failed = true;
+                return SMR_EUNSUPPORTED;
+            }
+        }
+        q.kargs = ring + (size_t)k * EAGER_SIGS * EAGER_SLOT;
+    }
+    e.ready = true;
+    return SMR_OK;
+}
+
+// drop the launches whose completion signal has reached 0 (in submission order: a queue completes in order)
+void put_packet(hsa_queue_t* hq, const void* body64, uint16_t header, uint16_t setup);
+void eager_wait_queue(Eager& e, Direct& d, int k);
+
+// (a queue completes in order: every packet carries the barrier bit; an entry without a signal of its own retires with the next
+// signalled one behind it)
+void eager_retire(EagerQueue& q) {
+    Hsa& h = hsa();
+    size_t done = 0;
+    for (size_t i = 0; i < q.inflight.size(); ++i) {
+        if (q.inflight[i].sig < 0) continue;
+        if (h.signal_load(q.sigs[q.inflight[i].sig]) != 0) break;
+        done = i + 1;
+    }
+    if (done) q.inflight.erase(q.inflight.begin(), q.inflight.begin() + (long)done);
+}
+
+int eager_take_signal(Eager& e, EagerQueue& q, int self);
+
+// a marker: an empty barrier packet that completes when everything submitted to the queue before it has; returns its signal index
+int eager_marker(Eager& e, EagerQueue& q, hsa_queue_t* hq, int self) {
+    const int si = eager_take_signal(e, q, self);
+    hsa_barrier_and_packet_t bp;
+    std::memset(&bp, 0, sizeof bp);
+    bp.completion_signal = q.sigs[si];
+    const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
+    put_packet(hq, &bp, hdr, 0);
+    Inflight f;
+    f.sig = si;
+    q.inflight.push_back(std::move(f));
+    q.tail = si;
+    q.unsignaled = 0;
+    return si;
+}
+
+void eager_wait_queue(Eager& e, Direct& d, int k) {
+    Hsa& h = hsa();
+    EagerQueue& q = e.q[k];
+    if (q.unsignaled > 0) (void)eager_marker(e, q, d.q[k], k);
+    if (q.tail >= 0 && h.signal_load(q.sigs[q.tail]) != 0) h.signal_wait(q.sigs[q.tail], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    q.inflight.clear();
+    q.tail = -1;
+    q.unsignaled = 0;
+}
+
+// the next completion signal of queue `self` (a ring): the packet that used it EAGER_SIGS signalled submissions ago must have completed,
+// and a barrier-AND packet of another queue that names it must have passed, before it is re-armed
+int eager_take_signal(Eager& e, EagerQueue& q, int self) {
+    Hsa& h = hsa();
+    const int si = (int)(q.next % EAGER_SIGS);
+    ++q.next;
+    if (h.signal_load(q.sigs[si]) != 0) h.signal_wait(q.sigs[si], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    if (q.dep_user[si]) {
+        if (q.dep_user[si] - 1 != self) eager_wait_queue(e, direct(), q.dep_user[si] - 1);
+        q.dep_user[si] = 0;
+    }
+    eager_retire(q);
+    h.signal_store_relaxed(q.sigs[si], 1);
+    return si;
+}
+
+bool conflicts(const EagerQueue& q, const Spans& rd, const Spans& wr) {
+    for (const Inflight& f : q.inflight)
+        if (overlaps(f.wr, wr) || overlaps(f.wr, rd) || overlaps(f.rd, wr)) return true;
+    return false;
+}
+
+void put_packet(hsa_queue_t* hq, const void* body64, uint16_t header, uint16_t setup) {
+    Hsa& h = hsa();
+    const uint64_t idx = h.add_write_index(hq, 1);
+    while (idx - h.load_read_index(hq) >= hq->size) {
+    }
+    char* slot = (char*)hq->base_address + (idx & (hq->size - 1)) * 64;
+    std::memcpy(slot + 4, (const char*)body64 + 4, 60);
+    __atomic_store_n((uint32_t*)slot, (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
+    h.signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)idx);
+}
+}  // namespace
+
+// smr_api.cpp: the launches of one execution, recorded by the caller; rd / wr = its footprint.  SMR_OK, an error, or
+// SMR_EUNSUPPORTED when this execution has to go through HIP (the caller fences and launches normally).
+int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::vector<std::pair<uintptr_t, uintptr_t>>& rd,
+                 const std::vector<std::pair<uintptr_t, uintptr_t>>& wr, hipStream_t s) {
+    Direct& d = direct();
+    if (!d.ok) return SMR_EUNSUPPORTED;
+    std::lock_guard<std::mutex> g(d.mu);
+    Eager& e = eager();
+    if (eager_init(d, e) != SMR_OK) return SMR_EUNSUPPORTED;
+    Hsa& h = hsa();
+    // kernels first: anything that cannot be dispatched directly sends the whole execution through HIP
+    std::vector<KernelRef> refs(launches.size());
+    for (size_t j = 0; j < launches.size(); ++j) {
+        RecLaunch& l = launches[j];
+        int rc;
+        if (l.hostfn) {
+            rc = resolve_kernel(d, l.hostfn, refs[j]);
+        } else if (!l.kname.empty()) {
+            auto it = e.jit.find(l.kname);
+            if (it != e.jit.end()) {
+                refs[j] = it->second.first;
+                rc = SMR_OK;
+            } else {
+                rc = resolve_name(d, l.kname, refs[j]);
+                if (rc == SMR_OK) {
+                    if (e.jit.size() > 512) e.jit.clear();  // unpins the modules; they are looked up again on their next use
+                    e.jit[l.kname] = std::make_pair(refs[j], l.keep);
+                }
+            }
+        } else {
+            rc = SMR_EUNSUPPORTED;
+        }
+        const size_t hid = (l.args.size() + 7) & ~(size_t)7;
+        if (rc != SMR_OK || refs[j].private_size != 0 || std::max<size_t>(refs[j].kernarg_size, hid + 128) > EAGER_SLOT) {
+            ++e.n_fallback;
+            return SMR_EUNSUPPORTED;
+        }
+    }
+    if (e.hip_pending) {  // copies the library queued on the stream through HIP come first
+        hipError_t he = hipStreamSynchronize(s);
+        if (he != hipSuccess) return hip_error(he, "draining the stream before a direct launch");
+        e.hip_pending = false;
+        e.sys_acquire = ~0u;
+    }
+    // which queue
+    int nconf = 0, conf[EAGER_Q], target = -1;
+    for (int k = 0; k < EAGER_Q; ++k) {
+        eager_retire(e.q[k]);
+        if (conflicts(e.q[k], rd, wr)) conf[nconf++] = k;
+    }
+    if (nconf == 0) {
+        size_t best = (size_t)-1;
+        for (int k = 0; k < EAGER_Q; ++k)
+            if (e.q[k].inflight.size() < best) {
+                best = e.q[k].inflight.size();
+                target = k;
+            }
+        ++e.n_free;
+    } else {
+        target = conf[0];
+        for (int i = 1; i < nconf; ++i)
+            if (e.q[conf[i]].inflight.size() > e.q[target].inflight.size()) target = conf[i];
+        if (nconf == 1) ++e.n_same;
+        else ++e.n_cross;
+    }
+    EagerQueue& q = e.q[target];
+    hsa_queue_t* hq = d.q[target];
+    if (nconf > 1) {  // wait (on the device) for the last packet of every other conflicting queue
+        hsa_barrier_and_packet_t bp;
+        std::memset(&bp, 0, sizeof bp);
+        int nd = 0;
+        for (int i = 0; i < nconf; ++i)
+            if (conf[i] != target) {
+                EagerQueue& o = e.q[conf[i]];
+                if (o.unsignaled > 0) (void)eager_marker(e, o, d.q[conf[i]], conf[i]);  // its last packet carries no signal: a marker behind it does
+                if (o.tail >= 0) {
+                    bp.dep_signal[nd++] = o.sigs[o.tail];
+                    o.dep_user[o.tail] = (signed char)(target + 1);
+                }
+            }
+        const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                        (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        put_packet(hq, &bp, hdr, 0);
+    }
+    for (size_t j = 0; j < launches.size(); ++j) {
+        const RecLaunch& l = launches[j];
+        // completion signals are expensive on the device side (the packet processor updates one in host memory before it goes on: a
+        // dependent chain with a signal per packet ran at 4.5 us per launch, 2.9 without): with resident argument blocks only every
+        // 8th launch of a queue carries one (it retires its predecessors too; fences and cross-queue waits add a marker on demand);
+        // with argument blocks in the per-launch ring slots every launch needs its own
+        const bool want_sig = !e.arena || q.unsignaled >= 7;
+        const int si = want_sig ? eager_take_signal(e, q, target) : -1;
+        // the argument block: a resident one when this plan's launch j was issued with these very bytes before (the hot loop of a
+        // host program), else a fresh block -- in the arena when there is one (it becomes resident), in the launch's ring slot otherwise
+        unsigned char* b = nullptr;
+        bool fresh = true;
+        if (e.arena) {
+            for (Plan::ArgBlock& ab : plan.eager_args)
+                if (ab.launch == (int)j && ab.epoch == e.epoch && ab.bytes.size() == l.args.size() && std::memcmp(ab.bytes.data(), l.args.data(), l.args.size()) == 0) {
+                    b = (unsigned char*)ab.dev;
+                    fresh = false;
+                    ++e.n_arg_hits;
+                    break;
+                }
+            if (!b) {
+                const size_t need = (std::max<size_t>(refs[j].kernarg_size, ((l.args.size() + 7) & ~(size_t)7) + 128) + 255) & ~(size_t)255;
+                if (e.arena_used + need > e.arena_bytes) {  // start over: nothing in flight may still read an old block
+                    for (int k = 0; k < EAGER_Q; ++k) eager_wait_queue(e, d, k);
+                    e.arena_used = 0;
+                    ++e.epoch;
+                }
+                b = e.arena + e.arena_used;
+                e.arena_used += need;
+                if (plan.eager_args.size() >= 8) plan.eager_args.erase(plan.eager_args.begin());  // a few rebinding patterns per plan
+                Plan::ArgBlock ab;
+                ab.launch = (int)j;
+                ab.bytes = l.args;
+                ab.dev = b;
+                ab.epoch = e.epoch;
+                plan.eager_args.push_back(std::move(ab));
+            }
+        } else {
+            b = q.kargs + (size_t)si * EAGER_SLOT;
+        }
+        if (fresh) {
+            std::memcpy(b, l.args.data(), l.args.size());
+            const size_t hid = (l.args.size() + 7) & ~(size_t)7;
+            if (refs[j].kernarg_size >= hid + 72) {
+                std::memset(b + hid, 0, std::min<size_t>(refs[j].kernarg_size - hid, 128));
+                uint32_t bc[3] = {l.grid, 1, 1};
+                uint16_t gs[6] = {(uint16_t)l.block, 1, 1, 0, 0, 0};
+                std::memcpy(b + hid, bc, 12);
+                std::memcpy(b + hid + 12, gs, 12);
+                uint16_t gd = 1;
+                std::memcpy(b + hid + 64, &gd, 2);
+                if (refs[j].kernarg_size >= hid + 124) {
+                    uint32_t dl = l.lds;
+                    std::memcpy(b + hid + 120, &dl, 4);
+                }
+            }
+            if (e.kargs_device) {  // posted writes through the BAR: a read of the last byte written returns only after they have landed
+                const size_t used = std::max<size_t>(l.args.size(), refs[j].kernarg_size);
+                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                volatile unsigned char sink = ((volatile unsigned char*)b)[used ? used - 1 : 0];
+                (void)sink;
+            }
+        }
+        hsa_kernel_dispatch_packet_t pk;
+        std::memset(&pk, 0, sizeof pk);
+        pk.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        pk.workgroup_size_x = (uint16_t)l.block;
+        pk.workgroup_size_y = pk.workgroup_size_z = 1;
+        pk.grid_size_x = l.grid * l.block;
+        pk.grid_size_y = pk.grid_size_z = 1;
+        pk.group_segment_size = refs[j].group_static + l.lds;
+        pk.kernel_object = refs[j].object;
+        pk.kernarg_address = b;
+        pk.completion_signal = si >= 0 ? q.sigs[si] : hsa_signal_t{0};
+        // agent-scope fences like HIP's between kernels (the argument block is host-coherent memory, never cached in L2); the first
+        // launch after a copy acquires at system scope
+        put_packet(hq, &pk, header_of(true, ((e.sys_acquire >> target) & 1u) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT), pk.setup);
+        e.sys_acquire &= ~(1u << target);
+        Inflight f;
+        f.sig = si;
+        if (j + 1 == launches.size()) {  // the execution's ranges retire with its LAST launch
+            f.rd = rd;
+            f.wr = wr;
+        }
+        q.inflight.push_back(std::move(f));
+        q.tail = si;
+        q.unsignaled = si >= 0 ? 0 : q.unsignaled + 1;
+        ++e.n_launch;
+    }
+    return SMR_OK;
+}
+
+// everything submitted directly has completed when this returns (host wait)
+void eager_fence_all() {
+    Direct& d = direct();
+    if (!d.ok) return;
+    std::lock_guard<std::mutex> g(d.mu);
+    Eager& e = eager();
+    if (!e.ready) return;
+    for (int k = 0; k < EAGER_Q; ++k) eager_wait_queue(e, d, k);
+}
+void eager_note_hip_work() {
+    Direct& d = direct();
+    if (!d.ok) return;
+    std::lock_guard<std::mutex> g(d.mu);
+    eager().hip_pending = true;
+}
+void eager_request_sys_acquire() {  // device memory was written behind the queues' backs (a table upload by hipMemcpy)
+    Direct& d = direct();
+    if (!d.ok) return;
+    std::lock_guard<std::mutex> g(d.mu);
+    eager().sys_acquire = ~0u;
+}
+long eager_stat(int which) {
+    Eager& e = eager();
+    switch (which) {
+        case 0: return e.n_launch;
+        case 1: return e.n_free;
+        case 2: return e.n_same;
+        case 3: return e.n_cross;
+        case 5: return e.kargs_device ? 1 : 0;
+        case 7: return e.n_arg_hits;
+        case 6: return e.gpu_only_signals ? 1 : 0;
+        default: return e.n_fallback;
+    }
+}
+bool eager_available() { return direct().ok; }
+// for paths that must not create the direct queues as a side effect (freeing memory, destroying plans)
+void eager_fence_if_active() {
+    {
+        std::lock_guard<std::mutex> g(g_direct_mu);
+        if (g_direct.empty()) return;
+    }
+    if (eager().ready) eager_fence_all();
+}
+}  // namespace smr
+
 using namespace smr;
 
 // ---- the sequence object ----------------------------------------------------------------------------------------------------------
@@ -374,25 +861,6 @@ struct smr_seq {
 };
 
 namespace {
-typedef std::vector<std::pair<uintptr_t, uintptr_t>> Spans;
-bool overlaps(const Spans& v, const std::pair<uintptr_t, uintptr_t>& x) {
-    for (const auto& y : v)
-        if (x.first < y.second && y.first < x.second) return true;
-    return false;
-}
-bool overlaps(const Spans& v, const Spans& w) {
-    for (const auto& x : w)
-        if (overlaps(v, x)) return true;
-    return false;
-}
-
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-uint16_t header_of(bool barrier, int acq, int rel) {
-    return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
-                      (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
-}
-
 int seq_build(smr_seq* q) {
     for (auto& v : q->packets) v.clear();
     q->keep.clear();
@@ -739,6 +1207,7 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
         return SMR_OK;
     }
     Direct& d = direct();
+    eager_fence_all();  // launches a library-owned stream submitted directly share these queues: they come first
     std::lock_guard<std::mutex> g(d.mu);
     Hsa& h = hsa();
     // the previous replay on these queues must have completed before the completion signals are re-armed
