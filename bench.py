@@ -416,8 +416,30 @@ def main():
     assert ok2 and ok3, "independent-launch replays produced wrong outputs"
     step_us["seq_one_queue"], _ = seq_us(1, 2 * reps)
     step_us["seq_queue_per_component"], sinfo = seq_us(4, 2 * reps)
+    # the same step issued EAGERLY, call by call from Python, on a library-owned stream (eager direct dispatch: the library submits each
+    # launch itself on the hardware queue its data dependencies select) against eager calls on a HIP stream
+    def eager_us(handle, sync, nsteps=1000):
+        for _ in range(20):
+            plan2.execute(handle); plan3.execute(handle)
+        sync()
+        best = 1e30
+        for _ in range(5):
+            t = time.perf_counter()
+            for _ in range(nsteps):
+                plan2.execute(handle); plan3.execute(handle)
+            sync()
+            best = min(best, time.perf_counter() - t)
+        return round(best / nsteps * 1e6, 3)
+    torch.cuda.synchronize()
+    lib_stream = S.Stream()
+    step_us["eager_library_stream"] = eager_us(lib_stream.handle, lib_stream.synchronize)
+    lib_stream.close()
+    hs = torch.cuda.Stream()
+    step_us["eager_hip_stream"] = eager_us(int(hs.cuda_stream), hs.synchronize)
+    check_outputs("after the eager steps")
     step_us["note"] = ("inorder/chains: hipGraph replay, HIP events; seq_*: smr_seq replay of 1000 steps, host wall clock around "
-                       "smr_seq_run + smr_seq_wait (the replay does not run on a HIP stream)")
+                       "smr_seq_run + smr_seq_wait (the replay does not run on a HIP stream); eager_*: 1000 steps issued call by call from Python, wall clock "
+                       "including the final synchronisation")
     check_outputs("after the long replays")
     dom = ("broadcast4", ms3, bytes3, plan3) if ms3 >= ms2 else ("permutedims", ms2, bytes2, plan2)
     achieved = dom[2] / (dom[1] * 1e-3) / 1e9

@@ -27,7 +27,18 @@ const MAXN, MAXM = 8, 8
 # `@time`, debugging); `StridedHIP.synchronize()` waits explicitly.
 const ASYNC = Ref(true)
 async!(on::Bool=true) = (ASYNC[] = on; nothing)
-synchronize() = check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))
+# The shim's stream belongs to the library (smr_stream_create): on MI355X the library submits its launches itself -- AQL packets on
+# HSA queues it owns, the queue chosen by the operands' byte ranges, so that independent broadcasts overlap and a call costs ~1.8 us
+# of host time instead of HIP's 3.8 -- and fences by itself before every copy / synchronisation below.
+const STREAM = Ref{Ptr{Cvoid}}(C_NULL)
+function stream()
+    if STREAM[] == C_NULL
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        ccall((:smr_stream_create, lib), Cint, (Ptr{Ptr{Cvoid}},), r) == 0 && (STREAM[] = r[])   # on failure: the null stream, through HIP
+    end
+    return STREAM[]
+end
+synchronize() = check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), stream()))
 
 struct Unsupported <: Exception
     msg::String
@@ -61,13 +72,13 @@ Base.similar(b::HipBuffer, ::Type{T}, dims::Dims) where {T} = HipBuffer{T}(undef
 Base.getindex(::HipBuffer, I...) = error("scalar indexing of device memory: download(...) first")
 Base.setindex!(::HipBuffer, v, I...) = error("scalar indexing of device memory: upload(...) instead")
 function Base.copyto!(dst::HipBuffer{T,N}, src::Array{T,N}) where {T,N}   # host -> device
-    check(ccall((:smr_memcpy_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dst.ptr, src, sizeof(src), C_NULL))
-    check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))
+    check(ccall((:smr_memcpy_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dst.ptr, src, sizeof(src), stream()))
+    check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), stream()))
     return dst
 end
 function Base.copyto!(dst::Array{T,N}, src::HipBuffer{T,N}) where {T,N}   # device -> host
-    check(ccall((:smr_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dst, src.ptr, sizeof(dst), C_NULL))
-    check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), C_NULL))
+    check(ccall((:smr_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dst, src.ptr, sizeof(dst), stream()))
+    check(ccall((:smr_stream_sync, lib), Cint, (Ptr{Cvoid},), stream()))
     return dst
 end
 upload(a::Array{T,N}) where {T,N} = copyto!(HipBuffer{T}(undef, size(a)), a)
@@ -243,7 +254,7 @@ function _mapreduce_fuse!(f, op, initop, dims::Dims, arrays::Tuple{HipView,Varar
         GC.@preserve arrays prog begin
             p = Ref(SmrProblem(N, M, pad(dims, 1), ops, pointer(prog.code), length(prog.code) ÷ 2,
                                length(prog.consts) ÷ 2, pointer(prog.consts), redcode(op), ic,
-                               (real(β), imag(β)), C_NULL))
+                               (real(β), imag(β)), stream()))
             # one process per GPU: after `smr_comm_init` (see INTEGRATION.md) the same call shards the box over the
             # ranks and all-reduces a split reduced dim; with a single rank it is plain smr_mapreduce.  An `f`
             # without a precompiled functor is compiled for gfx950 on first use (library-side, cached).

@@ -174,6 +174,9 @@ int window_fence(hipStream_t s) {
 }
 }  // namespace
 
+// for the other translation units (smr_comm.cpp: the RCCL collective is foreign work on the stream)
+int fence_for_foreign_work(hipStream_t s) { return window_fence(s); }
+
 unsigned take_launch_flags() {
     const unsigned f = tl_launch_flags;
     tl_launch_flags = 0;

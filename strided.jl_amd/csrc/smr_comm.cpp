@@ -346,6 +346,8 @@ int smr_mapreduce_sharded_ex(const smr_problem* p, uint32_t local_ops) {
     }
     rc = copy_kept(p, s.staging, stage, 0);
     if (rc) return rc;
+    rc = fence_for_foreign_work((hipStream_t)p->stream);  // the gather above may have been submitted directly (library-owned stream)
+    if (rc) return rc;
     static const ncclRedOp_t ops[] = {ncclSum, ncclSum, ncclProd, ncclMin, ncclMax, ncclMin /* & on 0/1 */, ncclMax /* | on 0/1 */};
     ncclResult_t e = s.r.all_reduce(s.staging, s.staging, (size_t)count * mult, t, ops[p->redop], s.comm, (hipStream_t)p->stream);
     if (e != ncclSuccess) return nccl_error(e, "ncclAllReduce");

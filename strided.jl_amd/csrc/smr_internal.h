@@ -333,6 +333,10 @@ JitStats jit_stats();
 // AQL ordering of the next kernel launch of the calling thread (0 or hipExtAnyOrderLaunch), consumed by the first launch that asks
 // (SMR_LAUNCH in smr_dispatch.h, jit_launch): set by the overlap window in smr_api.cpp
 unsigned take_launch_flags();
+// Before work that does NOT go through the library's launchers is queued on `s` (a collective, a copy): inside an overlap window / on a
+// library-owned stream everything the library launched so far is ordered before it (and, on an owned stream, that work before the
+// library's next direct launch).  No-op on ordinary streams.
+int fence_for_foreign_work(hipStream_t s);
 
 // Recording (smr_seq.cpp): while a sequence records, SMR_LAUNCH / jit_launch append what they WOULD launch instead of launching it
 struct RecLaunch {

@@ -24,6 +24,9 @@ def main():
 
     torch.cuda.set_device(0)
     D.comm_init(world, rank, uid)
+    # with four ranks every call goes through a library-owned stream (eager direct dispatch): the gather and the scatter around the
+    # collective are then submitted by the library itself, and the collective is foreign work it has to fence for
+    lib_stream = S.Stream() if world == 4 else None
     got_rank, got_world = D.comm_rank()
     res = {"comm_rank": np.array([got_rank, got_world]), "library": np.array(D.comm_library())}
 
@@ -70,10 +73,17 @@ def main():
                 ins.append(v if perm is None else v.permutedims(perm))
             local.append(bool(loc))
         del full
-        D.comm_mapreduce_sharded_(MC.F[case["f"]], case["op"], case["initop"], dims, (dest,) + tuple(ins), local=tuple(local))
+        torch.cuda.synchronize()  # torch prepared the operands on its own stream
+        D.comm_mapreduce_sharded_(MC.F[case["f"]], case["op"], case["initop"], dims, (dest,) + tuple(ins), local=tuple(local),
+                                  stream=lib_stream.handle if lib_stream else None)
+        if lib_stream:
+            lib_stream.synchronize()
         torch.cuda.synchronize()
         res["dest_%d" % ci] = dparent.cpu().numpy()
         res["meta_%d" % ci] = np.array([need.value, sdim, start, stop])
+    if lib_stream:
+        res["eager_launches"] = np.array(S.get_option("eager_launches"))
+        lib_stream.close()
     D.comm_destroy()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **res)
 

@@ -68,6 +68,8 @@ def test_ranks_sharing_one_gpu(world, tmp_path):
     for r in range(world):
         assert tuple(res[r]["comm_rank"]) == (r, world)            # what the COMMUNICATOR says (ncclCommUserRank / ncclCommCount)
         assert str(res[r]["library"]).endswith("libfake_rccl.so")
+    if world == 4:  # these ranks ran everything on a library-owned stream
+        assert all(int(res[r]["eager_launches"]) > 20 for r in range(world))
     collectives = 0
     for ci, case in enumerate(MC.cases(world)):
         full = [MC.gen_input(case, k, ci) for k in range(len(case["ins"]))]
