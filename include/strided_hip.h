@@ -315,6 +315,10 @@ int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap);
  *   [6] lshare   [7] fuse   [8] kt   [9] N   then N dims, N destination strides, N strides of operand kt, N flags ingroup,
  *   R offsets roff[r] (line-side offset of leading index r of the flat run)                                                */
 int64_t smr_plan_flat_side(const smr_plan* plan, int64_t* out, size_t cap);
+/* The same for the BATCHED form (round 4: contiguous blocks on both sides, csrc/smr_k_flat.hip: flatb_body); 0 for any other plan:
+ *   [0] g (dims of a block)   [1] P (elements of a block)   [2] K (blocks per workgroup)   [3] N
+ *   then N dims, N destination strides, N input strides, P offsets srcoff[r] (input offset inside the block of destination position r) */
+int64_t smr_plan_flat_batched(const smr_plan* plan, int64_t* out, size_t cap);
 
 /* Runtime compilation.  An `f` without a natively compiled functor is specialised the way
  * Julia specialises the reference's @generated kernel per closure (src/mapreduce.jl:229-425):
@@ -389,7 +393,7 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * leading dims that are not powers of two, on/off), "flat2" (its two-sided form: 0 off, 1 planner's rule, 2 wherever it applies) /
  * "flat2_bytes" / "flat2_lead_bytes", "reduce_row_floor", "reduce_row_dense", "tile_block" (block tile order for distinct arrays with several unit
  * axes: -1 auto, 0 off, n), "tile_block_xcd", "orbit_group", "orbit_minrun", "orbit_wgs".  Experiment
- * switches: "stream_u", "stream_pack_rows", "orbit_lds_min", "orbit_skew", "tile_block_min_axes"; "stamp_base" / "stamp_cap" / "stamp_used" (debug build
+ * switches: "stream_u", "stream_pack_rows", "flatb" (batched FLAT form on/off), "eager_direct", "orbit_lds_min", "orbit_skew", "tile_block_min_axes"; "stamp_base" / "stamp_cap" / "stamp_used" (debug build
  * with device-side wall-clock stamps, csrc/smr_device.h).  Read-only counters through
  * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms", "overlap_any" / "overlap_ordered" /
  * "overlap_fences" (launches dispatched without / with the barrier bit inside overlap windows, fences issued); "eager_launches",

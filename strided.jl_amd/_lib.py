@@ -74,7 +74,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank", "smr_comm_library",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_plan_flat_batched", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank", "smr_comm_library",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option", "smr_overlap_begin", "smr_overlap_end", "smr_overlap_fence", "smr_stream_create", "smr_stream_destroy",
     "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_set", "smr_seq_destroy",
@@ -143,6 +143,8 @@ def load():
     lib.smr_plan_flat_runs.restype = C.c_int64
     lib.smr_plan_flat_side.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_size_t]
     lib.smr_plan_flat_side.restype = C.c_int64
+    lib.smr_plan_flat_batched.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_size_t]
+    lib.smr_plan_flat_batched.restype = C.c_int64
     lib.smr_shard.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.POINTER(smr_problem),
                               C.POINTER(C.c_int)]
     lib.smr_shard_ex.argtypes = [C.POINTER(smr_problem), C.c_int, C.c_int, C.c_uint32, C.POINTER(smr_problem),
@@ -348,6 +350,22 @@ class Plan:
             out[name] = v[o:o + N]
             o += N
         out["roff"] = v[o:o + out["R"]]
+        return out
+
+    def flat_batched(self):
+        """The batched FLAT form's plan as a dict (None for any other plan); layout: include/strided_hip.h."""
+        n = int(self._lib.smr_plan_flat_batched(self._h, None, 0))
+        if n == 0:
+            return None
+        buf = (C.c_int64 * n)()
+        self._lib.smr_plan_flat_batched(self._h, buf, n)
+        v = list(buf)
+        out = dict(g=v[0], P=v[1], K=v[2], N=v[3])
+        N, o = v[3], 4
+        for name in ("dims", "s0", "s1"):
+            out[name] = v[o:o + N]
+            o += N
+        out["srcoff"] = v[o:o + out["P"]]
         return out
 
     @property

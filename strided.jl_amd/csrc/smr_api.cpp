@@ -683,7 +683,7 @@ int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
 }
 
 int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap) {
-    if (!plan || plan->plan.family != FAM_FLAT || !plan->plan.flat2.on) return 0;
+    if (!plan || plan->plan.family != FAM_FLAT || !plan->plan.flat2.on || plan->plan.flatb.on) return 0;
     const Canon& c = plan->plan.c;
     const Flat2Plan& f = plan->plan.flat2;
     std::vector<int64_t> v = {f.kt, f.shared ? 1 : 0, c.N, f.R[0], f.R[1], f.TP[0], f.TP[1], f.p[0], f.p[1]};
@@ -700,7 +700,7 @@ int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap) {
 }
 
 int64_t smr_plan_flat_side(const smr_plan* plan, int64_t* out, size_t cap) {
-    if (!plan || plan->plan.family != FAM_FLAT || plan->plan.flat2.on) return 0;
+    if (!plan || plan->plan.family != FAM_FLAT || plan->plan.flat2.on || plan->plan.flatb.on) return 0;
     const Canon& c = plan->plan.c;
     const FlatPlan& f = plan->plan.flat;
     std::vector<int64_t> v = {f.dir, f.R, f.tplog, f.tqlog, f.p, f.q, f.lshare ? 1 : 0, f.fuse ? 1 : 0, f.kt, c.N};
@@ -709,6 +709,20 @@ int64_t smr_plan_flat_side(const smr_plan* plan, int64_t* out, size_t cap) {
     for (int d = 0; d < c.N; ++d) v.push_back(c.strides[f.kt][d]);
     for (int d = 0; d < c.N; ++d) v.push_back(f.ingroup[d] ? 1 : 0);
     for (int r = 0; r < f.R; ++r) v.push_back(f.roff[r]);
+    if (out)
+        for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return (int64_t)v.size();
+}
+
+int64_t smr_plan_flat_batched(const smr_plan* plan, int64_t* out, size_t cap) {
+    if (!plan || plan->plan.family != FAM_FLAT || !plan->plan.flatb.on) return 0;
+    const Canon& c = plan->plan.c;
+    const FlatBPlan& f = plan->plan.flatb;
+    std::vector<int64_t> v = {f.g, f.P, f.K, c.N};
+    for (int d = 0; d < c.N; ++d) v.push_back(c.dims[d]);
+    for (int d = 0; d < c.N; ++d) v.push_back(c.strides[0][d]);
+    for (int d = 0; d < c.N; ++d) v.push_back(c.strides[1][d]);
+    for (int r = 0; r < f.P; ++r) v.push_back(f.srcoff[r]);
     if (out)
         for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
     return (int64_t)v.size();
@@ -849,6 +863,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "tiled_persist") o.tiled_persist = value;
     else if (n == "stream_u") o.stream_u = value;
     else if (n == "stream_pack_rows") o.stream_pack_rows = value;
+    else if (n == "flatb") o.flatb = value;
     else if (n == "eager_direct") o.eager_direct = value;
     else if (n == "reduce_tree") o.reduce_tree = value;
     else if (n == "tiled_persist_wpc") o.tiled_persist_wpc = value;
@@ -911,6 +926,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "tiled_persist") return o.tiled_persist;
     if (n == "stream_u") return o.stream_u;
     if (n == "stream_pack_rows") return o.stream_pack_rows;
+    if (n == "flatb") return o.flatb;
     if (n == "eager_direct") return o.eager_direct;
     if (n == "eager_launches") return eager_stat(0);
     if (n == "eager_free") return eager_stat(1);

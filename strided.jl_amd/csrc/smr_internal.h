@@ -28,6 +28,7 @@ constexpr int MAXM = SMR_MAXM;
 constexpr int MAXIN = SMR_MAXM - 1;
 constexpr int STACK = 8;  // device evaluator stack depth (register-rotated)
 constexpr int MAXG = 4;   // FAM_ORBIT: largest permutation group handled (slots of LDS per workgroup)
+constexpr int FLATB_MAXP = 512;  // FAM_FLAT, batched form: largest contiguous block (elements)
 
 #ifndef SMR_JIT
 int set_error(int code, const std::string& msg);  // returns code
@@ -185,9 +186,19 @@ struct Flat2Plan {
     int32_t roff[2][64];  // roff[s][r]: element offset on the OTHER side of leading index r of side s's run
 };
 
+// FLAT, batched form (round 4): a unary map whose first g dims form ONE contiguous block of P elements on both sides (in different
+// orders: a small matrix / tensor transposed) and whose next dim continues both sides right behind it -- (9,11,N) -> (11,9,N),
+// batched transposes of small matrices.  A workgroup moves K consecutive batch entries: K * P contiguous elements on each side.
+struct FlatBPlan {
+    bool on = false;
+    int g = 0, P = 0, K = 1;
+    uint16_t srcoff[FLATB_MAXP];  // input offset (inside the block) of destination position r
+};
+
 struct Plan {
     Canon c;
     int family = FAM_GENERIC;
+    FlatBPlan flatb;
     TilePlan tile;
     OrbitPlan orbit;
     FlatPlan flat;
@@ -263,6 +274,7 @@ struct Options {
                                 // counters (shards of ~sqrt(chunks)); 0: a second launch folds, as in rounds 1-3
     i64 eager_direct = 1;       // launches on a library-owned stream (smr_stream_create) are submitted by the library itself (AQL packets on its HSA queues,
                                 // queue chosen by the data dependencies); 0: through HIP, in stream order
+    i64 flatb = 1;              // FLAT family: batched form for contiguous small blocks (batched transposes of small matrices)
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)

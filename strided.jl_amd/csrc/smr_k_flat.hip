@@ -334,6 +334,69 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
     }
 }
 
+// ---- batched form (round 4) ----------------------------------------------------------------------------------------------
+// FlatBPlan (smr_internal.h): blocks of P elements that are contiguous on BOTH sides, in different element orders, one behind the
+// other along the batch dim -- batched transposes of small matrices.  A workgroup owns K consecutive blocks = K * P consecutive
+// elements of either side: phase 1 streams them from the input into LDS (16-byte vectors when the chunk is aligned), phase 2 writes
+// the destination's K * P consecutive elements, each fetched from LDS at [block * P + srcoff[r]].  Both sides move at streaming
+// speed whatever the block's shape; (9,11,N) -> (11,9,N) ran at 1.4 TB/s in the two-sided form (99-element tiles, element-wise).
+struct FlatBArgs {
+    OpTab ops;
+    int32_t P, K, nouter, conjv;
+    uint32_t magicP, nchunk;              // floor(2^32 / P) + 1; chunks of K blocks along the batch dim
+    i64 nb;                               // extent of the batch dim
+    i64 oext[MAXN], ostr[MAXN];           // the dims behind it: extents and (common) strides
+    uint16_t srcoff[FLATB_MAXP];
+};
+
+template <class T, class F>
+SMR_DEV void flatb_body(const FlatBArgs a, F f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_flat[];
+    T* lds = reinterpret_cast<T*>(smem_flat);
+    uint16_t* tab = reinterpret_cast<uint16_t*>(smem_flat + (((size_t)a.K * a.P * sizeof(T) + 15) & ~(size_t)15));
+    const uint32_t tid = threadIdx.x;
+    uint32_t b = blockIdx.x;
+    const uint32_t ch = b % a.nchunk;
+    b /= a.nchunk;
+    i64 base = (i64)ch * a.K * a.P;
+    for (int i = 0; i < a.nouter; ++i) {
+        const uint32_t e = (uint32_t)a.oext[i];
+        const uint32_t c = b % e;
+        b /= e;
+        base += (i64)c * a.ostr[i];
+    }
+    const i64 left = a.nb - (i64)ch * a.K;
+    const int n = (int)((left < a.K ? left : a.K) * a.P);  // elements of this chunk
+    for (int r = (int)tid; r < a.P; r += 256) tab[r] = a.srcoff[r];
+    const T* src = (const T*)a.ops.base[1] + base;
+    constexpr int V = (16 / (int)sizeof(T)) > 1 ? (16 / (int)sizeof(T)) : 1;
+    const bool vec = V > 1 && (n % V) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)((T*)a.ops.base[0] + base) % 16) == 0;
+    if (vec) {
+        for (int t = (int)tid * V; t < n; t += 256 * V) *reinterpret_cast<FVec<T, V>*>(lds + t) = *reinterpret_cast<const FVec<T, V>*>(src + t);
+    } else {
+        for (int t = (int)tid; t < n; t += 256) lds[t] = src[t];
+    }
+    __syncthreads();
+    const bool anyconj = a.conjv != 0;
+    if (vec) {
+        for (int t = (int)tid * V; t < n; t += 256 * V) {
+            T tv[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const uint32_t blk = fdiv16((uint32_t)(t + e), a.magicP), r = (uint32_t)(t + e) - blk * (uint32_t)a.P;
+                tv[e] = lds[blk * (uint32_t)a.P + tab[r]];
+            }
+            flat_emit<T, F, V>(a.ops, 1, 1, anyconj, base + t, tv, f);
+        }
+    } else {
+        for (int t = (int)tid; t < n; t += 256) {
+            const uint32_t blk = fdiv16((uint32_t)t, a.magicP), r = (uint32_t)t - blk * (uint32_t)a.P;
+            const T tv[1] = {lds[blk * (uint32_t)a.P + tab[r]]};
+            flat_emit<T, F, 1>(a.ops, 1, 1, anyconj, base + t, tv, f);
+        }
+    }
+}
+
 #ifndef SMR_JIT
 template <class T, class F, int DIR, int VL, int VF>
 __global__ void __launch_bounds__(256) k_flat_map(const FlatArgs a, F f) {
@@ -342,6 +405,59 @@ __global__ void __launch_bounds__(256) k_flat_map(const FlatArgs a, F f) {
 template <class T, class F>
 __global__ void __launch_bounds__(256) k_flat2_map(const Flat2Args a, F f) {
     flat2_body<T, F>(a, f);
+}
+
+template <class T, class F>
+__global__ void __launch_bounds__(256) k_flatb_map(const FlatBArgs a, F f) {
+    flatb_body<T, F>(a, f);
+}
+
+template <class T, class F>
+static int gob(const Plan& plan, void* const* bases, hipStream_t s, F f) {
+    const Canon& c = plan.c;
+    const FlatBPlan& fp = plan.flatb;
+    FlatBArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.ops = make_optab(c, bases);
+    a.P = fp.P;
+    a.K = fp.K;
+    a.magicP = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)fp.P + 1);
+    a.nb = c.dims[fp.g];
+    a.nchunk = (uint32_t)((a.nb + fp.K - 1) / fp.K);
+    i64 blocks = a.nchunk;
+    for (int d = fp.g + 1; d < c.N; ++d) {
+        a.oext[a.nouter] = c.dims[d];
+        a.ostr[a.nouter] = c.strides[0][d];
+        blocks *= c.dims[d];
+        ++a.nouter;
+    }
+    if (c.conj[0] || c.conj[1]) a.conjv = 1;
+    std::memcpy(a.srcoff, fp.srcoff, sizeof(uint16_t) * (size_t)fp.P);
+    if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "flat plan: too many tiles");
+    const size_t lds = (((size_t)fp.K * fp.P * sizeof(T) + 15) & ~(size_t)15) + (((size_t)fp.P * sizeof(uint16_t) + 15) & ~(size_t)15);
+    const unsigned grid = (unsigned)blocks;
+    if constexpr (is_jit<F>::value) {
+        JitLaunch l;
+        l.family = "flat";
+        l.tname = tname<T>();
+        l.argtype = "smr::FlatBArgs";
+        l.entry = std::string("smr::flatb_body<") + tname<T>() + ", smr::FJit>(a, smr::FJit{kc});";
+        l.grid = grid;
+        l.block = 256;
+        l.lds = lds;
+        l.args = &a;
+        l.argsize = sizeof a;
+        return jit_launch(plan.c, l, s);
+    } else {
+        if (jit_no_launch()) return SMR_OK;
+        clear_sticky_error();
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_flatb_map<T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+        }
+        SMR_LAUNCH((k_flatb_map<T, F>), dim3(grid), dim3(256), lds, s, a, f);
+        return check_launch("k_flatb_map");
+    }
 }
 
 template <class T, class F>
@@ -527,6 +643,21 @@ int launch_flat_map_ct<SMR_CT>(const Plan& plan, void* const* bases, hipStream_t
     typedef ct_type<SMR_CT>::type T;
     const Canon& c = plan.c;
     const bool two = plan.flat2.on;
+    if (plan.flatb.on) {
+        if (c.bitcopy) {
+#if SMR_CT == SMR_F32
+            switch (c.esize[0]) {
+                case 4: return gob<float, FIdent<float>>(plan, bases, s, FIdent<float>{});
+                case 8: return gob<double, FIdent<double>>(plan, bases, s, FIdent<double>{});
+                case 16: return gob<c64, FIdent<c64>>(plan, bases, s, FIdent<c64>{});
+                default: return set_error(SMR_EINVAL, "flat plan: 1- / 2-byte moves take the generic family");
+            }
+#else
+            return set_error(SMR_EINVAL, "bitcopy is dispatched through the f32 object");
+#endif
+        }
+        return with_functor<T>(c, fbit(FK_IDENT) | fbit(FK_SCALE), [&](auto f) { return gob<T, decltype(f)>(plan, bases, s, f); });
+    }
     if (c.bitcopy) {
 #if SMR_CT == SMR_F32
         switch (c.esize[0]) {

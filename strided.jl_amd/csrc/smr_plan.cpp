@@ -1238,6 +1238,63 @@ static bool plan_flat(const Canon& c, FlatPlan& f) {
     return plan_flat_side(c, f, 0, es) || plan_flat_side(c, f, 1, es);
 }
 
+// Batched FLAT form: see FlatBPlan (smr_internal.h).  Conditions: one input; the destination's first g >= 2 dims are dense
+// (strides 1, n0, n0 n1, ...) with P = n0 ... n_{g-1} <= 512 elements and at most 4 KiB; the input's strides over those dims are a
+// dense layout of the same P elements in another order; dim g has stride P on both sides (consecutive blocks are adjacent); every
+// further dim has the same stride on both sides.
+static bool plan_flatb(const Canon& c, FlatBPlan& f) {
+    const Options& o = options();
+    f.on = false;
+    if (!o.flatb || !o.flat || c.redop != SMR_RED_NONE || c.M != 2 || c.mixed || c.N < 3) return false;
+    const int es = c.bitcopy ? c.esize[0] : dtype_size(c.ct);
+    if (es < 4 || c.total < 65536) return false;
+    if (c.strides[0][0] != 1) return false;
+    // the longest dense destination prefix that stays within the size limits
+    int g = 0;
+    i64 P = 1;
+    while (g < c.N - 1 && c.strides[0][g] == P && P * c.dims[g] <= FLATB_MAXP && P * c.dims[g] * es <= 4096) {
+        P *= c.dims[g];
+        ++g;
+    }
+    for (; g >= 2; P /= c.dims[g - 1], --g) {
+        // the input over dims 0..g-1: a dense permutation of the same block?
+        int ord[MAXN];
+        for (int i = 0; i < g; ++i) ord[i] = i;
+        std::sort(ord, ord + g, [&](int a, int b) { return c.strides[1][a] < c.strides[1][b]; });
+        i64 run = 1;
+        bool dense = true, moved = false;
+        for (int i = 0; i < g && dense; ++i) {
+            if (c.strides[1][ord[i]] != run) dense = false;
+            run *= c.dims[ord[i]];
+            if (ord[i] != i) moved = true;
+        }
+        if (!dense || !moved) continue;
+        if (c.strides[0][g] != P || c.strides[1][g] != P) continue;
+        bool same = true;
+        for (int d = g + 1; d < c.N; ++d)
+            if (c.strides[0][d] != c.strides[1][d]) same = false;
+        if (!same) continue;
+        f.g = g;
+        f.P = (int)P;
+        // K blocks per workgroup: about 4096 elements (32 KiB of Float64 in LDS), an even count so that 16-byte vectors line up
+        i64 K = std::max<i64>(1, 4096 / P);
+        K = std::min<i64>(K, c.dims[g]);
+        if (K > 1) K &= ~(i64)1;
+        f.K = (int)K;
+        for (i64 r = 0; r < P; ++r) {
+            i64 rem = r, off = 0;
+            for (int d = 0; d < g; ++d) {
+                off += (rem % c.dims[d]) * c.strides[1][d];
+                rem /= c.dims[d];
+            }
+            f.srcoff[r] = (uint16_t)off;
+        }
+        f.on = true;
+        return true;
+    }
+    return false;
+}
+
 // Two-sided FLAT form: the unit-stride dims of BOTH sides are short (under 256 bytes) and at least one of them is not a
 // power of two (or under 32 bytes): no power-of-two tile fits either side -- (17,33,65,31) reversed runs a 32 x 32 tile over a
 // 31 x 17 face with 51 % of its lanes.  Each side's run = its leading dims taken whole while the run stays short + a tile of the
@@ -1355,12 +1412,18 @@ int make_plan(const smr_problem* p, Plan& plan) {
     const Options& o = options();
     int fam = FAM_GENERIC;
     plan.flat2.on = false;
+    plan.flatb.on = false;
     // FLAT: the one-sided form first -- unless its line side is under 8 elements long, where the two-sided form's bigger tiles win
     // (ComplexF64 (6,64,64,64,5) reversed 94 -> 40 us, (4,300,300,3) 16.5 -> 7.6; with 24-element lines the one-sided form's
     // vector accesses are 1.5x ahead; profiles/r03_flat2_ab.txt).  flat2 = 2: the two-sided form wherever it applies (experiments)
     bool flat_ok = c.redop == SMR_RED_NONE && o.force_family == 0;
     // several inputs that are permuted views of ONE buffer: the orbit kernel reads the buffer once, the n-ary FLAT forms would read it per view
     if (flat_ok && c.M > 2 && plan_orbit(c, plan.orbit)) flat_ok = false;
+    if (flat_ok && plan_flatb(c, plan.flatb)) {
+        plan.family = FAM_FLAT;
+        describe(plan);
+        return SMR_OK;
+    }
     const bool one = flat_ok && plan_flat(c, plan.flat);
     const bool two_first = flat_ok && (o.flat2 >= 2 || !one || (!plan.flat.fuse && !plan.flat.lshare && c.dims[plan.flat.q] < 8));
     if (two_first && plan_flat2(c, plan.flat2)) {
@@ -1620,6 +1683,8 @@ void describe(Plan& plan) {
                 first = false;
             }
         n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.list.size());
+    } else if (plan.family == FAM_FLAT && plan.flatb.on) {
+        n += std::snprintf(buf + n, sizeof buf - n, " batched block=%d(d0..d%d) blocks_per_wg=%d", plan.flatb.P, plan.flatb.g - 1, plan.flatb.K);
     } else if (plan.family == FAM_FLAT && plan.flat2.on) {
         const Flat2Plan& f2 = plan.flat2;
         n += std::snprintf(buf + n, sizeof buf - n, " two-sided dest_run=%dx%d(d%d) input_run=%dx%d(d%d)%s", f2.R[0], f2.TP[0], f2.p[0], f2.R[1], f2.TP[1], f2.p[1],

@@ -544,7 +544,15 @@ def _walk_two_sided_flat(fr):
     return np.concatenate(dst), np.concatenate(src)
 
 
-def test_two_sided_flat_plans_move_every_element_exactly_once():
+@pytest.fixture()
+def no_batched_flat():
+    """the batched FLAT form (round 4) takes precedence where it applies; these walks are about the forms behind it"""
+    S.set_option("flatb", 0)
+    yield
+    S.set_option("flatb", 1)
+
+
+def test_two_sided_flat_plans_move_every_element_exactly_once(no_batched_flat):
     """Planner check without a GPU: for a spread of shapes / permutations that take the two-sided FLAT form, walk all tiles with the
     plan's own numbers (runs, tiles, offset tables) and compare with the definition -- destination offset sum(i_d * s0_d) receives input
     offset sum(i_d * s1_d) for every index of the box, once."""
@@ -624,7 +632,7 @@ def _walk_one_sided_flat(fs, es):
     return (fl, ln) if fs["dir"] == 0 else (ln, fl)
 
 
-def test_one_sided_flat_plans_move_every_element_exactly_once():
+def test_one_sided_flat_plans_move_every_element_exactly_once(no_batched_flat):
     """The same planner check for the one-sided FLAT forms: plain (either operand flat), fused (planar <-> interleaved) and shared-lead
     (transposition of R-element groups), ragged tiles along both tiled dims, outer dims."""
     rng = np.random.default_rng(7)
@@ -655,3 +663,50 @@ def test_one_sided_flat_plans_move_every_element_exactly_once():
                 assert np.array_equal(got_d[o1], want_d[o2]), msg
                 assert np.array_equal(got_s[o1], want_s[o2]), msg
     assert seen["plain0"] >= 10 and seen["plain1"] >= 10 and seen["fuse"] >= 5 and seen["lshare"] >= 3, dict(seen)
+
+
+def test_batched_flat_plans_move_every_element_exactly_once():
+    """The batched FLAT form (round 4): blocks of P elements contiguous on both sides.  Walk every workgroup's chunk with the plan's own
+    numbers (block size, blocks per workgroup, the srcoff table) exactly as csrc/smr_k_flat.hip:flatb_body does and compare with the
+    definition -- destination offset sum(i_d * s0_d) receives input offset sum(i_d * s1_d), once."""
+    shapes = [((9, 11, 3000), (1, 0, 2)), ((5, 9, 4001), (1, 0, 2)), ((17, 23, 700), (1, 0, 2)), ((3, 4, 5, 2000), (2, 0, 1, 3)), ((3, 4, 5, 2000), (1, 2, 0, 3)),
+              ((7, 6, 333, 9), (1, 0, 2, 3)), ((2, 2, 2, 2, 5000), (3, 1, 2, 0, 4)), ((16, 16, 999), (1, 0, 2)), ((3, 100, 70, 5), (1, 0, 2, 3)),
+              ((9, 11, 300, 300), (1, 0, 3, 2)), ((31, 29, 1000), (1, 0, 2)), ((9, 11, 70000), (0, 1, 2))]
+    seen = 0
+    for shape, q in shapes:
+        for dt in (np.float64, np.float32, np.complex128):
+            a = S.StridedView(np.zeros(shape, dtype=dt, order="F"))
+            b = S.StridedView(np.zeros(tuple(shape[i] for i in q), dtype=dt, order="F"))
+            plan = S.make_plan(lambda x: x, None, None, b.size, (b, a.permutedims(q)))
+            fb = plan.flat_batched()
+            es = np.dtype(dt).itemsize
+            if fb is None:
+                # outside the form: no batch dim right behind the block on both sides, the identity, or a block over 4 KiB / 512 elements
+                assert (q == tuple(range(len(q)))) or (shape, q) == ((9, 11, 300, 300), (1, 0, 3, 2)) or shape[0] * shape[1] * es > 4096 or shape[0] * shape[1] > 512, (shape, q, dt)
+                continue
+            seen += 1
+            g, P, K, N = fb["g"], fb["P"], fb["K"], fb["N"]
+            dims, s0, s1 = fb["dims"], np.array(fb["s0"], dtype=np.int64), np.array(fb["s1"], dtype=np.int64)
+            assert P == int(np.prod(dims[:g])) and P * es <= 4096 and P <= 512 and s0[g] == P and s1[g] == P
+            idx = np.indices(dims).reshape(N, -1).astype(np.int64)
+            want_d, want_s = (idx * s0[:, None]).sum(0), (idx * s1[:, None]).sum(0)
+            nb = dims[g]
+            outer = np.indices(dims[g + 1:]).reshape(N - g - 1, -1).astype(np.int64) if N > g + 1 else np.zeros((0, 1), dtype=np.int64)
+            obase = (outer * s0[g + 1:, None]).sum(0) if N > g + 1 else np.zeros(1, dtype=np.int64)
+            srcoff = np.array(fb["srcoff"], dtype=np.int64)
+            got_d, got_s = [], []
+            for ch in range((nb + K - 1) // K):
+                n = min(K, nb - ch * K) * P
+                t = np.arange(n, dtype=np.int64)
+                blk, r = t // P, t % P
+                d_local = ch * K * P + t                    # destination: the chunk's elements in memory order
+                s_local = ch * K * P + blk * P + srcoff[r]  # input: the same block, position srcoff[r]
+                got_d.append((obase[:, None] + d_local[None, :]).ravel())
+                got_s.append((obase[:, None] + s_local[None, :]).ravel())
+            got_d, got_s = np.concatenate(got_d), np.concatenate(got_s)
+            msg = (shape, q, np.dtype(dt).name, plan.describe())
+            assert got_d.size == want_d.size, msg
+            o1, o2 = np.argsort(got_d, kind="stable"), np.argsort(want_d, kind="stable")
+            assert np.array_equal(got_d[o1], want_d[o2]), msg
+            assert np.array_equal(got_s[o1], want_s[o2]), msg
+    assert seen >= 20, seen

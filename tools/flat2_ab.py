@@ -44,7 +44,10 @@ for dt in (torch.float64, torch.float32):
         n = len(shape)
         ref = tA.reshape(tuple(reversed(shape))).permute(*[n - 1 - q[n - 1 - i] for i in range(n)]).contiguous().reshape(-1)
         row = []
-        for mode, lead, rb in ((0, 512, 384), (1, 512, 384), (2, 512, 384)):
+        # round 4: the batched form (contiguous blocks on both sides) ahead of the forms of round 3 ("flatb" = 0: as in round 3)
+        for mode, lead, rb in ((-1, 512, 384), (0, 512, 384), (1, 512, 384), (2, 512, 384)):
+            S._lib.check(lib.smr_set_option(b"flatb", 1 if mode < 0 else 0))
+            mode = max(mode, 1) if mode < 0 else mode
             S._lib.check(lib.smr_set_option(b"flat2", mode))
             S._lib.check(lib.smr_set_option(b"flat2_lead_bytes", lead))
             S._lib.check(lib.smr_set_option(b"flat2_bytes", rb))
@@ -53,8 +56,9 @@ for dt in (torch.float64, torch.float32):
             us = time_plan(plan, 50)
             ok = torch.equal(tB, ref)
             d = plan.describe()
-            lab = "flat2" if "two-sided" in d else d[d.find("family=") + 7:d.find(" ct=")]
+            lab = "flatb" if "batched" in d else ("flat2" if "two-sided" in d else d[d.find("family=") + 7:d.find(" ct=")])
             row.append("%s/%d/%d %-5s %6.2f%s" % (mode, lead, rb, lab, us, "" if ok else " WRONG"))
+        S._lib.check(lib.smr_set_option(b"flatb", 1))
         S._lib.check(lib.smr_set_option(b"flat2", KEEP))
         S._lib.check(lib.smr_set_option(b"flat2_lead_bytes", 512))
         S._lib.check(lib.smr_set_option(b"flat2_bytes", 384))
