@@ -345,7 +345,8 @@ struct FlatBArgs {
     int32_t P, K, nouter, conjv;
     uint32_t magicP, nchunk;              // floor(2^32 / P) + 1; chunks of K blocks along the batch dim
     i64 nb;                               // extent of the batch dim
-    i64 oext[MAXN], ostr[MAXN];           // the dims behind it: extents and (common) strides
+    i64 sstr;                             // input stride of the batch dim (P: the input's blocks are adjacent too)
+    i64 oext[MAXN], ostr[MAXN], ostr1[MAXN];  // the dims behind it: extents, destination strides, input strides
     uint16_t srcoff[FLATB_MAXP];
 };
 
@@ -358,23 +359,30 @@ SMR_DEV void flatb_body(const FlatBArgs a, F f) {
     uint32_t b = blockIdx.x;
     const uint32_t ch = b % a.nchunk;
     b /= a.nchunk;
-    i64 base = (i64)ch * a.K * a.P;
+    i64 base = (i64)ch * a.K * a.P, base1 = (i64)ch * a.K * a.sstr;
     for (int i = 0; i < a.nouter; ++i) {
         const uint32_t e = (uint32_t)a.oext[i];
         const uint32_t c = b % e;
         b /= e;
         base += (i64)c * a.ostr[i];
+        base1 += (i64)c * a.ostr1[i];
     }
     const i64 left = a.nb - (i64)ch * a.K;
     const int n = (int)((left < a.K ? left : a.K) * a.P);  // elements of this chunk
     for (int r = (int)tid; r < a.P; r += 256) tab[r] = a.srcoff[r];
-    const T* src = (const T*)a.ops.base[1] + base;
+    const T* src = (const T*)a.ops.base[1] + base1;
     constexpr int V = (16 / (int)sizeof(T)) > 1 ? (16 / (int)sizeof(T)) : 1;
-    const bool vec = V > 1 && (n % V) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)((T*)a.ops.base[0] + base) % 16) == 0;
-    if (vec) {
+    const bool adjacent = a.sstr == a.P;  // the chunk is contiguous in the input as well
+    const bool vec = V > 1 && (n % V) == 0 && ((uintptr_t)((T*)a.ops.base[0] + base) % 16) == 0;
+    if (vec && adjacent && ((uintptr_t)src % 16) == 0) {
         for (int t = (int)tid * V; t < n; t += 256 * V) *reinterpret_cast<FVec<T, V>*>(lds + t) = *reinterpret_cast<const FVec<T, V>*>(src + t);
-    } else {
+    } else if (adjacent) {
         for (int t = (int)tid; t < n; t += 256) lds[t] = src[t];
+    } else {  // block by block: P consecutive elements each
+        for (int t = (int)tid; t < n; t += 256) {
+            const uint32_t blk = fdiv16((uint32_t)t, a.magicP), r = (uint32_t)t - blk * (uint32_t)a.P;
+            lds[t] = src[(i64)blk * a.sstr + r];
+        }
     }
     __syncthreads();
     const bool anyconj = a.conjv != 0;
@@ -428,9 +436,11 @@ static int gob(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     for (int d = fp.g + 1; d < c.N; ++d) {
         a.oext[a.nouter] = c.dims[d];
         a.ostr[a.nouter] = c.strides[0][d];
+        a.ostr1[a.nouter] = c.strides[1][d];
         blocks *= c.dims[d];
         ++a.nouter;
     }
+    a.sstr = c.strides[1][fp.g];
     if (c.conj[0] || c.conj[1]) a.conjv = 1;
     std::memcpy(a.srcoff, fp.srcoff, sizeof(uint16_t) * (size_t)fp.P);
     if (blocks > 0x7fffffffLL) return set_error(SMR_EUNSUPPORTED, "flat plan: too many tiles");

@@ -1240,8 +1240,9 @@ static bool plan_flat(const Canon& c, FlatPlan& f) {
 
 // Batched FLAT form: see FlatBPlan (smr_internal.h).  Conditions: one input; the destination's first g >= 2 dims are dense
 // (strides 1, n0, n0 n1, ...) with P = n0 ... n_{g-1} <= 512 elements and at most 4 KiB; the input's strides over those dims are a
-// dense layout of the same P elements in another order; dim g has stride P on both sides (consecutive blocks are adjacent); every
-// further dim has the same stride on both sides.
+// dense layout of the same P elements in another order; dim g has stride P in the destination (consecutive blocks are adjacent
+// there).  When the input's blocks follow one another the same way and the dims behind agree, a chunk is contiguous on both sides;
+// otherwise (blocks of at least 256 bytes) the input side is read block by block.
 static bool plan_flatb(const Canon& c, FlatBPlan& f) {
     const Options& o = options();
     f.on = false;
@@ -1269,11 +1270,13 @@ static bool plan_flatb(const Canon& c, FlatBPlan& f) {
             if (ord[i] != i) moved = true;
         }
         if (!dense || !moved) continue;
-        if (c.strides[0][g] != P || c.strides[1][g] != P) continue;
-        bool same = true;
+        // the destination's blocks follow one another along dim g; the input's blocks may sit anywhere (a batch grid that is permuted
+        // as well: (9,11,300,300) -> (11,9,300',300)): its side then moves in whole blocks, which must not be tiny
+        if (c.strides[0][g] != P) continue;
+        bool same = c.strides[1][g] == P;
         for (int d = g + 1; d < c.N; ++d)
             if (c.strides[0][d] != c.strides[1][d]) same = false;
-        if (!same) continue;
+        if (!same && (P * es < 256 || c.strides[1][g] < P)) continue;
         f.g = g;
         f.P = (int)P;
         // K blocks per workgroup: about 4096 elements (32 KiB of Float64 in LDS), an even count so that 16-byte vectors line up

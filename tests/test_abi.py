@@ -671,7 +671,8 @@ def test_batched_flat_plans_move_every_element_exactly_once():
     definition -- destination offset sum(i_d * s0_d) receives input offset sum(i_d * s1_d), once."""
     shapes = [((9, 11, 3000), (1, 0, 2)), ((5, 9, 4001), (1, 0, 2)), ((17, 23, 700), (1, 0, 2)), ((3, 4, 5, 2000), (2, 0, 1, 3)), ((3, 4, 5, 2000), (1, 2, 0, 3)),
               ((7, 6, 333, 9), (1, 0, 2, 3)), ((2, 2, 2, 2, 5000), (3, 1, 2, 0, 4)), ((16, 16, 999), (1, 0, 2)), ((3, 100, 70, 5), (1, 0, 2, 3)),
-              ((9, 11, 300, 300), (1, 0, 3, 2)), ((31, 29, 1000), (1, 0, 2)), ((9, 11, 70000), (0, 1, 2))]
+              ((9, 11, 300, 300), (1, 0, 3, 2)), ((31, 29, 1000), (1, 0, 2)), ((9, 11, 70000), (0, 1, 2)), ((5, 9, 300, 300), (1, 0, 3, 2)),
+              ((4, 8, 60, 50, 7), (1, 0, 4, 2, 3)), ((13, 5, 40, 30), (1, 0, 3, 2))]
     seen = 0
     for shape, q in shapes:
         for dt in (np.float64, np.float32, np.complex128):
@@ -681,18 +682,21 @@ def test_batched_flat_plans_move_every_element_exactly_once():
             fb = plan.flat_batched()
             es = np.dtype(dt).itemsize
             if fb is None:
-                # outside the form: no batch dim right behind the block on both sides, the identity, or a block over 4 KiB / 512 elements
-                assert (q == tuple(range(len(q)))) or (shape, q) == ((9, 11, 300, 300), (1, 0, 3, 2)) or shape[0] * shape[1] * es > 4096 or shape[0] * shape[1] > 512, (shape, q, dt)
+                # outside the form: the identity, a block over 4 KiB / 512 elements, or input blocks under 256 bytes that are not adjacent
+                permuted_grid = tuple(q[2:]) != tuple(range(2, len(q)))
+                assert (q == tuple(range(len(q)))) or shape[0] * shape[1] * es > 4096 or shape[0] * shape[1] > 512 or \
+                    (permuted_grid and shape[0] * shape[1] * es < 256), (shape, q, dt)
                 continue
             seen += 1
             g, P, K, N = fb["g"], fb["P"], fb["K"], fb["N"]
             dims, s0, s1 = fb["dims"], np.array(fb["s0"], dtype=np.int64), np.array(fb["s1"], dtype=np.int64)
-            assert P == int(np.prod(dims[:g])) and P * es <= 4096 and P <= 512 and s0[g] == P and s1[g] == P
+            assert P == int(np.prod(dims[:g])) and P * es <= 4096 and P <= 512 and s0[g] == P and s1[g] >= P
             idx = np.indices(dims).reshape(N, -1).astype(np.int64)
             want_d, want_s = (idx * s0[:, None]).sum(0), (idx * s1[:, None]).sum(0)
             nb = dims[g]
             outer = np.indices(dims[g + 1:]).reshape(N - g - 1, -1).astype(np.int64) if N > g + 1 else np.zeros((0, 1), dtype=np.int64)
             obase = (outer * s0[g + 1:, None]).sum(0) if N > g + 1 else np.zeros(1, dtype=np.int64)
+            obase1 = (outer * s1[g + 1:, None]).sum(0) if N > g + 1 else np.zeros(1, dtype=np.int64)
             srcoff = np.array(fb["srcoff"], dtype=np.int64)
             got_d, got_s = [], []
             for ch in range((nb + K - 1) // K):
@@ -700,9 +704,9 @@ def test_batched_flat_plans_move_every_element_exactly_once():
                 t = np.arange(n, dtype=np.int64)
                 blk, r = t // P, t % P
                 d_local = ch * K * P + t                    # destination: the chunk's elements in memory order
-                s_local = ch * K * P + blk * P + srcoff[r]  # input: the same block, position srcoff[r]
+                s_local = (ch * K + blk) * s1[g] + srcoff[r]  # input: the same block (wherever it sits), position srcoff[r]
                 got_d.append((obase[:, None] + d_local[None, :]).ravel())
-                got_s.append((obase[:, None] + s_local[None, :]).ravel())
+                got_s.append((obase1[:, None] + s_local[None, :]).ravel())
             got_d, got_s = np.concatenate(got_d), np.concatenate(got_s)
             msg = (shape, q, np.dtype(dt).name, plan.describe())
             assert got_d.size == want_d.size, msg

