@@ -274,6 +274,7 @@ struct Options {
                                 // counters (shards of ~sqrt(chunks)); 0: a second launch folds, as in rounds 1-3
     i64 eager_direct = 1;       // launches on a library-owned stream (smr_stream_create) are submitted by the library itself (AQL packets on its HSA queues,
                                 // queue chosen by the data dependencies); 0: through HIP, in stream order
+    i64 flat2_long = 80;        // two-sided FLAT form for LONG unit-stride dims (arrays of >= 8 MiB) whose 32 x 32 tiles would be under this many per cent full (0: off)
     i64 flatb = 1;              // FLAT family: batched form for contiguous small blocks (batched transposes of small matrices)
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows

@@ -287,6 +287,9 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
         if (a.shared) {
             r = (int)fdiv16((uint32_t)t, a.magicTP0);
             jp = t - r * a.TP[0];
+        } else if (a.R[0] == 1) {  // (the magic number of 1 does not fit 32 bits) a run that is a tile of the unit dim itself
+            jp = t;
+            r = 0;
         } else {
             jp = (int)fdiv16((uint32_t)t, a.magicR[0]);
             r = t - jp * a.R[0];
@@ -295,7 +298,7 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
         xcol[t] = r + jp * a.R[0];
     }
     for (int y = 255 - (int)tid; y < L1; y += 256) {  // (the other end of the workgroup: L0 + L1 <= 256 is the common case)
-        const int jp = (int)fdiv16((uint32_t)y, a.magicR[1]), r = y - jp * a.R[1];
+        const int jp = a.R[1] == 1 ? y : (int)fdiv16((uint32_t)y, a.magicR[1]), r = y - jp * a.R[1];
         offd[y] = (i64)a.roff[1][r] + (i64)jp * a.spo[1];
     }
     __syncthreads();

@@ -1318,18 +1318,41 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
             if (st[s][d] == 1 && c.dims[d] > 1) lead[s] = d;
         }
     if (lead[0] < 0 || lead[1] < 0 || lead[0] == lead[1]) return false;
-    bool awkward = false;
+    // Round 4: a LONG unit-stride dim that 32-wide power-of-two tiles fit badly (100 -> 3 x 32 + 4: a quarter of the last tile's lanes,
+    // 257 -> 8 x 32 + 1) is cut EVENLY instead -- its side's run is then a tile of the unit dim itself (R = 1, p = the lead,
+    // TP = extent / ceil(extent / ~48)): (100,90,80) -> tiles of 34 x 30, no lane idles.
+    // Measured (tools/flat2_long_ab.py, profiles/r04_flat2_long_ab.txt, Float64): (257,129,65) 12.3-14.0 -> 9.5-10.1 us, (17,33,65,31)
+    // (3,2,0,1) 9.0 -> 6.5 us, (999,1001) 7.2 -> 6.4 us; but (100,90,80) (6 MB) 5.5 -> 6.4 us and well-filled tiles ((200,300,70),
+    // (1400,1500), (4000,4100), every power of two) stay ahead in TILED -- so: the padded tiles would be under flat2_long % full and
+    // the array has at least 8 MiB, or the OTHER side's lead is short and awkward anyway.
+    bool awkward = false, cutlead[2] = {false, false};
+    long double fill = 1;
     for (int s = 0; s < 2; ++s) {
         const i64 e = c.dims[lead[s]];
-        if (e * es >= o.flat2_lead_bytes) return false;
+        if (e * es >= o.flat2_lead_bytes) {
+            if (!o.flat2_long || c.M != 2) return false;
+            cutlead[s] = true;
+            fill *= (long double)e / (long double)((e + 31) / 32 * 32);
+            continue;
+        }
         if ((e & (e - 1)) != 0 || e * es < 32) awkward = true;
     }
+    if ((cutlead[0] || cutlead[1]) && fill * 100 < (long double)o.flat2_long && c.total * es >= ((i64)8 << 20)) awkward = true;
     if (!awkward) return false;
     bool used[MAXN];
     for (int d = 0; d < MAXN; ++d) used[d] = f.ingroup[0][d] = f.ingroup[1][d] = false;
     used[lead[0]] = used[lead[1]] = true;
     const i64 target = std::max<i64>(64, o.flat2_bytes);
     for (int s = 0; s < 2; ++s) {
+        if (cutlead[s]) {
+            const i64 e = c.dims[lead[s]];
+            i64 tp = std::max<i64>(8, std::min<i64>(target / es, 128));
+            const i64 nt = (e + tp - 1) / tp;
+            f.R[s] = 1;
+            f.p[s] = lead[s];
+            f.TP[s] = (int)((e + nt - 1) / nt);
+            continue;
+        }
         f.ingroup[s][lead[s]] = true;
         i64 R = c.dims[lead[s]];
         f.p[s] = -1;

@@ -558,7 +558,8 @@ def test_two_sided_flat_plans_move_every_element_exactly_once(no_batched_flat):
     offset sum(i_d * s1_d) for every index of the box, once."""
     rng = np.random.default_rng(2026)
     shapes = [(5, 60, 50, 7), (17, 9, 33, 31), (3, 100, 90, 3), (7, 30, 40, 9), (6, 16, 16, 16, 5), (12, 10, 14, 9, 11), (10, 50, 60, 10), (31, 65, 33, 17),
-              (5, 3000, 7), (3, 40, 50, 3, 9), (24, 30, 30, 20), (9, 11, 700), (13, 6, 900, 2)]
+              (5, 3000, 7), (3, 40, 50, 3, 9), (24, 30, 30, 20), (9, 11, 700), (13, 6, 900, 2),
+              (100, 90, 80), (257, 129, 65), (70, 100, 33), (17, 200, 90)]   # round 4: long unit-stride dims cut evenly (R = 1, p = the lead)
     seen = shared = ragged = 0
     for shape in shapes:
         n = len(shape)

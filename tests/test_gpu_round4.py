@@ -132,3 +132,35 @@ def test_two_level_fold_is_reproducible_and_accurate_on_real_data():
         assert np.allclose(out.toarray(), want + 2.0, rtol=0, atol=2e-3 * np.sqrt(50400))
     finally:
         S.set_option("reduce_tree", 0)
+
+
+@pytest.mark.parametrize("shape", [(100, 90, 80), (257, 129, 65), (17, 33, 65, 31), (200, 300, 70), (999, 1001), (130, 70, 50, 9), (1400, 1500)])
+@pytest.mark.parametrize("dt", [np.float64, np.float32, np.complex128])
+def test_ragged_transposes_with_long_unit_dims(shape, dt):
+    """Two-sided FLAT form with evenly cut leads (round 4): every permutation that moves dim 0, bit-exact vs NumPy; the same with
+    the form switched off (TILED)."""
+    import itertools
+    import torch
+    rng = np.random.default_rng(sum(shape))
+    a = rng.standard_normal(shape).astype(dt)
+    A = dview(a)
+    n = len(shape)
+    perms = [q for q in itertools.permutations(range(n)) if q[0] != 0]
+    if n == 4:
+        perms = [(3, 2, 1, 0), (3, 2, 0, 1), (1, 0, 2, 3), (2, 3, 0, 1), (1, 3, 0, 2)]
+    hit = 0
+    for q in perms:
+        out = dview(np.zeros(tuple(shape[i] for i in q), dtype=dt))
+        for v in (100, 0):   # 100: wherever the form applies (every array here has fewer than 8 MiB or well-filled tiles otherwise)
+            S.set_option("flat2_long", v)
+            try:
+                plan = S.make_plan(lambda x: x, None, None, out.size, (out, A.permutedims(q)))
+                hit += int("two-sided" in plan.describe() and v == 100)
+                out.parent.zero_()
+                plan.execute()
+                torch.cuda.synchronize()
+            finally:
+                S.set_option("flat2_long", 80)
+            assert np.array_equal(out.toarray(), np.transpose(a, q)), (shape, q, v, plan.describe())
+    if shape == (257, 129, 65) and dt == np.float64:
+        assert hit >= 2, hit
