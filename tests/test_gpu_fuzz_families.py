@@ -233,7 +233,7 @@ def test_family_targeted_random_problems_match_the_oracle(name, monkeypatch):
         oraclelib.mapreduce(p, 4)
         return arrays[0]
 
-    n = {"reduce_short": 24, "flat2": 44, "tiled_big": 40, "tiled_blocks": 30, "flat": 56, "generic": 150, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
+    n = {"reduce_short": 24, "flat2": 44, "tiled_big": 40, "tiled_blocks": 30, "flat": 56, "generic": 200, "stream": 40, "tiled": 40, "tiled_reversed": 40, "tiled_persistent": 40, "aliased_classic": 40, "orbit_pipe": 30, "tiled_short0": 30}.get(name, 60)
     fam = collections.Counter()
     for i in range(n):
         for T in TYPES:
