@@ -395,25 +395,6 @@ def main():
             q.run(nsteps, cur()); q.wait()
             best = min(best, time.perf_counter() - t)
         return round(best / nsteps * 1e6, 3), q.info()
-    def independent_us(plan, nout, nin_same):
-        """Throughput of ONE kernel when consecutive launches are independent (the same input, four rotating output arrays -> four
-        dependency components -> four hardware queues): wall clock per launch of an smr_seq replay, best of 7."""
-        outs = [torch.empty_like(tA) for _ in range(4)]
-        q = S.Sequence()
-        for o in outs:
-            q.add(plan, bases=[o.data_ptr()] + [tA.data_ptr()] * nin_same)
-        q.run(5, cur()); q.wait()
-        best = 1e30
-        for _ in range(7):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            q.run(250, cur()); q.wait()
-            best = min(best, time.perf_counter() - t)
-        ok = all(torch.equal(o, nout) for o in outs)
-        return round(best / 1000 * 1e6, 3), ok, q.info()
-    ind2, ok2, _ = independent_us(plan2, ref2, 1)
-    ind3, ok3, iinfo = independent_us(plan3, ref3, 4)
-    assert ok2 and ok3, "independent-launch replays produced wrong outputs"
     step_us["seq_one_queue"], _ = seq_us(1, 2 * reps)
     step_us["seq_queue_per_component"], sinfo = seq_us(4, 2 * reps)
     # the same step issued EAGERLY, call by call from Python, on a library-owned stream (eager direct dispatch: the library submits each
@@ -454,11 +435,6 @@ def main():
         "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "us_per_launch": round(dom[1] * 1e3, 3),
-        # the same kernels when consecutive launches are INDEPENDENT (four rotating output arrays, replayed by smr_seq on four
-        # hardware queues): a kernel boundary of one chain overlaps the other chains' kernels.  Wall clock per launch, outputs verified.
-        "independent_launches": {"permutedims_us": ind2, "permutedims_frac": round(bytes2 / (ind2 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "broadcast4_us": ind3, "broadcast4_frac": round(bytes3 / (ind3 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "how": iinfo.split(" last_replay_us")[0]},
         "per_kernel": {
             "permutedims": {"us": round(ms2 * 1e3, 3), "us_median": round(med2 * 1e3, 3), "GB/s": round(bytes2 / (ms2 * 1e-3) / 1e9, 1),
                             "frac": round(bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan": plan2.describe()},
