@@ -197,7 +197,9 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
     if (!jit_no_launch() && !recorder()) {
         // a library-owned stream: the library submits the launch itself (smr_seq.cpp: eager direct dispatch), on the hardware queue its
         // data dependencies select -- independent executions run concurrently, host cost ~1 us instead of HIP's 3.6-4 us
-        if (options().eager_direct && stream_is_owned(s) && eager_available()) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (options().eager_direct && stream_is_owned(s) && eager_available() &&
+            (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing == hipStreamCaptureStatusNone)) {  // (a capture records HIP launches)
             std::vector<Span> rd, wr;
             footprint(plan, bases, rd, wr);
             std::vector<RecLaunch> rec;

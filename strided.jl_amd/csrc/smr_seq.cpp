@@ -419,8 +419,14 @@ struct Eager {
     std::map<std::string, std::pair<KernelRef, std::shared_ptr<void>>> jit;  // runtime-compiled kernels by entry-point name (module pinned)
     long n_launch = 0, n_free = 0, n_same = 0, n_cross = 0, n_fallback = 0;
 };
-Eager& eager() {
-    static Eager* e = new Eager();
+Eager& eager() {  // per device, like the direct queues it drives (one process per GPU is the usual case)
+    static std::mutex mu;
+    static std::map<int, Eager*> all;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    Eager*& e = all[dev];
+    if (!e) e = new Eager();
     return *e;
 }
 
