@@ -337,10 +337,11 @@ def main():
         seq.run(K, cur())
         seq.wait()
     tB.zero_(); tC.zero_()  # the timed region must (re)produce both outputs
+    stream_handle = cur()
     barrier()
     t0 = time.perf_counter()
     if use_seq:
-        seq.run(K, cur())
+        seq.run(K, stream_handle)
         seq.wait()
     elif use_graph:
         for _ in range(nrep):
@@ -542,6 +543,21 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
         g.replay()
         torch.cuda.synchronize()
         rec(name, p, min(event_time_ms(torch, g.replay, 2) for _ in range(3)) / (4 * npair))
+        # the same 40 INDEPENDENT launches as a recorded sequence on two hardware queues (the boundary of one launch overlaps the next
+        # pair's kernel; two queues measured best, profiles/r04_seq_vs_eager.txt): wall clock around smr_seq_run + smr_seq_wait
+        q = S.Sequence()
+        for i in range(npair):
+            q.add(p, bases=[poolB.data_ptr() + i * esz] + [poolA.data_ptr() + i * esz] * len(srcs))
+        q.set("queues", 2)
+        q.run(2, cur()); q.wait()
+        best = 1e30
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            q.run(8, cur()); q.wait()
+            best = min(best, time.perf_counter() - t0)
+        rec(name + "_seq_2_queues", p, best / (8 * npair) * 1e3)
+        del q
     del poolA, poolB
     # C5 compute-bound map 8192^2 f32
     m = 8192
