@@ -75,9 +75,15 @@ def _initop_code(initop):
 _TORCH_CUR = None
 
 
+_STREAM_OVERRIDE = []  # innermost `with S.Stream() as st:` first: the front ends then launch on the library-owned stream
+
+
 def _current_stream() -> int:
-    """Raw handle of torch's current HIP stream (0 = the null stream when torch / a device is absent)."""
+    """Raw handle of the stream the front ends launch on: the library-owned stream of an enclosing `with S.Stream():` block, else
+    torch's current HIP stream (0 = the null stream when torch / a device is absent)."""
     global _TORCH_CUR
+    if _STREAM_OVERRIDE:
+        return _STREAM_OVERRIDE[-1]
     if _TORCH_CUR is None:
         try:
             import torch

@@ -160,3 +160,28 @@ def test_through_hip_when_switched_off(stream):
     finally:
         S.set_option("eager_direct", 1)
     assert np.array_equal(host(B), a.T + 1)
+
+
+def test_front_ends_inside_a_stream_block_use_direct_dispatch():
+    """`with S.Stream():` -- broadcast, map!, permutedims!, reductions through the Python mirror, submitted by the library itself."""
+    import torch
+    rng = np.random.default_rng(21)
+    a = rng.standard_normal((30, 20, 25))
+    b = rng.standard_normal((30, 20, 25))
+    A, B = dev(a), dev(b)
+    out = dev(np.zeros((25, 20, 30)))
+    torch.cuda.synchronize()
+    before = stats()
+    st = S.Stream()
+    with st:
+        S.permutedims_(out, A, (2, 1, 0))
+        C1 = S.map(lambda x, y: x * y - 2 * x, A, B)                       # allocates (torch), launches on the stream
+        S.map_(lambda x: x + 1, out, out)                                  # depends on the permutedims! above
+        r = S.sum(C1, dims=(0, 2))
+    torch.cuda.synchronize()
+    after = stats()
+    st.close()
+    assert after["launches"] - before["launches"] >= 4, (before, after)
+    assert np.array_equal(host(out), np.transpose(a, (2, 1, 0)) + 1)
+    assert np.array_equal(C1.toarray(), a * b - 2 * a)
+    assert np.allclose(r.toarray(), (a * b - 2 * a).sum(axis=(0, 2), keepdims=True), rtol=1e-12)
