@@ -246,8 +246,8 @@ int smr_stream_destroy(void* stream);
  * boundary with the other chain's kernel.  A replay costs ~0.1 us of host time per launch instead of
  * HIP's 3.6-4 us.  Work queued on `stream` before the call completes first (the call waits for it on
  * the host when the stream is busy); work queued on `stream` afterwards waits for the replay
- * (hipStreamWaitValue64 on the completion signals where the device supports it, else smr_seq_run itself
- * returns only when the replay has completed); smr_seq_wait blocks the host until the last replay has
+ * (smr_seq_run itself returns only when the replay has completed; with $SMR_SEQ_STREAM_WAIT=1 and a device that
+ * supports it, hipStreamWaitValue64 on the completion signals instead); smr_seq_wait blocks the host until the last replay has
  * completed (active wait on the signals: microseconds sooner than hipStreamSynchronize).  Runtime-
  * compiled kernels take part like precompiled ones (their entry points carry a per-program name; the
  * sequence co-owns the loaded program).  A sequence holding a kernel that needs scratch memory is

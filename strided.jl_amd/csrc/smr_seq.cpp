@@ -292,7 +292,10 @@ Direct& direct() {
         return *d;
     }
     int can = 0;
-    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can && d->done_ptr[0]) d->wait_value_ok = true;
+    // stream-side waits (hipStreamWaitValue64 on the completion signals) are opt-in ($SMR_SEQ_STREAM_WAIT=1): the MI355X boxes this was
+    // developed on report hipDeviceAttributeCanUseStreamWaitValue = 0, so only the host-side wait has run on hardware
+    const char* sw = std::getenv("SMR_SEQ_STREAM_WAIT");
+    if (sw && sw[0] == '1' && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can && d->done_ptr[0]) d->wait_value_ok = true;
     d->ok = true;
     return *d;
 }
