@@ -1325,19 +1325,22 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
     // (3,2,0,1) 9.0 -> 6.5 us, (999,1001) 7.2 -> 6.4 us; but (100,90,80) (6 MB) 5.5 -> 6.4 us and well-filled tiles ((200,300,70),
     // (1400,1500), (4000,4100), every power of two) stay ahead in TILED -- so: the padded tiles would be under flat2_long % full and
     // the array has at least 8 MiB, or the OTHER side's lead is short and awkward anyway.
-    bool awkward = false, cutlead[2] = {false, false};
+    bool awkward = false, cutlead[2] = {false, false}, novec = false;
     long double fill = 1;
+    const i64 vlen = std::max<i64>(1, 16 / es);
     for (int s = 0; s < 2; ++s) {
         const i64 e = c.dims[lead[s]];
         if (e * es >= o.flat2_lead_bytes) {
             if (!o.flat2_long || c.M != 2) return false;
             cutlead[s] = true;
             fill *= (long double)e / (long double)((e + 31) / 32 * 32);
+            if (e % vlen) novec = true;  // TILED then moves 4- / 8-byte elements one by one as well, in padded tiles: (999,1001) 7.2 -> 6.4 us
             continue;
         }
         if ((e & (e - 1)) != 0 || e * es < 32) awkward = true;
     }
-    if ((cutlead[0] || cutlead[1]) && fill * 100 < (long double)o.flat2_long && c.total * es >= ((i64)8 << 20)) awkward = true;
+    if ((cutlead[0] || cutlead[1]) && ((fill * 100 < (long double)o.flat2_long && c.total * es >= ((i64)8 << 20)) || (novec && c.total * es >= ((i64)3 << 20))))
+        awkward = true;
     if (!awkward) return false;
     bool used[MAXN];
     for (int d = 0; d < MAXN; ++d) used[d] = f.ingroup[0][d] = f.ingroup[1][d] = false;

@@ -10,7 +10,8 @@ from reduce_tree_ab import mk, time_plan  # noqa: E402
 
 for dt in (torch.float64, torch.float32):
     for shape in ((100, 90, 80), (257, 129, 65), (17, 33, 65, 31), (48, 36, 24, 30), (1000, 3, 700), (200, 300, 70), (130, 70, 50, 9), (1400, 1500), (999, 1001), (4000, 4100),
-                  (1024, 1024), (4096, 4096), (96, 64, 80), (128, 128, 64), (32, 32, 32, 32), (64, 64, 64, 64), (8192, 8192), (96, 96, 96, 96)):
+                  (1024, 1024), (4096, 4096), (96, 64, 80), (128, 128, 64), (32, 32, 32, 32), (64, 64, 64, 64), (8192, 8192), (96, 96, 96, 96),
+                  (2049, 2051), (1001, 1100), (513, 700, 9), (4001, 4003), (301, 303, 35)):
         A = mk(shape, dt)
         n = len(shape)
         for q in itertools.permutations(range(n)):
