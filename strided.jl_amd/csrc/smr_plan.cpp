@@ -1331,7 +1331,7 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
     for (int s = 0; s < 2; ++s) {
         const i64 e = c.dims[lead[s]];
         if (e * es >= o.flat2_lead_bytes) {
-            if (!o.flat2_long || c.M != 2) return false;
+            if (!o.flat2_long) return false;
             cutlead[s] = true;
             fill *= (long double)e / (long double)((e + 31) / 32 * 32);
             if (e % vlen) novec = true;  // TILED then moves 4- / 8-byte elements one by one as well, in padded tiles: (999,1001) 7.2 -> 6.4 us

@@ -164,3 +164,21 @@ def test_ragged_transposes_with_long_unit_dims(shape, dt):
             assert np.array_equal(out.toarray(), np.transpose(a, q)), (shape, q, v, plan.describe())
     if shape == (257, 129, 65) and dt == np.float64:
         assert hit >= 2, hit
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_nary_maps_with_long_odd_unit_dims(dt):
+    """`C .= C ./ 2 .+ 2 .* permutedims(A, p)` (TensorOperations' tensoradd!) on shapes whose unit-stride dims are long and odd: the
+    two-sided FLAT form with cut leads reads the same-layout inputs at the destination's offsets."""
+    import torch
+    rng = np.random.default_rng(31)
+    for shape, q in (((257, 129, 65), (1, 0, 2)), ((301, 303, 35), (2, 0, 1)), ((2049, 2051), (1, 0))):
+        a = rng.integers(-50, 50, size=shape).astype(dt)
+        c0 = rng.integers(-50, 50, size=tuple(shape[i] for i in q)).astype(dt)
+        d0 = rng.integers(-50, 50, size=tuple(shape[i] for i in q)).astype(dt)
+        A, C, D = dview(a), dview(c0), dview(d0)
+        plan = S.make_plan(lambda c, x, d: c / 2 + 2 * x - d, None, None, C.size, (C, C, A.permutedims(q), D))
+        assert "two-sided" in plan.describe(), plan.describe()
+        plan.execute()
+        torch.cuda.synchronize()
+        assert np.array_equal(C.toarray(), c0 / dt(2) + dt(2) * np.transpose(a, q) - d0), (shape, q)
