@@ -1270,6 +1270,11 @@ static bool plan_flatb(const Canon& c, FlatBPlan& f) {
             if (ord[i] != i) moved = true;
         }
         if (!dense || !moved) continue;
+        // blocks whose extents are all powers of two are TILED's home ground ((2,128,2,128,8) permutations: 2.6 us there, 4.0-5.5 here)
+        bool pow2 = true;
+        for (int i = 0; i < g; ++i)
+            if (c.dims[i] & (c.dims[i] - 1)) pow2 = false;
+        if (pow2) continue;
         // the destination's blocks follow one another along dim g; the input's blocks may sit anywhere (a batch grid that is permuted
         // as well: (9,11,300,300) -> (11,9,300',300)): its side then moves in whole blocks, which must not be tiny
         if (c.strides[0][g] != P) continue;
@@ -1325,7 +1330,7 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
     // (3,2,0,1) 9.0 -> 6.5 us, (999,1001) 7.2 -> 6.4 us; but (100,90,80) (6 MB) 5.5 -> 6.4 us and well-filled tiles ((200,300,70),
     // (1400,1500), (4000,4100), every power of two) stay ahead in TILED -- so: the padded tiles would be under flat2_long % full and
     // the array has at least 8 MiB, or the OTHER side's lead is short and awkward anyway.
-    bool awkward = false, cutlead[2] = {false, false}, novec = false;
+    bool awkward = false, cutlead[2] = {false, false}, novec = false, odd_short = false;
     long double fill = 1;
     const i64 vlen = std::max<i64>(1, 16 / es);
     for (int s = 0; s < 2; ++s) {
@@ -1337,10 +1342,14 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
             if (e % vlen) novec = true;  // TILED then moves 4- / 8-byte elements one by one as well, in padded tiles: (999,1001) 7.2 -> 6.4 us
             continue;
         }
-        if ((e & (e - 1)) != 0 || e * es < 32) awkward = true;
+        if ((e & (e - 1)) != 0) awkward = odd_short = true;
+        else if (e * es < 32) awkward = true;
     }
-    if ((cutlead[0] || cutlead[1]) && ((fill * 100 < (long double)o.flat2_long && c.total * es >= ((i64)8 << 20)) || (novec && c.total * es >= ((i64)3 << 20))))
-        awkward = true;
+    if (cutlead[0] || cutlead[1]) {
+        // next to a cut lead only a short lead that is NOT a power of two counts ((2,2,256,2,2,256) and (64,2,64,2,16) permutations with a
+        // 16-byte lead beside a 2-KiB one: TILED 3.2-3.9 us, this form 6.9-7.1)
+        awkward = odd_short || (fill * 100 < (long double)o.flat2_long && c.total * es >= ((i64)8 << 20)) || (novec && c.total * es >= ((i64)3 << 20));
+    }
     if (!awkward) return false;
     bool used[MAXN];
     for (int d = 0; d < MAXN; ++d) used[d] = f.ingroup[0][d] = f.ingroup[1][d] = false;

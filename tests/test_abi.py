@@ -685,7 +685,8 @@ def test_batched_flat_plans_move_every_element_exactly_once():
             if fb is None:
                 # outside the form: the identity, a block over 4 KiB / 512 elements, or input blocks under 256 bytes that are not adjacent
                 permuted_grid = tuple(q[2:]) != tuple(range(2, len(q)))
-                assert (q == tuple(range(len(q)))) or shape[0] * shape[1] * es > 4096 or shape[0] * shape[1] > 512 or \
+                pow2 = all(n & (n - 1) == 0 for n in shape[:2])           # power-of-two blocks stay with TILED
+                assert (q == tuple(range(len(q)))) or pow2 or shape[0] * shape[1] * es > 4096 or shape[0] * shape[1] > 512 or \
                     (permuted_grid and shape[0] * shape[1] * es < 256), (shape, q, dt)
                 continue
             seen += 1
@@ -714,4 +715,4 @@ def test_batched_flat_plans_move_every_element_exactly_once():
             o1, o2 = np.argsort(got_d, kind="stable"), np.argsort(want_d, kind="stable")
             assert np.array_equal(got_d[o1], want_d[o2]), msg
             assert np.array_equal(got_s[o1], want_s[o2]), msg
-    assert seen >= 20, seen
+    assert seen >= 18, seen

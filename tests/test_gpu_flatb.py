@@ -39,7 +39,7 @@ def test_batched_blocks(shape, perm, dt):
     A = dview(a)
     out = dview(np.zeros(tuple(shape[i] for i in perm), dtype=dt))
     plan = S.make_plan(lambda x: x, None, None, out.size, (out, A.permutedims(perm)))
-    if shape[:3] in ((9, 11, 3000), (5, 9, 4001), (16, 16, 999)) or (shape[:2] == (9, 11) and len(shape) == 4 and np.dtype(dt).itemsize >= 8):
+    if shape[:3] in ((9, 11, 3000), (5, 9, 4001)) or (shape[:2] == (9, 11) and len(shape) == 4 and np.dtype(dt).itemsize >= 8):
         assert "batched" in plan.describe(), plan.describe()
     plan.execute()
     torch.cuda.synchronize()
