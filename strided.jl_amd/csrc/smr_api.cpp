@@ -583,6 +583,16 @@ int smr_stream_destroy(void* stream) {
         W.map.erase(it);
     }
     eager_fence_if_active();
+    {   // cached one-shot plans remember the stream they were created on and drain it when they are dropped: none may outlive this one
+        // (round 4: a later smr_set_option -- which clears the cache -- synchronised a destroyed stream and crashed)
+        Cache& c = cache();
+        std::vector<PlanRef> dropped;
+        {
+            std::lock_guard<std::mutex> g(c.mu);
+            cache_clear_locked(c, dropped);
+        }
+        dropped.clear();
+    }
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamDestroy((hipStream_t)stream);
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipStreamDestroy");
