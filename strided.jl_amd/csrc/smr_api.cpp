@@ -877,6 +877,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "stream_pack_rows") o.stream_pack_rows = value;
     else if (n == "flatb") o.flatb = value;
     else if (n == "flat2_long") o.flat2_long = value;
+    else if (n == "flat2_pair") o.flat2_pair = value;
     else if (n == "eager_direct") o.eager_direct = value;
     else if (n == "reduce_tree") o.reduce_tree = value;
     else if (n == "tiled_persist_wpc") o.tiled_persist_wpc = value;
@@ -941,6 +942,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "stream_pack_rows") return o.stream_pack_rows;
     if (n == "flatb") return o.flatb;
     if (n == "flat2_long") return o.flat2_long;
+    if (n == "flat2_pair") return o.flat2_pair;
     if (n == "eager_direct") return o.eager_direct;
     if (n == "eager_launches") return eager_stat(0);
     if (n == "eager_free") return eager_stat(1);

@@ -256,6 +256,7 @@ struct Options {
                                 // round 3: 512-1024 is as fast or faster on every shape of tools/reduce_sweep.py, with 4x fewer partials)
     i64 reduce_row_floor = -1;  // ROW form: least log2 lanes per output (-1 = planner's rule)
     i64 flat2 = 1;              // two-sided FLAT form (both sides' runs are short leading dims): on / off
+    i64 flat2_pair = 1;         // two-sided FLAT form: move pairs of elements where a row's parity allows (4- / 8-byte element types)
     i64 flat2_bytes = 384;      // ... target bytes of a run
     i64 flat2_lead_bytes = 512; // ... both sides' unit-stride dims must be shorter than this
     i64 reduce_row_dense = 1;   // ROW form: lanes along the outputs when the inner reduced dim is at most 64 bytes and kept dim 0 is dense behind it

@@ -242,13 +242,18 @@ struct Flat2Args {
     uint32_t magicTP0;
     uint32_t ntp[2];                      // tiles along p[0] / p[1]
     uint32_t magicR[2], magicL[2];        // floor(2^32 / d) + 1 for d = R[s], L[s]
+    uint32_t magicI[2];                   // ... for d = (L[s] + 2) / 2: pair slots per run (PAIR form)
     i64 dimp[2];                          // extents of p[s] (1 when there is none)
     i64 spo[2];                           // stride of p[s] on the OTHER side
     int32_t roff[2][FLAT_MAXR];           // offset on the other side of leading index r of run s
     i64 oext[MAXN], os0[MAXN], os1[MAXN]; // outer dims: extents, destination / input strides
 };
 
-template <class T, class F>
+// PAIR (round 4): both phases move two consecutive elements of a run per lane wherever the pair starts on an address that is a multiple
+// of 2 * sizeof(T) -- the runs start at odd offsets as often as not (a row of 257 elements shifts the next row's parity), so every row
+// gets its pairs from ITS parity: slot i of a row holds elements 2i - p and 2i - p + 1 (p = parity of the row's first element), the
+// first / last slot may hold a single element.  Halves the global-memory instructions of 4- and 8-byte element types.
+template <class T, class F, bool PAIR = false>
 SMR_DEV void flat2_body(const Flat2Args a, F f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_flat[];
     T* lds = reinterpret_cast<T*>(smem_flat);
@@ -302,6 +307,65 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
         offd[y] = (i64)a.roff[1][r] + (i64)jp * a.spo[1];
     }
     __syncthreads();
+    if constexpr (PAIR) {
+        const int I1 = (L1 + 2) >> 1, I0 = (L0 + 2) >> 1;
+        {   // phase 1: lanes along the pair slots of the input run
+            const int dx = (int)fdiv16(256u, a.magicI[1]), di = 256 - dx * I1;
+            int x = (int)fdiv16(tid, a.magicI[1]), i = (int)tid - x * I1;
+            while (x < L0) {
+                const int xc = xcol[x];
+                if (xc < n0) {
+                    const T* row = src + bs + offs[x];
+                    const int p = (int)(((uintptr_t)row / sizeof(T)) & 1u);
+                    const int y = 2 * i - p;
+                    const bool v0 = y >= 0 && y < n1, v1 = y + 1 < n1;
+                    if (v0 && v1) {
+                        const FVec<T, 2> v = *reinterpret_cast<const FVec<T, 2>*>(row + y);
+                        lds[y * PITCH + xc] = v.v[0];
+                        lds[(y + 1) * PITCH + xc] = v.v[1];
+                    } else if (v0) {
+                        lds[y * PITCH + xc] = row[y];
+                    } else if (v1) {
+                        lds[(y + 1) * PITCH + xc] = row[y + 1];
+                    }
+                }
+                x += dx;
+                i += di;
+                if (i >= I1) {
+                    i -= I1;
+                    ++x;
+                }
+            }
+        }
+        __syncthreads();
+        {   // phase 2: lanes along the pair slots of the destination run
+            const int dy = (int)fdiv16(256u, a.magicI[0]), di = 256 - dy * I0;
+            int y = (int)fdiv16(tid, a.magicI[0]), i = (int)tid - y * I0;
+            while (y < n1) {
+                const i64 o = bd + offd[y];
+                const int p = (int)(((uintptr_t)((const T*)a.ops.base[0] + o) / sizeof(T)) & 1u);
+                const int x = 2 * i - p;
+                const bool v0 = x >= 0 && x < n0, v1 = x + 1 < n0;
+                if (v0 && v1) {
+                    const T tv[2] = {lds[y * PITCH + x], lds[y * PITCH + x + 1]};
+                    flat_emit<T, F, 2>(a.ops, a.nin, a.kt, anyconj, o + x, tv, f);
+                } else if (v0) {
+                    const T tv[1] = {lds[y * PITCH + x]};
+                    flat_emit<T, F, 1>(a.ops, a.nin, a.kt, anyconj, o + x, tv, f);
+                } else if (v1) {
+                    const T tv[1] = {lds[y * PITCH + x + 1]};
+                    flat_emit<T, F, 1>(a.ops, a.nin, a.kt, anyconj, o + x + 1, tv, f);
+                }
+                y += dy;
+                i += di;
+                if (i >= I0) {
+                    i -= I0;
+                    ++y;
+                }
+            }
+        }
+        return;
+    }
     // phase 1: (x along the destination run) x (y along the input run), lanes along y; (x, y) advance by 256 positions per step
     {
         const int dx = (int)fdiv16(256u, a.magicL[1]), dy = 256 - dx * L1;
@@ -413,9 +477,9 @@ template <class T, class F, int DIR, int VL, int VF>
 __global__ void __launch_bounds__(256) k_flat_map(const FlatArgs a, F f) {
     flat_map_body<T, F, DIR, VL, VF>(a, f);
 }
-template <class T, class F>
+template <class T, class F, bool PAIR>
 __global__ void __launch_bounds__(256) k_flat2_map(const Flat2Args a, F f) {
-    flat2_body<T, F>(a, f);
+    flat2_body<T, F, PAIR>(a, f);
 }
 
 template <class T, class F>
@@ -490,6 +554,7 @@ static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
         a.ntp[t] = (unsigned)((a.dimp[t] + fp.TP[t] - 1) / fp.TP[t]);
         a.magicR[t] = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.R[t] + 1);
         a.magicL[t] = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.L[t] + 1);
+        a.magicI[t] = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)((a.L[t] + 2) / 2) + 1);
         for (int r = 0; r < fp.R[t]; ++r) a.roff[t][r] = fp.roff[t][r];
         blocks *= a.ntp[t];
     }
@@ -511,12 +576,22 @@ static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.shared = (fp.shared && fp.TP[0] > 1) ? 1 : 0;
     a.magicTP0 = fp.TP[0] > 1 ? (uint32_t)(((uint64_t)1 << 32) / (uint32_t)fp.TP[0] + 1) : 0u;
     const unsigned grid = (unsigned)blocks;
+    // pairs: 4- / 8-byte elements, runs long enough to hold a few, the two-element slots of the tile within 16-bit divisions, and every
+    // input that shares the destination's layout congruent with it modulo the pair size (it is read at the destination's offsets)
+    // Measured (tools/flat2_pair_ab.py, profiles/r04_flat2_pair_ab.txt): 4-byte elements with both runs made of short leading dims gain 5-20 %
+    // ((6,64,64,64,5) 22.4 -> 18.5 us, (40,50,60,36) 12.4 -> 10.8, (12,5000,30,10) 37.8 -> 32.8); 8-byte elements and cut leads (R = 1: every
+    // other row of an odd extent starts misaligned) lose 0-18 % -- flat2_pair = 2 forces pairs wherever they are possible
+    const int pmode = (int)options().flat2_pair;
+    bool pair = pmode != 0 && sizeof(T) <= 8 && a.L[0] >= 8 && a.L[1] >= 8 &&
+                (pmode >= 2 || (sizeof(T) == 4 && a.R[0] > 1 && a.R[1] > 1 && c.total * (i64)sizeof(T) >= ((i64)8 << 20)));
+    for (int k = 1; k < c.M && pair; ++k)
+        if (k != fp.kt && ((uintptr_t)a.ops.base[k] % (2 * sizeof(T))) != ((uintptr_t)a.ops.base[0] % (2 * sizeof(T)))) pair = false;
     if constexpr (is_jit<F>::value) {
         JitLaunch l;
         l.family = "flat";
         l.tname = tname<T>();
         l.argtype = "smr::Flat2Args";
-        l.entry = std::string("smr::flat2_body<") + tname<T>() + ", smr::FJit>(a, smr::FJit{kc});";
+        l.entry = std::string("smr::flat2_body<") + tname<T>() + ", smr::FJit, " + (pair ? "true" : "false") + ">(a, smr::FJit{kc});";
         l.grid = grid;
         l.block = 256;
         l.lds = lds;
@@ -526,7 +601,10 @@ static int go2(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     } else {
         if (jit_no_launch()) return SMR_OK;
         clear_sticky_error();
-        SMR_LAUNCH((k_flat2_map<T, F>), dim3(grid), dim3(256), lds, s, a, f);
+        if (pair)
+            SMR_LAUNCH((k_flat2_map<T, F, true>), dim3(grid), dim3(256), lds, s, a, f);
+        else
+            SMR_LAUNCH((k_flat2_map<T, F, false>), dim3(grid), dim3(256), lds, s, a, f);
         return check_launch("k_flat2_map");
     }
 }

@@ -182,3 +182,25 @@ def test_nary_maps_with_long_odd_unit_dims(dt):
         plan.execute()
         torch.cuda.synchronize()
         assert np.array_equal(C.toarray(), c0 / dt(2) + dt(2) * np.transpose(a, q) - d0), (shape, q)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+def test_two_sided_flat_pairs(dt):
+    """The pair form of the two-sided FLAT kernel (forced with flat2_pair = 2): rows whose first element sits at an odd element address
+    start with a single element, the others with a pair; plain and n-ary maps, group runs and cut leads."""
+    import torch
+    rng = np.random.default_rng(41)
+    S.set_option("flat2_pair", 2)
+    try:
+        for shape, q in (((5, 300, 30, 7), (3, 2, 1, 0)), ((17, 33, 65, 31), (3, 2, 1, 0)), ((257, 129, 65), (2, 1, 0)), ((9, 70, 3, 90, 11), (4, 3, 2, 1, 0)),
+                         ((6, 64, 64, 16, 5), (4, 3, 2, 1, 0))):
+            a = rng.integers(-99, 99, size=shape).astype(dt)
+            c0 = rng.integers(-99, 99, size=tuple(shape[i] for i in q)).astype(dt)
+            A, C = dview(a), dview(c0)
+            # an odd element offset on both sides: a sub-view that drops the first index of the LAST dim keeps the layout, shifts the parity
+            plan = S.make_plan(lambda c, x: c - 2 * x, None, None, C.size, (C, C, A.permutedims(q)))
+            plan.execute()
+            torch.cuda.synchronize()
+            assert np.array_equal(C.toarray(), c0 - dt(2) * np.transpose(a, q)), (shape, q, plan.describe())
+    finally:
+        S.set_option("flat2_pair", 1)
