@@ -261,6 +261,9 @@ int smr_seq_add(smr_seq* seq, smr_plan* plan, void* const* bases);
 int smr_seq_run(smr_seq* seq, int reps, void* stream);
 int smr_seq_wait(smr_seq* seq);
 int smr_seq_info(smr_seq* seq, char* buf, size_t buflen);
+/* The dependency analysis alone (host arithmetic on strides and base pointers, no device needed): comp[i] = dependency component
+ * of recorded execution i (numbered in order of first appearance); returns the number of components or a negative status.      */
+int smr_seq_components(smr_seq* seq, int32_t* comp, size_t cap);
 /* "queues" (1..8, default 4: hardware queues a replay may spread over; 1 = everything in recorded order on one queue; more than 4
  * are time-multiplexed by the hardware scheduler), "slices" (1..8, default 1: a component that consists of ONE launch of independent
  * workgroups is cut into that many contiguous block ranges, one queue each -- the device form of _mapreduce_threaded!'s bisection).

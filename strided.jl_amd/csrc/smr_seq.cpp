@@ -870,6 +870,32 @@ struct smr_seq {
 };
 
 namespace {
+// dependency components of a list of executions given their byte ranges (union-find over "one writes what the other reads or writes");
+// comp[i] = component of execution i, numbered in order of first appearance; returns their number
+int components_of(const std::vector<Spans>& rd, const std::vector<Spans>& wr, std::vector<int>& comp) {
+    const size_t ni = rd.size();
+    std::vector<int> parent(ni);
+    for (size_t i = 0; i < ni; ++i) parent[i] = (int)i;
+    auto find = [&](int x) {
+        while (parent[x] != x) x = parent[x] = parent[parent[x]];
+        return x;
+    };
+    for (size_t i = 0; i < ni; ++i)
+        for (size_t j = i + 1; j < ni; ++j)
+            if (overlaps(wr[i], wr[j]) || overlaps(wr[i], rd[j]) || overlaps(rd[i], wr[j])) parent[find((int)j)] = find((int)i);
+    std::vector<int> roots;
+    comp.assign(ni, 0);
+    for (size_t i = 0; i < ni; ++i) {
+        const int r = find((int)i);
+        size_t c = 0;
+        for (; c < roots.size(); ++c)
+            if (roots[c] == r) break;
+        if (c == roots.size()) roots.push_back(r);
+        comp[i] = (int)c;
+    }
+    return (int)roots.size();
+}
+
 int seq_build(smr_seq* q) {
     for (auto& v : q->packets) v.clear();
     q->keep.clear();
@@ -934,33 +960,27 @@ int seq_build(smr_seq* q) {
     //    nothing that is written: they go to different queues (longest-processing-time first over the bytes they touch) and run
     //    concurrently -- the spawn / wait of src/mapreduce.jl:203-223 at the granularity of whole launches.
     const size_t ni = recs.size();
-    std::vector<int> parent(ni);
-    for (size_t i = 0; i < ni; ++i) parent[i] = (int)i;
-    auto find = [&](int x) {
-        while (parent[x] != x) x = parent[x] = parent[parent[x]];
-        return x;
-    };
-    for (size_t i = 0; i < ni; ++i)
-        for (size_t j = i + 1; j < ni; ++j)
-            if (overlaps(recs[i].wr, recs[j].wr) || overlaps(recs[i].wr, recs[j].rd) || overlaps(recs[i].rd, recs[j].wr)) parent[find((int)j)] = find((int)i);
-    std::vector<int> roots, csize, cfirst;
+    std::vector<int> csize, cfirst;
     std::vector<size_t> cbytes;
-    for (size_t i = 0; i < ni; ++i) {
-        const int r = find((int)i);
-        size_t c = 0;
-        for (; c < roots.size(); ++c)
-            if (roots[c] == r) break;
-        if (c == roots.size()) {
-            roots.push_back(r);
-            cbytes.push_back(0);
-            csize.push_back(0);
-            cfirst.push_back((int)i);
+    {
+        std::vector<Spans> rds(ni), wrs(ni);
+        for (size_t i = 0; i < ni; ++i) {
+            rds[i] = recs[i].rd;
+            wrs[i] = recs[i].wr;
         }
-        recs[i].comp = (int)c;
-        cbytes[c] += recs[i].bytes;
-        ++csize[c];
+        std::vector<int> comp;
+        const int nc = components_of(rds, wrs, comp);
+        csize.assign(nc, 0);
+        cfirst.assign(nc, -1);
+        cbytes.assign(nc, 0);
+        for (size_t i = 0; i < ni; ++i) {
+            recs[i].comp = comp[i];
+            cbytes[comp[i]] += recs[i].bytes;
+            ++csize[comp[i]];
+            if (cfirst[comp[i]] < 0) cfirst[comp[i]] = (int)i;
+        }
     }
-    const int ncomp = (int)roots.size();
+    const int ncomp = (int)csize.size();
     q->ncomp = ncomp;
     const int maxq = std::max(1, std::min(q->max_queues, SEQ_MAXQ));
     // 3b. slices.  A component that consists of ONE execution with ONE launch whose workgroups are independent (the launcher says so:
@@ -1272,6 +1292,19 @@ int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
     else
         std::snprintf(buf, buflen, "backend=hip items=%zu (%s)", q->items.size(), q->why_not_aql.c_str());
     return SMR_OK;
+}
+
+// Host-only view of the dependency analysis (no device needed: footprints are arithmetic on the plans' strides and base pointers):
+// comp[i] = dependency component of recorded execution i.  Returns the number of components, or a negative status.
+int smr_seq_components(smr_seq* q, int32_t* comp, size_t cap) {
+    if (!q) return set_error(SMR_EINVAL, "null sequence");
+    std::vector<Spans> rd(q->items.size()), wr(q->items.size());
+    for (size_t i = 0; i < q->items.size(); ++i) seq_footprint(q->items[i].plan, q->items[i].has_bases ? q->items[i].bases : nullptr, rd[i], wr[i]);
+    std::vector<int> c;
+    const int n = components_of(rd, wr, c);
+    if (comp)
+        for (size_t i = 0; i < c.size() && i < cap; ++i) comp[i] = c[i];
+    return n;
 }
 
 int smr_seq_set(smr_seq* q, const char* name, int64_t value) {
