@@ -1348,7 +1348,9 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
     if (cutlead[0] || cutlead[1]) {
         // next to a cut lead only a short lead that is NOT a power of two counts ((2,2,256,2,2,256) and (64,2,64,2,16) permutations with a
         // 16-byte lead beside a 2-KiB one: TILED 3.2-3.9 us, this form 6.9-7.1)
-        awkward = odd_short || (fill * 100 < (long double)o.flat2_long && c.total * es >= ((i64)8 << 20)) || (novec && c.total * es >= ((i64)3 << 20));
+        const bool anysize = o.flat2_long >= 100;  // tests / experiments: wherever the form applies
+        awkward = odd_short || (fill * 100 < (long double)o.flat2_long && (anysize || c.total * es >= ((i64)8 << 20))) ||
+                  (novec && (anysize || c.total * es >= ((i64)3 << 20)));
     }
     if (!awkward) return false;
     bool used[MAXN];
