@@ -716,3 +716,34 @@ def test_batched_flat_plans_move_every_element_exactly_once():
             assert np.array_equal(got_d[o1], want_d[o2]), msg
             assert np.array_equal(got_s[o1], want_s[o2]), msg
     assert seen >= 18, seen
+
+
+def test_round4_planner_rules_for_ragged_and_batched_shapes():
+    """Which family / form the planner picks for the shapes round 4 measured (profiles/r04_flat2_long_ab.txt, r04_flat2_batched.txt,
+    r04_perf_sanity.txt) -- so that a change of these rules is a deliberate one."""
+    def desc(shape, q, dt=np.float64, f=lambda x: x):
+        a = S.StridedView(np.zeros(shape, dtype=dt, order="F"))
+        b = S.StridedView(np.zeros(tuple(shape[i] for i in q), dtype=dt, order="F"))
+        return S.make_plan(f, None, None, b.size, (b, a.permutedims(q))).describe()
+
+    # long unit-stride dims: evenly cut leads when 32 x 32 tiles would be poorly filled (and the array has >= 8 MiB) ...
+    assert "two-sided" in desc((257, 129, 65), (2, 1, 0)) and "dest_run=1x" in desc((257, 129, 65), (2, 1, 0))
+    # ... or when an extent is not a multiple of the 16-byte vector length (TILED would move single elements as well) ...
+    assert "two-sided" in desc((2049, 2051), (1, 0)) and "two-sided" in desc((2049, 2051), (1, 0), np.float32)
+    # ... or next to a short lead that is not a power of two
+    assert "two-sided" in desc((17, 33, 65, 31), (3, 2, 0, 1))
+    # well-filled, even and power-of-two shapes stay with TILED; so do small arrays
+    for shape, q in (((1400, 1500), (1, 0)), ((4000, 4100), (1, 0)), ((4096, 4096), (1, 0)), ((128, 128, 64), (1, 0, 2)), ((100, 90, 80), (1, 0, 2)),
+                     ((64, 2, 64, 2, 16), (3, 0, 1, 2, 4)), ((2, 2, 256, 2, 2, 256), (5, 4, 3, 2, 1, 0))):
+        assert "family=tiled" in desc(shape, q), (shape, q, desc(shape, q))
+    # contiguous small blocks with a non-power-of-two extent: the batched form, also with a permuted batch grid (blocks of >= 256 bytes)
+    assert "batched block=99" in desc((9, 11, 3000), (1, 0, 2)) and "batched block=99" in desc((9, 11, 70, 60), (1, 0, 3, 2))
+    assert "batched" in desc((100, 3, 100, 3, 10), (1, 0, 4, 3, 2))
+    assert "batched" not in desc((2, 128, 2, 128, 8), (2, 0, 1, 3, 4)) and "batched" not in desc((16, 16, 999), (1, 0, 2))   # power-of-two blocks: TILED
+    assert "batched" not in desc((5, 9, 300, 300), (1, 0, 3, 2), np.float32)                                                  # 180-byte blocks on a permuted grid
+    # a stepped range behind a permutation: its smallest stride (3) is the input's near-unit axis
+    A = S.StridedView(np.zeros((2048, 2048), order="F"))
+    B = S.StridedView(np.zeros((2048, 2048), order="F"))
+    d = S.make_plan(lambda x, y: x + y, None, None, (682, 682),
+                    (B.sview(slice(0, 682), slice(0, 682)), A.sview(slice(0, 2046, 3), slice(0, 682)), A.permutedims((1, 0)).sview(slice(0, 682), slice(0, 2046, 3)))).describe()
+    assert "family=tiled" in d, d
