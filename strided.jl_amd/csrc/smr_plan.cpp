@@ -1456,9 +1456,16 @@ int make_plan(const smr_problem* p, Plan& plan) {
     // FLAT: the one-sided form first -- unless its line side is under 8 elements long, where the two-sided form's bigger tiles win
     // (ComplexF64 (6,64,64,64,5) reversed 94 -> 40 us, (4,300,300,3) 16.5 -> 7.6; with 24-element lines the one-sided form's
     // vector accesses are 1.5x ahead; profiles/r03_flat2_ab.txt).  flat2 = 2: the two-sided form wherever it applies (experiments)
-    bool flat_ok = c.redop == SMR_RED_NONE && o.force_family == 0;
+    // force_family = FAM_FLAT (tests, experiments) tries the FLAT planners like the default does and leaves the rest of the decision alone
+    bool flat_ok = c.redop == SMR_RED_NONE && (o.force_family == 0 || o.force_family == FAM_FLAT);
+    // plan_orbit builds the orbit list: run it once per plan, whoever asks first
+    int orbit_state = -1;
+    auto orbit_ok = [&]() {
+        if (orbit_state < 0) orbit_state = plan_orbit(c, plan.orbit) ? 1 : 0;
+        return orbit_state == 1;
+    };
     // several inputs that are permuted views of ONE buffer: the orbit kernel reads the buffer once, the n-ary FLAT forms would read it per view
-    if (flat_ok && c.M > 2 && plan_orbit(c, plan.orbit)) flat_ok = false;
+    if (flat_ok && c.M > 2 && o.force_family == 0 && orbit_ok()) flat_ok = false;
     if (flat_ok && plan_flatb(c, plan.flatb)) {
         plan.family = FAM_FLAT;
         describe(plan);
@@ -1502,7 +1509,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
         if (fam == FAM_TILED) {
         } else if (stream) {
             fam = FAM_STREAM;
-        } else if (o.force_family != FAM_TILED && o.force_family != FAM_GENERIC && plan_orbit(c, plan.orbit)) {
+        } else if (o.force_family != FAM_TILED && o.force_family != FAM_GENERIC && orbit_ok()) {
             fam = FAM_ORBIT;
         } else if (plan_tiles(c, plan.tile)) {
             fam = FAM_TILED;
