@@ -304,6 +304,12 @@ static int execute_owned(smr_plan* h, void* const* bases, hipStream_t s) {
         hipStreamCaptureStatus c1 = hipStreamCaptureStatusNone, c2 = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &c1);
         (void)hipStreamIsCapturing(h->last_stream, &c2);
+        // launches the library submitted itself (a library-owned stream) are not HIP work: no event covers them, and the direct queues do
+        // not honour hipStreamWaitEvent.  With such a stream on either side the previous execution is waited for on the host.
+        if (c1 == hipStreamCaptureStatusNone && c2 == hipStreamCaptureStatusNone && (stream_is_owned(s) || stream_is_owned(h->last_stream))) {
+            eager_fence_if_active();
+            (void)hipStreamSynchronize(h->last_stream);
+        }
         if (c1 == hipStreamCaptureStatusNone && c2 == hipStreamCaptureStatusNone) {
             if (!h->order_ev) (void)hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming);
             if (h->order_ev && hipEventRecord(h->order_ev, h->last_stream) == hipSuccess) (void)hipStreamWaitEvent(s, h->order_ev, 0);

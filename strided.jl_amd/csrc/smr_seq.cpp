@@ -11,8 +11,10 @@
 //     graphs get the batched submission.
 // So the library submits its own packets: a sequence is recorded ONCE (every launch's kernel object, grid and kernarg block, resident
 // in device memory), the dependency analysis of the overlap window (smr_api.cpp: byte ranges read / written) decides per launch whether
-// its packet carries the barrier bit, and a replay is N x 64-byte stores into the queue ring plus one doorbell -- ~0.1 us of host time
-// per launch, no host thread in the loop, independent launches in flight together inside ONE hardware queue.
+// its packet carries the barrier bit, and a replay is N x 64-byte stores into the queue rings plus a doorbell per queue -- ~0.1 us of
+// host time per launch, no host thread in the loop.  Independent launches go to DIFFERENT hardware queues (one per dependency
+// component): inside one queue the packet processor runs consecutive dispatches one after the other on their agent-scope fences even
+// with the barrier bit clear (measured with device stamps, profiles/r04_overlap.txt); two queues do overlap.
 //
 // Kernel objects come from the code objects HIP itself has loaded: host stub -> kernel name (hipKernelNameRefByPtr) -> "<name>.kd" looked
 // up in the process's HSA executables (loader extension 1.03: hsa_ven_amd_loader_iterate_executables).  Nothing is loaded twice.
@@ -400,7 +402,7 @@ struct Inflight {
 };
 struct EagerQueue {
     std::vector<hsa_signal_t> sigs;
-    std::vector<signed char> dep_user;  // queue (1-based) whose barrier-AND packet names this signal, 0: none
+    std::vector<unsigned char> dep_user;  // bit k: a barrier-AND packet on queue k names this signal (several queues may name the same tail)
     std::vector<Inflight> inflight;  // oldest first
     unsigned next = 0;               // next signal / argument slot
     int tail = -1;                   // signal index of the last packet submitted when it carries one (-1: it does not, or nothing was submitted since the last fence)
@@ -587,9 +589,10 @@ int eager_take_signal(Eager& e, EagerQueue& q, int self) {
     const int si = (int)(q.next % EAGER_SIGS);
     ++q.next;
     if (h.signal_load(q.sigs[si]) != 0) h.signal_wait(q.sigs[si], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
-    if (q.dep_user[si]) {
-        if (q.dep_user[si] - 1 != self) eager_wait_queue(e, direct(), q.dep_user[si] - 1);
+    if (const unsigned users = q.dep_user[si]) {  // every queue whose barrier-AND packet names it must have consumed that packet
         q.dep_user[si] = 0;
+        for (int k = 0; k < EAGER_Q; ++k)
+            if (((users >> k) & 1u) && k != self) eager_wait_queue(e, direct(), k);
     }
     eager_retire(q);
     h.signal_store_relaxed(q.sigs[si], 1);
@@ -624,6 +627,12 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
     Eager& e = eager();
     if (eager_init(d, e) != SMR_OK) return SMR_EUNSUPPORTED;
     Hsa& h = hsa();
+    // a sequence replay still in flight on these queues (only with stream-side waits, $SMR_SEQ_STREAM_WAIT=1) comes first
+    for (int k = 0; k < SEQ_MAXQ; ++k)
+        if (d.armed[k]) {
+            if (h.signal_load(d.done[k]) != 0) h.signal_wait(d.done[k], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+            d.armed[k] = false;
+        }
     // kernels first: anything that cannot be dispatched directly sends the whole execution through HIP
     std::vector<KernelRef> refs(launches.size());
     for (size_t j = 0; j < launches.size(); ++j) {
@@ -639,7 +648,10 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
             } else {
                 rc = resolve_name(d, l.kname, refs[j]);
                 if (rc == SMR_OK) {
-                    if (e.jit.size() > 512) e.jit.clear();  // unpins the modules; they are looked up again on their next use
+                    if (e.jit.size() > 512) {  // unpins the modules (looked up again on their next use): nothing in flight may still run their code
+                        for (int k = 0; k < EAGER_Q; ++k) eager_wait_queue(e, d, k);
+                        e.jit.clear();
+                    }
                     e.jit[l.kname] = std::make_pair(refs[j], l.keep);
                 }
             }
@@ -691,7 +703,7 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
                 if (o.unsignaled > 0) (void)eager_marker(e, o, d.q[conf[i]], conf[i]);  // its last packet carries no signal: a marker behind it does
                 if (o.tail >= 0) {
                     bp.dep_signal[nd++] = o.sigs[o.tail];
-                    o.dep_user[o.tail] = (signed char)(target + 1);
+                    o.dep_user[o.tail] |= (unsigned char)(1u << target);
                 }
             }
         const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
@@ -927,8 +939,9 @@ int seq_build(smr_seq* q) {
         for (const auto& x : recs[i].wr) recs[i].bytes += x.second - x.first;
     }
     bool aql = d.ok;
-    // 2. resolve kernels
+    // 2. resolve kernels (the device's kernel map and queues are shared with the eager path: d.mu)
     std::vector<std::vector<KernelRef>> refs(recs.size());
+    std::unique_lock<std::mutex> dlock(d.mu);
     for (size_t i = 0; aql && i < recs.size(); ++i)
         for (const RecLaunch& l : recs[i].launches) {
             KernelRef k;
@@ -950,6 +963,7 @@ int seq_build(smr_seq* q) {
             }
             refs[i].push_back(k);
         }
+    dlock.unlock();
     q->aql = aql;
     q->built = true;
     if (!aql) return SMR_OK;
@@ -1025,8 +1039,10 @@ int seq_build(smr_seq* q) {
         }
     }
     const int nq = nextq;
+    dlock.lock();
     for (int k = 0; k < nq; ++k)
         if (int rc = direct_queue(d, k)) return rc;
+    dlock.unlock();
     q->nq = nq;
     // 4. kernarg blocks (explicit arguments + the code-object-v5 hidden block), one resident copy in device memory; a sliced launch
     //    has one block per slice (its block-offset field / list pointer patched)

@@ -185,3 +185,29 @@ def test_front_ends_inside_a_stream_block_use_direct_dispatch():
     assert np.array_equal(host(out), np.transpose(a, (2, 1, 0)) + 1)
     assert np.array_equal(C1.toarray(), a * b - 2 * a)
     assert np.allclose(r.toarray(), (a * b - 2 * a).sum(axis=(0, 2), keepdims=True), rtol=1e-12)
+
+
+def test_scratch_plan_alternating_between_a_library_stream_and_hip_streams(stream):
+    """A split partial reduction owns partials + arrival counters: its executions must never overlap.  On a library-owned stream the
+    launches are not HIP work (no event covers them), so alternating with ordinary HIP streams is ordered on the host (csrc/smr_api.cpp:
+    execute_owned)."""
+    import torch
+    from strided_jl_amd.broadcast import promoteshape
+    rng = np.random.default_rng(77)
+    a = rng.integers(-4, 5, size=(33, 200000)).astype(np.float64)
+    A = dev(a)
+    out = dev(np.zeros((33, 1)))
+    torch.cuda.synchronize()
+    plan = S.make_plan(lambda x: x, "+", None, A.size, promoteshape(A.size, out, A))     # accumulates INTO out
+    side = torch.cuda.Stream()
+    want = a.sum(axis=1, keepdims=True)
+    n = 0
+    for rep in range(6):
+        plan.execute(stream.handle)                 # direct dispatch
+        plan.execute(side.cuda_stream)              # HIP, another stream
+        plan.execute(stream.handle)
+        plan.execute(0)                             # HIP, the null stream
+        n += 4
+    stream.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out), want * n)
