@@ -231,12 +231,12 @@ class Stream:
 
     def __enter__(self):
         import importlib
-        importlib.import_module(".mapreduce", __package__)._STREAM_OVERRIDE.append(self.handle)  # (the package attribute is the function)
+        importlib.import_module(".mapreduce", __package__)._push_stream(self.handle)  # (the package attribute is the function)
         return self
 
     def __exit__(self, *exc):
         import importlib
-        importlib.import_module(".mapreduce", __package__)._STREAM_OVERRIDE.pop()
+        importlib.import_module(".mapreduce", __package__)._pop_stream()
         self.synchronize()
         return False
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 import collections
 import ctypes as C
 import operator
+import threading
 
 import numpy as np
 
@@ -75,15 +76,30 @@ def _initop_code(initop):
 _TORCH_CUR = None
 
 
-_STREAM_OVERRIDE = []  # innermost `with S.Stream() as st:` first: the front ends then launch on the library-owned stream
+class _StreamStack(threading.local):
+    """Per thread (like torch's current stream): the library-owned streams of the enclosing `with S.Stream():` blocks, innermost last."""
+
+    def __init__(self):
+        self.stack = []
+
+
+_STREAM_OVERRIDE = _StreamStack()
+
+
+def _push_stream(handle: int) -> None:
+    _STREAM_OVERRIDE.stack.append(int(handle))
+
+
+def _pop_stream() -> None:
+    _STREAM_OVERRIDE.stack.pop()
 
 
 def _current_stream() -> int:
     """Raw handle of the stream the front ends launch on: the library-owned stream of an enclosing `with S.Stream():` block, else
     torch's current HIP stream (0 = the null stream when torch / a device is absent)."""
     global _TORCH_CUR
-    if _STREAM_OVERRIDE:
-        return _STREAM_OVERRIDE[-1]
+    if _STREAM_OVERRIDE.stack:
+        return _STREAM_OVERRIDE.stack[-1]
     if _TORCH_CUR is None:
         try:
             import torch

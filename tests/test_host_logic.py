@@ -267,3 +267,27 @@ def test_numpy_scalar_on_the_left_keeps_its_type():
     # ... while a Python float IS a Float64 literal and widens the call, as in Julia
     d = S.make_plan(lambda x, y: 0.5 * x + 2.0 * y, None, None, c.size, (c, c, a.permutedims((2, 1, 0)))).describe()
     assert "ct=f64(mixed)" in d, d
+
+
+def test_stream_override_is_per_thread():
+    """`with S.Stream():` redirects the front ends of the CURRENT thread only (like torch's current stream); no device needed here:
+    the stack is exercised directly."""
+    import threading
+    from strided_jl_amd import mapreduce as M
+    import importlib
+    M = importlib.import_module("strided_jl_amd.mapreduce")
+    seen = {}
+    M._push_stream(0x1234)
+    try:
+        assert M._current_stream() == 0x1234
+        t = threading.Thread(target=lambda: seen.setdefault("other", list(M._STREAM_OVERRIDE.stack)))
+        t.start()
+        t.join()
+        assert seen["other"] == []
+        M._push_stream(0x5678)
+        assert M._current_stream() == 0x5678
+        M._pop_stream()
+        assert M._current_stream() == 0x1234
+    finally:
+        M._pop_stream()
+    assert M._STREAM_OVERRIDE.stack == []
