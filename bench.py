@@ -5,7 +5,8 @@ Metric (BASELINE.json): GB/s effective HBM (and % of roofline) for @strided perm
 broadcast on 32^4 Float64.  One STEP = the two README workloads on one pair of 32^4 f64 arrays,
 inputs resident in HBM:
     (C2)  permutedims!(B, A, (4,3,2,1))                         README.md:98
-    (C3)  B .= A_p1 .+ A_p2 .+ A_p3 .+ A_p4  (4 permuted views) README.md:104
+    (C3)  C .= A_p1 .+ A_p2 .+ A_p3 .+ A_p4  (4 permuted views) README.md:104   (into a third array C: the two
+          operations of a step then share nothing but the read-only input A)
 Algorithmic bytes per step = 2 launches x (8 MiB read + 8 MiB written) = 33,554,432 B
 (every distinct array counted once).
 
@@ -315,12 +316,15 @@ def main():
     if use_seq:
         # the recorded step, replayed by the library (csrc/smr_seq.cpp).  One smr_seq_run(K) = K steps; it returns when the
         # replay has completed on devices without stream-side waits, smr_seq_wait covers the others.
+        # The replay is issued on a library-owned stream (smr_stream_create): smr_seq_run returns after the doorbells and needs no
+        # holding kernel on a HIP stream; smr_seq_wait is the host-side wait; torch.cuda.synchronize() in barrier() covers the device.
         seq = S.Sequence().add(plan2).add(plan3)
         if args.step_mode == "seq1":
             seq.set("queues", 1)
+        seq_stream = S.Stream()
         tB.zero_(); tC.zero_()
         torch.cuda.synchronize()
-        seq.run(max(1, W), cur())  # untimed: builds the packets, creates the queues
+        seq.run(max(1, W), seq_stream.handle)  # untimed: builds the packets, creates the queues
         seq.wait()
         check_outputs("sequence warm-up")
     if use_graph:
@@ -334,10 +338,10 @@ def main():
         nrep = K // chunk
         gstep.replay()  # untimed: first replay uploads the graph
     if use_seq:  # untimed rehearsal of exactly the timed call (host code paths, queue doorbells and signals warm)
-        seq.run(K, cur())
+        seq.run(K, seq_stream.handle)
         seq.wait()
     tB.zero_(); tC.zero_()  # the timed region must (re)produce both outputs
-    stream_handle = cur()
+    stream_handle = seq_stream.handle if use_seq else cur()
     barrier()
     t0 = time.perf_counter()
     if use_seq:
@@ -387,17 +391,24 @@ def main():
     def seq_us(queues, nsteps):
         """wall clock (run + wait) per step of `nsteps` replays of the recorded step; best of 7"""
         q = S.Sequence().add(plan2).add(plan3)
-        q.set("queues", queues)
-        q.run(5, cur()); q.wait()
+        for k, v in queues.items():
+            q.set(k, v)
+        st = S.Stream()
+        q.run(5, st.handle); q.wait()
         best = 1e30
         for _ in range(7):
             torch.cuda.synchronize()
             t = time.perf_counter()
-            q.run(nsteps, cur()); q.wait()
+            q.run(nsteps, st.handle); q.wait()
             best = min(best, time.perf_counter() - t)
-        return round(best / nsteps * 1e6, 3), q.info()
-    step_us["seq_one_queue"], _ = seq_us(1, 2 * reps)
-    step_us["seq_queue_per_component"], sinfo = seq_us(4, 2 * reps)
+        info = q.info()
+        del q
+        st.close()
+        return round(best / nsteps * 1e6, 3), info
+    step_us["seq_one_queue"], _ = seq_us({"queues": 1}, 2 * reps)
+    step_us["seq_queue_per_component"], _ = seq_us({"queues": 2, "slices": 1}, 2 * reps)
+    step_us["seq_queue_per_component_r04_fences"], _ = seq_us({"queues": 2, "slices": 1, "acquire": 1}, 2 * reps)
+    step_us["seq_default"], sinfo = seq_us({}, 2 * reps)
     # the same step issued EAGERLY, call by call from Python, on a library-owned stream (eager direct dispatch: the library submits each
     # launch itself on the hardware queue its data dependencies select) against eager calls on a HIP stream
     def eager_us(handle, sync, nsteps=1000):
@@ -462,12 +473,13 @@ def main():
             "ms_per_step_replay": round(replay_us / K * 1e-3, 6) if (use_seq and replay_us is not None) else None,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]+configs[2]: permutedims!(B,A,(4,3,2,1)) then B .= sum of 4 permuted views, "
-                                   "32x32x32x32 Float64, one pair of arrays per GPU",
+            "config": {"workload": "configs[1]+configs[2]: permutedims!(B,A,(4,3,2,1)) then C .= sum of 4 permuted views of A (a third array C), "
+                                   "32x32x32x32 Float64, one set of arrays (A, B, C) per GPU",
                        "algorithmic_bytes_per_step": bytes2 + bytes3,
                        "launch": ("smr_seq replay (AQL packets on the library's HSA queues), " +
-                                  ("one queue per dependency component: the step's two operations only share the read-only input A and overlap; "
-                                   "results of in-order execution, verified bit-exactly after the timed region" if args.step_mode == "seq"
+                                  ("one queue per dependency component, the heavier chain (the 4-way sum) cut into two block ranges: the step's two "
+                                   "operations only share the read-only input A and overlap; acquire fences only where the sequence reads what it "
+                                   "writes (nowhere here); results of in-order execution, verified bit-exactly after the timed region" if args.step_mode == "seq"
                                    else "one queue, in recorded order") + " | " + str(seq_info)) if use_seq else
                                  ("hipGraph, " + ("two stream-ordered chains (one per output array; both operations only read A), one fork / one join per graph"
                                                   if args.step_mode == "chains" else "in order on one stream")) if use_graph else "eager",
@@ -549,6 +561,7 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
         for i in range(npair):
             q.add(p, bases=[poolB.data_ptr() + i * esz] + [poolA.data_ptr() + i * esz] * len(srcs))
         q.set("queues", 2)
+        q.set("async", 0)
         q.run(2, cur()); q.wait()
         best = 1e30
         for _ in range(5):

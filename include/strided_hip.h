@@ -245,14 +245,24 @@ int smr_stream_destroy(void* stream);
  * kernel boundary costs 1.6-1.9 us there (profiles/r04_overlap.txt); two queues overlap one chain's
  * boundary with the other chain's kernel.  A replay costs ~0.1 us of host time per launch instead of
  * HIP's 3.6-4 us.  Work queued on `stream` before the call completes first (the call waits for it on
- * the host when the stream is busy); work queued on `stream` afterwards waits for the replay
- * (smr_seq_run itself returns only when the replay has completed; with $SMR_SEQ_STREAM_WAIT=1 and a device that
- * supports it, hipStreamWaitValue64 on the completion signals instead); smr_seq_wait blocks the host until the last replay has
- * completed (active wait on the signals: microseconds sooner than hipStreamSynchronize).  Runtime-
- * compiled kernels take part like precompiled ones (their entry points carry a per-program name; the
- * sequence co-owns the loaded program).  A sequence holding a kernel that needs scratch memory is
- * replayed through HIP, in order (smr_seq_info tells which, and reports "last_replay_us": first
- * doorbell -> completion observed).
+ * the host when the stream is busy).  smr_seq_run is ASYNCHRONOUS (round 5): it returns when the doorbells are rung -- like the
+ * reference's @spawn, whose `wait` is a separate step (src/mapreduce.jl:214-223) -- and work queued on `stream` afterwards still
+ * comes after the replay:
+ *   - a library-owned stream (smr_stream_create): everything on it goes through this library, which waits for the replay before
+ *     whatever it submits or does there next;
+ *   - a HIP stream: hipStreamWaitValue64 on the completion signals where the device offers it ($SMR_SEQ_STREAM_WAIT=1), otherwise a
+ *     one-wave holding kernel on the stream that polls the signals (bounded by $SMR_DIRECT_TIMEOUT_MS; smr_seq_wait reports a
+ *     hold that gave up).
+ * smr_seq_wait blocks the host until the last replay has completed (active wait on the signals: microseconds sooner than
+ * hipStreamSynchronize).  smr_seq_set "async" = 0 makes smr_seq_run itself wait.  Runtime-compiled kernels take part like
+ * precompiled ones (their entry points carry a per-program name; the sequence co-owns the loaded program).  A sequence holding a
+ * kernel that needs scratch memory is replayed through HIP, in order (smr_seq_info tells which, and reports "last_replay_us":
+ * first doorbell -> completion observed; "kernarg_layout": how the hidden-argument offsets of the packets are known -- "metadata"
+ * = read from the code objects' NT_AMDGPU_METADATA notes, "+verified" = a self-test packet saw the blockDim / gridDim / LDS it was
+ * given; csrc/smr_kmeta.cpp).
+ * Failure: an HSA queue error, or a completion signal that does not arrive within $SMR_DIRECT_TIMEOUT_MS (default 30 s), marks the
+ * device's direct path as failed -- the call that notices returns SMR_EHIP, nothing waits on those queues again, and later
+ * executions and replays go through HIP.
  * One replay per device is in flight at a time.  The recorded base pointers / plans must stay alive
  * while the sequence exists.                                                                         */
 typedef struct smr_seq smr_seq;
@@ -265,12 +275,23 @@ int smr_seq_info(smr_seq* seq, char* buf, size_t buflen);
  * of recorded execution i (numbered in order of first appearance); returns the number of components or a negative status.      */
 int smr_seq_components(smr_seq* seq, int32_t* comp, size_t cap);
 /* "queues" (1..8, default 4: hardware queues a replay may spread over; 1 = everything in recorded order on one queue; more than 4
- * are time-multiplexed by the hardware scheduler), "slices" (1..8, default 1: a component that consists of ONE launch of independent
- * workgroups is cut into that many contiguous block ranges, one queue each -- the device form of _mapreduce_threaded!'s bisection).
- * Experiments: "fence_scope" (acquire/release scope of the packets inside a replay: 0 none, 1 agent, 2 system),
+ * are time-multiplexed by the hardware scheduler); "slices" (-1 | 1..8: a component that consists of ONE launch of independent
+ * workgroups is cut into that many contiguous block ranges, one queue each -- the device form of _mapreduce_threaded!'s bisection;
+ * -1, the default: only the heaviest such component is cut, in two, when a third queue is free); "slices:<c>" (block ranges of
+ * component c alone); "async" (-1 default / 0 blocking smr_seq_run / 1).
+ * Fences of the packets inside a replay: "acquire" (-1 default: agent scope only on packets that read bytes the sequence writes --
+ * an acquire invalidates the L2s, i.e. the read-only inputs of everything in flight; 0 none, 1 agent, 2 system on every packet),
+ * "release" (1 agent, default; 2 system; 0 none: an EXPERIMENT, write-after-write across XCDs needs the write-back).
+ * Experiments: "fence_scope" (both at once), "first_acquire" / "last_release" (scope of a replay's first / last packet, default 2),
  * "order" (0: every packet carries the barrier bit, 1: only those that conflict with an earlier one in flight) */
 int smr_seq_set(smr_seq* seq, const char* name, int64_t value);
 int smr_seq_destroy(smr_seq* seq);
+/* Diagnostics (no device needed): the kernarg layout csrc/smr_kmeta.cpp reads from an AMDGPU code object image.  out[0..19] =
+ * kernarg_size, explicit_end, nargs_explicit, hidden block_count x/y/z, group_size x/y/z, remainder x/y/z, global_offset x/y/z,
+ * grid_dims, dynamic_lds_size offsets (-1 = not declared), needs_runtime, private_size, group_static.  `symbol` = "<mangled>.kd", or
+ * NULL with index >= 0 to enumerate (the symbol is copied to name_out).  Returns the number of kernels, negative on a parse error. */
+int smr_debug_kernarg_layout(const void* elf, size_t bytes, const char* symbol, int index, int32_t* out, char* name_out, size_t name_cap);
+
 
 /* ---- the hot path --------------------------------------------------------------------- */
 /* One-shot replacement of _mapreduce_fuse! (src/mapreduce.jl:98): canonicalise, pick the

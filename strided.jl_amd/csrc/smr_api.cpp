@@ -166,9 +166,10 @@ int window_fence(hipStream_t s) {
         owned = it->second.owned;
         rc = window_fence_locked(W, it->second, s);
     }
-    if (owned && eager_available()) {  // what the library submitted directly completes before whatever follows on the stream through HIP ...
-        eager_fence_all();
-        eager_note_hip_work();         // ... and that HIP work completes before the next direct launch
+    if (owned && eager_available(s)) {  // what the library submitted directly completes before whatever follows on the stream through HIP ...
+        const int rc2 = eager_fence_all();
+        eager_note_hip_work(s);        // ... and that HIP work completes before the next direct launch ON THIS STREAM
+        if (rc == SMR_OK) rc = rc2;
     }
     return rc;
 }
@@ -198,7 +199,7 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
         // a library-owned stream: the library submits the launch itself (smr_seq.cpp: eager direct dispatch), on the hardware queue its
         // data dependencies select -- independent executions run concurrently, host cost ~1 us instead of HIP's 3.6-4 us
         hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-        if (options().eager_direct && stream_is_owned(s) && eager_available() &&
+        if (options().eager_direct && stream_is_owned(s) && eager_available(s) &&
             (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing == hipStreamCaptureStatusNone)) {  // (a capture records HIP launches)
             std::vector<Span> rd, wr;
             footprint(plan, bases, rd, wr);
@@ -209,7 +210,7 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
             if (rc) return rc;
             if (!plan.eager_seen) {
                 plan.eager_seen = true;
-                eager_request_sys_acquire();
+                eager_request_sys_acquire(s);
             }
             std::vector<std::pair<uintptr_t, uintptr_t>> r2, w2;
             for (const Span& x : rd) r2.emplace_back(x.lo, x.hi);
@@ -217,8 +218,8 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
             rc = rec.empty() ? SMR_EUNSUPPORTED : eager_submit(plan, rec, r2, w2, s);
             if (rc != SMR_EUNSUPPORTED) return rc;
             // this execution goes through HIP (a kernel that needs scratch memory, ...): everything submitted directly comes first
-            eager_fence_all();
-            eager_note_hip_work();
+            if (int rc3 = eager_fence_all()) return rc3;
+            eager_note_hip_work(s);
         }
         window_admit(plan, bases, s);
     }
@@ -307,7 +308,7 @@ static int execute_owned(smr_plan* h, void* const* bases, hipStream_t s) {
         // launches the library submitted itself (a library-owned stream) are not HIP work: no event covers them, and the direct queues do
         // not honour hipStreamWaitEvent.  With such a stream on either side the previous execution is waited for on the host.
         if (c1 == hipStreamCaptureStatusNone && c2 == hipStreamCaptureStatusNone && (stream_is_owned(s) || stream_is_owned(h->last_stream))) {
-            eager_fence_if_active();
+            (void)eager_fence_if_active();
             (void)hipStreamSynchronize(h->last_stream);
         }
         if (c1 == hipStreamCaptureStatusNone && c2 == hipStreamCaptureStatusNone) {
@@ -363,7 +364,7 @@ static int ensure_scratch(smr_plan* h) {
 
 static void plan_free(smr_plan* h) {
     if (!h) return;
-    eager_fence_if_active();  // launches submitted directly may still read the plan's tables
+    (void)eager_fence_if_active();  // launches submitted directly may still read the plan's tables
     if (h->plan.scratch) (void)hipFree(h->plan.scratch);
     for (void*& p : h->plan.lanetab)
         if (p) {
@@ -388,6 +389,7 @@ void seq_footprint(smr_plan* plan, void* const* bases, std::vector<std::pair<uin
     for (const Span& x : w) wr.emplace_back(x.lo, x.hi);
 }
 int seq_nops(smr_plan* plan) { return plan->nops; }
+bool seq_stream_is_owned(hipStream_t s) { return stream_is_owned(s); }
 }  // namespace smr
 
 // ---- plan cache for the one-shot entry point ---------------------------------------------------------
@@ -514,9 +516,10 @@ int smr_malloc(size_t bytes, void** out) {
     return e == hipSuccess ? SMR_OK : hip_error(e, "hipMalloc");
 }
 int smr_free(void* p) {
-    eager_fence_if_active();  // hipFree waits for HIP's queues only
+    const int rc = eager_fence_if_active();  // hipFree waits for HIP's queues only
     hipError_t e = hipFree(p);
-    return e == hipSuccess ? SMR_OK : hip_error(e, "hipFree");
+    if (e != hipSuccess) return hip_error(e, "hipFree");
+    return rc;
 }
 int smr_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
     if (int rc = window_fence((hipStream_t)stream)) return rc;
@@ -588,7 +591,8 @@ int smr_stream_destroy(void* stream) {
         (void)window_fence_locked(W, it->second, (hipStream_t)stream);
         W.map.erase(it);
     }
-    eager_fence_if_active();
+    (void)eager_fence_if_active();
+    eager_forget_stream((hipStream_t)stream);
     {   // cached one-shot plans remember the stream they were created on and drain it when they are dropped: none may outlive this one
         // (round 4: a later smr_set_option -- which clears the cache -- synchronised a destroyed stream and crashed)
         Cache& c = cache();
@@ -901,6 +905,8 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
+    else if (n == "seq_self_release") o.seq_self_release = value;
+    else if (n == "self_release_max_bytes") o.self_release_max_bytes = value;
     else if (n == "nt_load") o.nt_load = value;
     else if (n == "orbit_min") o.orbit_min = value;
     else if (n == "orbit_few") o.orbit_few = value;
@@ -983,6 +989,8 @@ int64_t smr_get_option(const char* name) {
     if (n == "tiled_vec") return o.tiled_vec;
     if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
+    if (n == "seq_self_release") return o.seq_self_release;
+    if (n == "self_release_max_bytes") return o.self_release_max_bytes;
     if (n == "nt_load") return o.nt_load;
     if (n == "orbit_min") return o.orbit_min;
     if (n == "orbit_few") return o.orbit_few;

@@ -79,6 +79,11 @@ template <> struct tr<b16> { typedef float real; static constexpr bool cx = fals
 // as if (nts) store_nt else store: the optimiser hoists/sinks the pair into ONE store and drops `nt`
 // (seen in the ISA).  store_vec() keeps them apart with asm statements; loops over several stores
 // branch once and bracket the non-temporal block with nt_block_guard().
+// Store policy of a launch (kernel argument `nts`): 0 plain, 1 non-temporal, 2 agent-scope WRITE-THROUGH.
+// Policy 2 ("self-released" launches, round 5): every store carries sc1 -- it is written through the XCD's L2 to the memory side, the
+// level all eight XCDs share -- and the wave waits for the acknowledgements before it ends (self_release_wait).  When such a kernel
+// has completed, nothing it wrote sits dirty in an L2: the release fence of its dispatch packet (a write-back of all eight L2s by the
+// packet processor) has nothing left to do, and a recorded sequence drops it (smr_seq.cpp).  A later reader still acquires.
 template <bool NT, class VT>
 SMR_DEV void store_vec_ct(char* p, const VT& v) {
     if constexpr (NT && sizeof(VT) == 16) {
@@ -93,6 +98,34 @@ SMR_DEV void store_vec_ct(char* p, const VT& v) {
         *reinterpret_cast<VT*>(p) = v;
     }
 }
+// is there a write-through form for this vector type?  (launchers offer policy 2 only where every store of the kernel has one)
+template <class VT>
+struct has_wt_store {
+    static constexpr bool value = sizeof(VT) == 16 || sizeof(VT) == 8 || sizeof(VT) == 4;
+};
+template <class VT>
+SMR_DEV void store_vec_wt(char* p, const VT& v) {
+    if constexpr (sizeof(VT) == 16) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 x = *reinterpret_cast<const u4*>(&v);
+        // The s_nop belongs to the store: on gfx940+ a VALU instruction that writes a data VGPR of a store of more than 64 bits needs
+        // two wait states behind it (the store is still reading the register).  For its own stores the compiler inserts them; an
+        // inline-asm statement is opaque to its hazard recogniser, and the register allocator does reuse the data registers for the
+        // next address right away (seen in the ISA: wrong sums until the s_nop was added).
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+    } else if constexpr (sizeof(VT) == 8) {
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        const u2 x = *reinterpret_cast<const u2*>(&v);
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    } else if constexpr (sizeof(VT) == 4) {
+        const uint32_t x = *reinterpret_cast<const uint32_t*>(&v);
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    } else {
+        *reinterpret_cast<VT*>(p) = v;  // (never offered: has_wt_store)
+    }
+}
+// every store of this wave has been acknowledged by the memory side (policy 2: the last thing a wave does)
+SMR_DEV void self_release_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 SMR_DEV void nt_block_guard() { asm volatile("; nt stores" ::: "memory"); }
 
 // vector load, plain or non-temporal by a compile-time switch (a run-time switch belongs around the whole loop:
@@ -115,7 +148,9 @@ SMR_DEV VT load_vec_ct(const void* p) {
 
 template <class VT>
 SMR_DEV void store_vec(char* p, const VT& v, int nts) {
-    if (nts) {
+    if (nts == 2) {
+        store_vec_wt<VT>(p, v);
+    } else if (nts) {
         nt_block_guard();
         store_vec_ct<true>(p, v);
         nt_block_guard();

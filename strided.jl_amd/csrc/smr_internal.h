@@ -233,6 +233,7 @@ struct Plan {
         int launch = 0;
         std::vector<unsigned char> bytes;  // explicit arguments (the key)
         void* dev = nullptr;
+        int dev_index = 0;                 // the device whose arena holds the block (epochs are per device)
         unsigned long long epoch = 0;      // arena generation the block belongs to
     };
     mutable std::vector<ArgBlock> eager_args;
@@ -280,6 +281,8 @@ struct Options {
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
+    i64 seq_self_release = 1;   // launches recorded for a sequence use write-through stores where the family can, and their packets drop the release fence
+    i64 self_release_max_bytes = (i64)64 << 20;  // ... when the destination is at most this big (beyond, a launch lasts far longer than its fences)
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
     i64 orbit_min = 150;     // pick the largest tile edge that still yields this many orbits (measured: tools/orbit_sweep.py)
     i64 orbit_pipe = -1;     // persistent pipelined ORBIT form: 0 never, 1 whenever there are more orbits than CUs, -1 = when LDS leaves one workgroup per CU
@@ -364,6 +367,10 @@ struct RecLaunch {
     //   2: the pointer at byte `slice_off` addresses a table with one row of `slice_row` bytes per workgroup (advance it by lo rows).
     int slice_kind = 0;
     unsigned slice_off = 0, slice_row = 0;
+    // The launcher's statement that every global store of this launch is an agent-scope write-through store and that every wave waits
+    // for the acknowledgements before it ends (smr_device.h: store policy 2): nothing the launch wrote is left dirty in an L2, so
+    // its dispatch packet needs no release fence inside a replay.
+    bool self_released = false;
     std::vector<unsigned char> args;  // the explicit kernel arguments in kernarg-segment layout
 };
 std::vector<RecLaunch>* recorder();  // thread-local, nullptr when nothing records
@@ -371,15 +378,21 @@ std::vector<RecLaunch>* recorder();  // thread-local, nullptr when nothing recor
 struct Plan;
 int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::vector<std::pair<uintptr_t, uintptr_t>>& rd,
                  const std::vector<std::pair<uintptr_t, uintptr_t>>& wr, hipStream_t s);
-void eager_fence_all();
-void eager_note_hip_work();
-void eager_request_sys_acquire();
+int eager_fence_all();                            // SMR_OK, or SMR_EHIP: a device's direct path failed (reported once)
+void eager_note_hip_work(hipStream_t s);          // the library queued HIP work on owned stream s: s's next direct launch drains it first
+void eager_forget_stream(hipStream_t s);
+void eager_request_sys_acquire(hipStream_t s);
 long eager_stat(int which);
-bool eager_available();
-void eager_fence_if_active();
+bool eager_available(hipStream_t s);              // (of the stream's device)
+int eager_fence_if_active();
 void mark_sliceable(int kind, unsigned off, unsigned row);  // applies to the NEXT recorded launch of the calling thread (no-op when nothing records)
+void mark_self_released();                                  // likewise: RecLaunch::self_released
 void take_slice_mark(RecLaunch& r);
-void set_recorder(std::vector<RecLaunch>* r);
+void set_recorder(std::vector<RecLaunch>* r, bool for_sequence = false);
+// Is the launch being recorded for a SEQUENCE (smr_seq) whose packets may drop their release fence, and is this execution in the
+// regime where the fence matters (what it writes fits the caches: option "self_release_max_bytes", default 64 MiB)?  Launchers that
+// can issue write-through stores then do (store policy 2) and call mark_self_released().
+bool want_self_release(const Plan& plan);
 
 // launchers (one per kernel TU)
 int launch_generic_map(const Plan& plan, void* const* bases, hipStream_t s);

@@ -283,7 +283,14 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
         }
         const bool nts = nts_flag != 0;
         if (!PIPE || live) {
-            if (nts) {
+            if (nts_flag == 2) {  // agent-scope write-through ("self-released" launch: smr_device.h)
+                if constexpr (has_wt_store<VT>::value) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int r = 0; r < NREP; ++r) store_vec_wt<VT>(a.dst + org[g] + goff[r], x[g][r]);
+                }
+            } else if (nts) {
                 nt_block_guard();
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
@@ -298,9 +305,13 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
             }
         }
         if constexpr (!PIPE) {
+            if (nts_flag == 2) self_release_wait();
             return;
         } else {
-            if (!more) return;
+            if (!more) {
+                if (nts_flag == 2) self_release_wait();
+                return;
+            }
             __syncthreads();  // every lane has read its LDS values: the slots may be overwritten
             live = nlive;
 #pragma unroll
@@ -493,6 +504,10 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     // automatic: only tiles that write whole 128-byte lines (symmetrise 4000^2: 40.2 -> 38.5 us); the 32-/64-byte
     // runs of the 4-D orbits rely on line partners meeting in L2 and get slower (4.8 -> 6.3 us at 32^4)
     a.nts = (opt.nt_store > 0 || (opt.nt_store < 0 && plan.c.strides[0][0] == 1 && (sizeof(T) << o.lg[0]) >= 128)) ? 1 : 0;
+    // write-through stores: forced (nt_store = 2), or a launch recorded for a sequence that fits the caches several times over
+    // (want_self_release): its packet then needs no release fence
+    const bool wt = has_wt_store<OVec<T, V>>::value && (opt.nt_store == 2 || want_self_release(plan));
+    if (wt) a.nts = 2;
     const unsigned block = 1u << a.ntlog;
     size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);
     if (opt.orbit_lds_min > 0) lds = std::max(lds, (size_t)opt.orbit_lds_min);  // experiment: fewer resident workgroups per CU
@@ -532,6 +547,7 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
         }
         if (!PIPE) mark_sliceable(2, (unsigned)offsetof(OrbitArgs, list), (unsigned)(NG * sizeof(uint32_t)));  // one table row per workgroup
+        if (a.nts == 2) mark_self_released();
         SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, a, f SMR_STAMP_ARG(grid, block));
         return check_launch("k_orbit_map");
     }

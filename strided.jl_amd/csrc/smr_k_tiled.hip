@@ -388,7 +388,14 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
             for (int r = 0; r < NREP; ++r)
                 if (okd[r]) store_vec_ct<decltype(NT)::value, VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
         };
-        if (a.nts) {
+        if (a.nts == 2) {  // agent-scope write-through ("self-released" launch: smr_device.h)
+            if constexpr (has_wt_store<VT>::value) {
+#pragma unroll
+                for (int r = 0; r < NREP; ++r)
+                    if (okd[r]) store_vec_wt<VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
+                self_release_wait();
+            }
+        } else if (a.nts) {
             nt_block_guard();
             put(BoolC<true>{});
             nt_block_guard();
@@ -764,6 +771,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
                 if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
             }
             mark_sliceable(1, (unsigned)offsetof(TiledArgs<WIDE>, blk0), 0);  // a workgroup owns its tile: block ranges are independent
+            if (ka.nts == 2) mark_self_released();
             SMR_LAUNCH(kern, dim3(grid_), dim3(1u << THRLOG), lds, s, ka, f SMR_STAMP_ARG(grid_, 1u << THRLOG));
             return check_launch("k_tiled_map");
         }
@@ -776,6 +784,11 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     if (options().nt_store < 0) {
         const i64 run = std::min<i64>(c.dims[0], (i64)1 << t.tlog[0]) * c.esize[0];
         nts_now = (c.strides[0][0] == 1 && run >= 128) ? 1 : 0;
+    }
+    // write-through stores (policy 2): forced, or a launch recorded for a sequence (its packet then needs no release fence).  Only the
+    // one-shot vector form: there every store of the kernel is one of the vector stores below.
+    if constexpr (V > 1 && !MIXED && has_wt_store<TVec<T, V>>::value) {
+        if (pgrid == 0 && (options().nt_store == 2 || want_self_release(plan))) nts_now = 2;
     }
     // the arguments depend on the plan only, except for the operand addresses: built once
     std::vector<unsigned char>& cached = plan.tiled_args[variant];

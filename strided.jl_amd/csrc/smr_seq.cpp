@@ -25,6 +25,9 @@
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
 #include <link.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -34,16 +37,37 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
 #include "smr_internal.h"
+#include "smr_kmeta.h"
 
 namespace smr {
 
 static thread_local std::vector<RecLaunch>* tl_recorder = nullptr;
 std::vector<RecLaunch>* recorder() { return tl_recorder; }
-void set_recorder(std::vector<RecLaunch>* r) { tl_recorder = r; }
+static thread_local bool tl_rec_seq = false, tl_self_released = false;
+void set_recorder(std::vector<RecLaunch>* r, bool for_sequence) {
+    tl_recorder = r;
+    tl_rec_seq = r != nullptr && for_sequence;
+}
+void mark_self_released() {
+    if (tl_recorder) tl_self_released = true;
+}
+bool want_self_release(const Plan& plan) {
+    if (!tl_recorder || !tl_rec_seq) return false;
+    const Options& o = options();
+    if (!o.seq_self_release) return false;
+    const Canon& c = plan.c;
+    i64 lo = 0, hi = 0;  // extent of the destination in elements
+    for (int d = 0; d < c.N; ++d) {
+        const i64 ext = (c.dims[d] - 1) * c.strides[0][d];
+        (ext < 0 ? lo : hi) += ext;
+    }
+    return (hi - lo + 1) * (i64)c.esize[0] <= o.self_release_max_bytes;
+}
 static thread_local int tl_slice_kind = 0;
 static thread_local unsigned tl_slice_off = 0, tl_slice_row = 0;
 void mark_sliceable(int kind, unsigned off, unsigned row) {
@@ -57,12 +81,15 @@ void take_slice_mark(RecLaunch& r) {
     r.slice_off = tl_slice_off;
     r.slice_row = tl_slice_row;
     tl_slice_kind = 0;
+    r.self_released = tl_self_released;
+    tl_self_released = false;
 }
 
 // smr_api.cpp
 int seq_execute_plan(smr_plan* plan, void* const* bases, hipStream_t s, bool prepare_only);
 void seq_footprint(smr_plan* plan, void* const* bases, std::vector<std::pair<uintptr_t, uintptr_t>>& rd, std::vector<std::pair<uintptr_t, uintptr_t>>& wr);
 int seq_nops(smr_plan* plan);
+bool seq_stream_is_owned(hipStream_t s);
 
 namespace {
 
@@ -190,9 +217,21 @@ struct KernelRef {
     uint64_t object = 0;
     uint32_t kernarg_size = 0, group_static = 0, private_size = 0;
     std::string name;
+    KernargLayout layout;        // where the hidden arguments live: from the code object's metadata, else the code-object-v5 rule
+    bool from_metadata = false;
 };
 struct Direct {
+    int dev = 0;
     hsa_agent_t agent{};
+    // A queue error (the HSA callback) or a wait that ran out of time marks the device's direct path as failed: every wait returns,
+    // the call that noticed returns SMR_EHIP, and later executions go through HIP (direct().ok is false from then on).
+    std::atomic<bool> failed{false};
+    std::string fail_why;
+    // kernarg layouts by code object (storage base address of the loaded image) and kernel-descriptor symbol
+    std::map<uint64_t, std::map<std::string, KernargLayout>> code_objects;
+    int n_meta = 0, n_v5 = 0;    // kernels resolved with a layout from metadata / from the v5 rule
+    bool probe_ok = false;       // the self-test launch saw the blockDim / gridDim / LDS it was given
+    bool probe_meta = false;     // ... with a layout read from metadata
     // SEQ_MAXQ hardware queues of the library's own (created on first use): launches that belong to different dependency
     // components of a sequence go to different queues, where neither the barrier bit nor the acquire / release fences of one
     // chain hold up the other (inside ONE queue the packet processor serialises consecutive dispatches on their fences even
@@ -231,8 +270,54 @@ hsa_status_t pick_agent(hsa_agent_t a, void* data) {
     return HSA_STATUS_SUCCESS;
 }
 
-void queue_error(hsa_status_t st, hsa_queue_t*, void*) {
-    std::fprintf(stderr, "libstrided_hip: the direct-dispatch HSA queue reported error 0x%x\n", (unsigned)st);
+void queue_error(hsa_status_t st, hsa_queue_t*, void* data) {
+    std::fprintf(stderr, "libstrided_hip: the direct-dispatch HSA queue reported error 0x%x; direct dispatch is switched off\n", (unsigned)st);
+    if (Direct* d = (Direct*)data) d->failed.store(true);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// how long a wait on the direct queues may last before the path is declared dead ($SMR_DIRECT_TIMEOUT_MS, default 30 s: far above
+// any replay this library issues, far below "forever")
+double direct_timeout_s() {
+    static const double t = [] {
+        const char* e = std::getenv("SMR_DIRECT_TIMEOUT_MS");
+        const double ms = e ? std::atof(e) : 0;
+        return ms > 0 ? ms * 1e-3 : 30.0;
+    }();
+    return t;
+}
+
+void direct_fail(Direct& d, const std::string& why) {
+    const bool first = !d.failed.exchange(true) || d.fail_why.empty();
+    if (first) d.fail_why = why;
+    d.ok = false;
+    d.why = "direct dispatch failed earlier: " + d.fail_why;
+    set_error(SMR_EHIP, "direct dispatch: " + d.fail_why);
+}
+
+// Bounded wait for a completion signal.  false: the queue reported an error or the time ran out -- the device's direct path is
+// marked failed (the caller unwinds; nothing waits on these queues again).
+bool wait_signal(Direct& d, hsa_signal_t sig) {
+    Hsa& h = hsa();
+    if (h.signal_load(sig) == 0) return true;
+    if (d.failed.load()) {
+        direct_fail(d, "the HSA queue reported an error");
+        return false;
+    }
+    const double t0 = now_s(), limit = direct_timeout_s();
+    for (;;) {
+        // timeout hint in timestamp ticks (100 MHz on this part: ~2 ms per slice)
+        if (h.signal_wait(sig, HSA_SIGNAL_CONDITION_EQ, 0, 200000, HSA_WAIT_STATE_ACTIVE) == 0) return true;
+        if (d.failed.load()) {
+            direct_fail(d, "the HSA queue reported an error");
+            return false;
+        }
+        if (now_s() - t0 > limit) {
+            direct_fail(d, "a completion signal did not arrive within the time limit ($SMR_DIRECT_TIMEOUT_MS)");
+            return false;
+        }
+    }
 }
 
 std::mutex g_direct_mu;
@@ -242,7 +327,7 @@ std::map<int, Direct*> g_direct;
 int direct_queue(Direct& d, int k) {
     if (d.q[k]) return SMR_OK;
     Hsa& h = hsa();
-    hsa_status_t st = h.queue_create(d.agent, 16384, HSA_QUEUE_TYPE_SINGLE, queue_error, nullptr, UINT32_MAX, UINT32_MAX, &d.q[k]);
+    hsa_status_t st = h.queue_create(d.agent, 16384, HSA_QUEUE_TYPE_SINGLE, queue_error, &d, UINT32_MAX, UINT32_MAX, &d.q[k]);
     if (st != HSA_STATUS_SUCCESS) {
         d.q[k] = nullptr;
         d.why = "hsa_queue_create failed";
@@ -257,13 +342,30 @@ int direct_queue(Direct& d, int k) {
     return SMR_OK;
 }
 
-Direct& direct() {
+int current_device() {
     int dev = 0;
     (void)hipGetDevice(&dev);
+    return dev;
+}
+// the device a stream belongs to (not the calling thread's current device: a process that drives several GPUs may submit to a
+// stream of another one); the null stream belongs to the current device
+int device_of(hipStream_t s) {
+    if (s) {
+        hipDevice_t dv = 0;
+        if (hipStreamGetDevice(s, &dv) == hipSuccess) return (int)dv;
+        (void)hipGetLastError();
+    }
+    return current_device();
+}
+
+int direct_selftest(Direct& d);
+
+Direct& direct_of(int dev) {
     std::lock_guard<std::mutex> g(g_direct_mu);
     auto it = g_direct.find(dev);
     if (it != g_direct.end()) return *it->second;
     Direct* d = new Direct();
+    d->dev = dev;
     g_direct[dev] = d;
     Hsa& h = hsa();
     if (!h.ok) {
@@ -299,16 +401,59 @@ Direct& direct() {
     const char* sw = std::getenv("SMR_SEQ_STREAM_WAIT");
     if (sw && sw[0] == '1' && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can && d->done_ptr[0]) d->wait_value_ok = true;
     d->ok = true;
+    // one packet through queue 0 before anything depends on the path: a probe kernel reports the blockDim / gridDim it sees and
+    // writes through its dynamic LDS.  A wrong hidden-argument layout, a ring that is not ours to write, a signal that never
+    // arrives -- all end here, with the path switched off and everything going through HIP.
+    if (direct_selftest(*d) != SMR_OK) d->ok = false;
     return *d;
 }
+Direct& direct() { return direct_of(current_device()); }
 
 struct Lookup {
     Hsa* h;
+    Direct* d;
     hsa_agent_t agent;
     std::string kd;
     KernelRef out;
     bool have = false;
 };
+
+// is [p, p + n) mapped in this process?  (the loader reports where the code object's image was when it was loaded; HIP keeps that
+// memory for the life of the module, but a stale address must cost a fallback, not a fault)
+bool range_mapped(const void* p, size_t n) {
+    const long page = sysconf(_SC_PAGESIZE);
+    if (page <= 0 || !p || !n) return false;
+    const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)(page - 1), hi = ((uintptr_t)p + n + (uintptr_t)page - 1) & ~(uintptr_t)(page - 1);
+    std::vector<unsigned char> vec((hi - lo) / (uintptr_t)page);
+    return mincore((void*)lo, hi - lo, vec.data()) == 0;
+}
+
+// the loaded code objects of the executable that holds the kernel: parse the metadata of each image once, look the kernel up
+hsa_status_t scan_code_object(hsa_executable_t, hsa_loaded_code_object_t lco, void* data) {
+    Lookup* l = (Lookup*)data;
+    auto get = l->h->loader.hsa_ven_amd_loader_loaded_code_object_get_info;
+    if (!get) return HSA_STATUS_INFO_BREAK;
+    hsa_ven_amd_loader_code_object_storage_type_t st = HSA_VEN_AMD_LOADER_CODE_OBJECT_STORAGE_TYPE_NONE;
+    if (get(lco, HSA_VEN_AMD_LOADER_LOADED_CODE_OBJECT_INFO_CODE_OBJECT_STORAGE_TYPE, &st) != HSA_STATUS_SUCCESS || st != HSA_VEN_AMD_LOADER_CODE_OBJECT_STORAGE_TYPE_MEMORY)
+        return HSA_STATUS_SUCCESS;
+    uint64_t base = 0, size = 0;
+    if (get(lco, HSA_VEN_AMD_LOADER_LOADED_CODE_OBJECT_INFO_CODE_OBJECT_STORAGE_MEMORY_BASE, &base) != HSA_STATUS_SUCCESS ||
+        get(lco, HSA_VEN_AMD_LOADER_LOADED_CODE_OBJECT_INFO_CODE_OBJECT_STORAGE_MEMORY_SIZE, &size) != HSA_STATUS_SUCCESS || !base || !size)
+        return HSA_STATUS_SUCCESS;
+    auto it = l->d->code_objects.find(base);
+    if (it == l->d->code_objects.end()) {
+        std::map<std::string, KernargLayout> kernels;
+        std::string why;
+        if (range_mapped((const void*)base, (size_t)size)) (void)kmeta_parse((const void*)base, (size_t)size, kernels, why);
+        it = l->d->code_objects.emplace(base, std::move(kernels)).first;  // (an image that did not parse stays as an empty entry)
+    }
+    auto k = it->second.find(l->kd);
+    if (k == it->second.end()) return HSA_STATUS_SUCCESS;
+    l->out.layout = k->second;
+    l->out.from_metadata = true;
+    return HSA_STATUS_INFO_BREAK;
+}
+
 hsa_status_t lookup_exec(hsa_executable_t ex, void* data) {
     Lookup* l = (Lookup*)data;
     hsa_executable_symbol_t sym;
@@ -320,6 +465,10 @@ hsa_status_t lookup_exec(hsa_executable_t ex, void* data) {
     l->h->symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &l->out.group_static);
     l->h->symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &l->out.private_size);
     l->have = true;
+    // the hidden-argument layout, from the metadata of the code object this executable was loaded from
+    const char* off = std::getenv("SMR_DIRECT_METADATA");
+    if (!(off && off[0] == '0') && l->h->loader.hsa_ven_amd_loader_executable_iterate_loaded_code_objects)
+        (void)l->h->loader.hsa_ven_amd_loader_executable_iterate_loaded_code_objects(ex, scan_code_object, l);
     return HSA_STATUS_INFO_BREAK;
 }
 
@@ -327,13 +476,50 @@ hsa_status_t lookup_exec(hsa_executable_t ex, void* data) {
 int resolve_name(Direct& d, const std::string& name, KernelRef& out) {
     Lookup l;
     l.h = &hsa();
+    l.d = &d;
     l.agent = d.agent;
     l.kd = name + ".kd";
     l.h->loader.hsa_ven_amd_loader_iterate_executables(lookup_exec, &l);
     if (!l.have) return set_error(SMR_EUNSUPPORTED, std::string("direct dispatch: kernel descriptor not found for ") + name);
     l.out.name = name;
+    if (l.out.from_metadata) {
+        // the runtime's view of the kernel and the metadata's must agree, and nothing only HIP could supply may be asked for
+        if ((uint32_t)l.out.layout.kernarg_size != l.out.kernarg_size)
+            return set_error(SMR_EUNSUPPORTED, "direct dispatch: kernarg size of " + name + " differs between the loader and the code object's metadata");
+        if (l.out.layout.needs_runtime) return set_error(SMR_EUNSUPPORTED, "direct dispatch: " + name + " declares hidden arguments only the HIP runtime can supply");
+        ++d.n_meta;
+    } else {
+        ++d.n_v5;  // layout by the code-object-v5 rule once the explicit size is known (kernarg_layout_of); trusted only because the self-test passed with it
+    }
     out = l.out;
     return SMR_OK;
+}
+
+// The layout to fill for a launch whose explicit arguments occupy `explicit_bytes`: the metadata's when it was found -- and then the
+// recorded explicit block must end where the metadata says the explicit arguments end -- else the code-object-v5 rule.
+// false: this launch cannot be dispatched directly.
+bool kernarg_layout_of(const KernelRef& k, size_t explicit_bytes, KernargLayout& L) {
+    if (k.from_metadata) {
+        // the recorder packs the explicit arguments the way the kernarg segment holds them: its block must cover every explicit
+        // argument the metadata lists and must not reach into the first hidden field
+        int32_t first_hidden = k.layout.kernarg_size;
+        auto lower = [&](int32_t off) {
+            if (off >= 0) first_hidden = std::min(first_hidden, off);
+        };
+        for (int d3 = 0; d3 < 3; ++d3) {
+            lower(k.layout.block_count[d3]);
+            lower(k.layout.group_size[d3]);
+            lower(k.layout.remainder[d3]);
+            lower(k.layout.global_offset[d3]);
+        }
+        lower(k.layout.grid_dims);
+        lower(k.layout.dynamic_lds);
+        if ((size_t)k.layout.explicit_end > explicit_bytes || explicit_bytes > (size_t)first_hidden) return false;
+        L = k.layout;
+        return true;
+    }
+    L = kmeta_v5_default(explicit_bytes, k.kernarg_size);
+    return true;
 }
 
 // host stub -> kernel descriptor in the code object HIP has loaded
@@ -352,6 +538,121 @@ int resolve_kernel(Direct& d, const void* hostfn, KernelRef& out) {
     if (rc) return rc;
     d.kernels[hostfn] = out;
     return SMR_OK;
+}
+
+// ---- self-test: one hand-built packet before anything relies on the path ------------------------------------------------------------
+// out[0] = blockDim.x, out[1] = gridDim.x (both read by the compiler from the HIDDEN arguments this file fills), out[2] = a value that
+// went through the dynamic LDS the packet asked for, out[3] = number of workgroups that ran.
+__global__ void k_direct_probe(unsigned* out, unsigned magic) {
+    extern __shared__ unsigned probe_lds[];
+    probe_lds[threadIdx.x] = magic + threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) {
+            out[0] = blockDim.x;
+            out[1] = gridDim.x;
+            out[2] = probe_lds[blockDim.x - 1];
+        }
+        atomicAdd(&out[3], 1u);
+    }
+}
+
+// a kernel on the caller's stream that holds the stream back until the replay's completion signals (host memory) read zero: makes
+// smr_seq_run asynchronous on devices without hipStreamWaitValue64.  Bounded: after ~`limit` ticks of the 100 MHz device clock it
+// gives up and raises *gave_up (the host reports it from smr_seq_wait).
+__global__ void k_seq_hold(const volatile long long* const* sigs, int n, unsigned long long limit, unsigned* gave_up) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    for (int k = 0; k < n; ++k)
+        while (__hip_atomic_load((const long long*)sigs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > limit) {
+                __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+}
+
+int direct_selftest(Direct& d) {
+    const char* off = std::getenv("SMR_DIRECT_SELFTEST");
+    if (off && off[0] == '0') return SMR_OK;
+    if (off && std::strcmp(off, "fail") == 0) {  // tests: the path a failing self-test takes
+        d.why = "direct-dispatch self-test: forced failure ($SMR_DIRECT_SELFTEST=fail)";
+        return SMR_EUNSUPPORTED;
+    }
+    Hsa& h = hsa();
+    unsigned* out = nullptr;
+    void* kargs = nullptr;
+    auto done = [&](int rc, const std::string& why) {
+        if (out) (void)hipHostFree(out);
+        if (kargs) (void)hipHostFree(kargs);
+        (void)hipGetLastError();
+        if (rc != SMR_OK) d.why = "direct-dispatch self-test: " + why;
+        return rc;
+    };
+    if (hipHostMalloc((void**)&out, 64, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&kargs, 4096, hipHostMallocDefault) != hipSuccess)
+        return done(SMR_EUNSUPPORTED, "hipHostMalloc failed");
+    std::memset(out, 0, 64);
+    KernelRef k;
+    if (resolve_kernel(d, (const void*)k_direct_probe, k) != SMR_OK) return done(SMR_EUNSUPPORTED, smr_last_error());
+    const unsigned grid = 5, block = 192, lds = 192 * 4, magic = 0x5eed0000u;
+    std::vector<unsigned char> ex(12);  // (unsigned* out, unsigned magic) in kernarg layout
+    std::memcpy(ex.data(), &out, 8);
+    std::memcpy(ex.data() + 8, &magic, 4);
+    KernargLayout lay;
+    if (k.private_size != 0 || k.kernarg_size > 4096 || !kernarg_layout_of(k, ex.size(), lay)) return done(SMR_EUNSUPPORTED, "the probe kernel's arguments do not match its metadata");
+    std::memset(kargs, 0, 4096);
+    std::memcpy(kargs, ex.data(), ex.size());
+    kmeta_fill_hidden(lay, (unsigned char*)kargs, grid, block, lds);
+    hsa_kernel_dispatch_packet_t pk;
+    std::memset(&pk, 0, sizeof pk);
+    pk.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+    pk.workgroup_size_x = (uint16_t)block;
+    pk.workgroup_size_y = pk.workgroup_size_z = 1;
+    pk.grid_size_x = grid * block;
+    pk.grid_size_y = pk.grid_size_z = 1;
+    pk.group_segment_size = k.group_static + lds;
+    pk.kernel_object = k.object;
+    pk.kernarg_address = kargs;
+    pk.completion_signal = d.done[0];
+    h.signal_store_relaxed(d.done[0], 1);
+    hsa_queue_t* hq = d.q[0];
+    const uint64_t idx = h.add_write_index(hq, 1);
+    char* slot = (char*)hq->base_address + (idx & (hq->size - 1)) * 64;
+    std::memcpy(slot + 4, (const char*)&pk + 4, 60);
+    const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                    (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+    __atomic_store_n((uint32_t*)slot, (uint32_t)hdr | ((uint32_t)pk.setup << 16), __ATOMIC_RELEASE);
+    h.signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)idx);
+    // (a short limit of its own: a first packet that does not come back within 5 s never will)
+    const double t0 = now_s();
+    while (h.signal_wait(d.done[0], HSA_SIGNAL_CONDITION_EQ, 0, 200000, HSA_WAIT_STATE_ACTIVE) != 0) {
+        if (d.failed.load() || now_s() - t0 > std::min(5.0, direct_timeout_s())) {
+            d.failed.store(true);
+            d.fail_why = "the self-test packet did not complete";
+            // the queue may still hold the packet: the buffers stay allocated (leaked on purpose)
+            out = nullptr;
+            kargs = nullptr;
+            return done(SMR_EUNSUPPORTED, "the probe packet did not complete (queue error or time-out)");
+        }
+    }
+    const unsigned want2 = magic + block - 1;
+    if (out[0] != block || out[1] != grid || out[2] != want2 || out[3] != grid) {
+        char msg[200];
+        std::snprintf(msg, sizeof msg, "the probe kernel saw blockDim %u (want %u), gridDim %u (want %u), LDS word 0x%x (want 0x%x), %u workgroups (want %u)", out[0], block,
+                      out[1], grid, out[2], want2, out[3], grid);
+        return done(SMR_EUNSUPPORTED, msg);
+    }
+    d.probe_ok = true;
+    d.probe_meta = k.from_metadata;
+    return done(SMR_OK, "");
+}
+
+// how the hidden-argument layout of this device's direct launches is known
+const char* layout_source(const Direct& d) {
+    if (!d.probe_ok) return d.n_meta > 0 && d.n_v5 == 0 ? "metadata" : "v5-rule(unverified)";
+    if (d.n_v5 == 0) return "metadata+verified";
+    return d.n_meta > 0 ? "metadata|v5-rule+verified" : "v5-rule+verified";
 }
 
 }  // namespace
@@ -386,8 +687,6 @@ bool overlaps(const Spans& v, const Spans& w) {
     return false;
 }
 
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
 uint16_t header_of(bool barrier, int acq, int rel) {
     return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                       (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
@@ -411,7 +710,7 @@ struct EagerQueue {
 };
 struct Eager {
     EagerQueue q[EAGER_Q];
-    bool ready = false, failed = false;
+    bool ready = false, failed = false, fail_reported = false;
     bool kargs_device = false, gpu_only_signals = false;
     // resident argument blocks (device memory only): a bump arena behind the per-queue rings; when it is full everything in flight is
     // waited for and the arena starts over (blocks of an older epoch are stale)
@@ -419,20 +718,25 @@ struct Eager {
     size_t arena_bytes = 0, arena_used = 0;
     unsigned long long epoch = 1;
     long n_arg_hits = 0;
-    bool hip_pending = false;  // the library queued HIP work on an owned stream since the last drain
+    std::set<hipStream_t> hip_pending;  // owned streams on which the library queued HIP work (a copy, a fallback launch) since their last drain:
+                                        // a direct launch on stream s waits for s's own HIP work only -- streams are ordered in themselves, not among each other
     unsigned sys_acquire = ~0u; // bit k: the next direct launch on queue k follows work of another agent (a copy, a table upload): acquire at system scope
     std::map<std::string, std::pair<KernelRef, std::shared_ptr<void>>> jit;  // runtime-compiled kernels by entry-point name (module pinned)
     long n_launch = 0, n_free = 0, n_same = 0, n_cross = 0, n_fallback = 0;
 };
-Eager& eager() {  // per device, like the direct queues it drives (one process per GPU is the usual case)
-    static std::mutex mu;
-    static std::map<int, Eager*> all;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> g(mu);
-    Eager*& e = all[dev];
+std::mutex g_eager_mu;
+std::map<int, Eager*> g_eager;
+Eager& eager_of(int dev) {  // per device, like the direct queues it drives (one process per GPU is the usual case)
+    std::lock_guard<std::mutex> g(g_eager_mu);
+    Eager*& e = g_eager[dev];
     if (!e) e = new Eager();
     return *e;
+}
+std::vector<int> eager_devices() {
+    std::lock_guard<std::mutex> g(g_eager_mu);
+    std::vector<int> v;
+    for (auto& kv : g_eager) v.push_back(kv.first);
+    return v;
 }
 
 // a CPU agent (for hsa_amd_agents_allow_access) and a device-local pool the CPU may be given access to (large BAR)
@@ -538,7 +842,7 @@ int eager_init(Direct& d, Eager& e) {
 }
 
 // drop the launches whose completion signal has reached 0 (in submission order: a queue completes in order)
-void put_packet(hsa_queue_t* hq, const void* body64, uint16_t header, uint16_t setup);
+bool put_packet(Direct& d, hsa_queue_t* hq, const void* body64, uint16_t header, uint16_t setup);
 void eager_wait_queue(Eager& e, Direct& d, int k);
 
 // (a queue completes in order: every packet carries the barrier bit; an entry without a signal of its own retires with the next
@@ -554,16 +858,16 @@ void eager_retire(EagerQueue& q) {
     if (done) q.inflight.erase(q.inflight.begin(), q.inflight.begin() + (long)done);
 }
 
-int eager_take_signal(Eager& e, EagerQueue& q, int self);
+int eager_take_signal(Eager& e, Direct& d, EagerQueue& q, int self);
 
 // a marker: an empty barrier packet that completes when everything submitted to the queue before it has; returns its signal index
-int eager_marker(Eager& e, EagerQueue& q, hsa_queue_t* hq, int self) {
-    const int si = eager_take_signal(e, q, self);
+int eager_marker(Eager& e, Direct& d, EagerQueue& q, hsa_queue_t* hq, int self) {
+    const int si = eager_take_signal(e, d, q, self);
     hsa_barrier_and_packet_t bp;
     std::memset(&bp, 0, sizeof bp);
     bp.completion_signal = q.sigs[si];
     const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
-    put_packet(hq, &bp, hdr, 0);
+    (void)put_packet(d, hq, &bp, hdr, 0);
     Inflight f;
     f.sig = si;
     q.inflight.push_back(std::move(f));
@@ -572,11 +876,13 @@ int eager_marker(Eager& e, EagerQueue& q, hsa_queue_t* hq, int self) {
     return si;
 }
 
+// (after a failure nothing is waited for any more: the bookkeeping is dropped, the caller learns about it from d.failed)
 void eager_wait_queue(Eager& e, Direct& d, int k) {
-    Hsa& h = hsa();
     EagerQueue& q = e.q[k];
-    if (q.unsignaled > 0) (void)eager_marker(e, q, d.q[k], k);
-    if (q.tail >= 0 && h.signal_load(q.sigs[q.tail]) != 0) h.signal_wait(q.sigs[q.tail], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    if (!d.failed.load()) {
+        if (q.unsignaled > 0) (void)eager_marker(e, d, q, d.q[k], k);
+        if (q.tail >= 0) (void)wait_signal(d, q.sigs[q.tail]);
+    }
     q.inflight.clear();
     q.tail = -1;
     q.unsignaled = 0;
@@ -584,15 +890,15 @@ void eager_wait_queue(Eager& e, Direct& d, int k) {
 
 // the next completion signal of queue `self` (a ring): the packet that used it EAGER_SIGS signalled submissions ago must have completed,
 // and a barrier-AND packet of another queue that names it must have passed, before it is re-armed
-int eager_take_signal(Eager& e, EagerQueue& q, int self) {
+int eager_take_signal(Eager& e, Direct& d, EagerQueue& q, int self) {
     Hsa& h = hsa();
     const int si = (int)(q.next % EAGER_SIGS);
     ++q.next;
-    if (h.signal_load(q.sigs[si]) != 0) h.signal_wait(q.sigs[si], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+    (void)wait_signal(d, q.sigs[si]);
     if (const unsigned users = q.dep_user[si]) {  // every queue whose barrier-AND packet names it must have consumed that packet
         q.dep_user[si] = 0;
         for (int k = 0; k < EAGER_Q; ++k)
-            if (((users >> k) & 1u) && k != self) eager_wait_queue(e, direct(), k);
+            if (((users >> k) & 1u) && k != self) eager_wait_queue(e, d, k);
     }
     eager_retire(q);
     h.signal_store_relaxed(q.sigs[si], 1);
@@ -605,15 +911,30 @@ bool conflicts(const EagerQueue& q, const Spans& rd, const Spans& wr) {
     return false;
 }
 
-void put_packet(hsa_queue_t* hq, const void* body64, uint16_t header, uint16_t setup) {
+// false: the ring stayed full until the time limit or the queue failed (the packet is NOT written; the path is marked failed)
+bool put_packet(Direct& d, hsa_queue_t* hq, const void* body64, uint16_t header, uint16_t setup) {
     Hsa& h = hsa();
+    if (d.failed.load()) return false;
     const uint64_t idx = h.add_write_index(hq, 1);
-    while (idx - h.load_read_index(hq) >= hq->size) {
+    if (idx - h.load_read_index(hq) >= hq->size) {  // ring full: spin briefly, then yield the core; bounded
+        const double t0 = now_s();
+        for (unsigned spins = 0; idx - h.load_read_index(hq) >= hq->size; ++spins) {
+            if (spins < 256) {
+                __builtin_ia32_pause();
+            } else {
+                sched_yield();
+                if ((spins & 63) == 0 && (d.failed.load() || now_s() - t0 > direct_timeout_s())) {
+                    direct_fail(d, "a hardware queue stayed full (the packet processor stopped consuming packets)");
+                    return false;
+                }
+            }
+        }
     }
     char* slot = (char*)hq->base_address + (idx & (hq->size - 1)) * 64;
     std::memcpy(slot + 4, (const char*)body64 + 4, 60);
     __atomic_store_n((uint32_t*)slot, (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
     h.signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)idx);
+    return true;
 }
 }  // namespace
 
@@ -621,16 +942,16 @@ void put_packet(hsa_queue_t* hq, const void* body64, uint16_t header, uint16_t s
 // SMR_EUNSUPPORTED when this execution has to go through HIP (the caller fences and launches normally).
 int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::vector<std::pair<uintptr_t, uintptr_t>>& rd,
                  const std::vector<std::pair<uintptr_t, uintptr_t>>& wr, hipStream_t s) {
-    Direct& d = direct();
+    const int dev = device_of(s);  // the stream's device, not the calling thread's current one
+    Direct& d = direct_of(dev);
     if (!d.ok) return SMR_EUNSUPPORTED;
     std::lock_guard<std::mutex> g(d.mu);
-    Eager& e = eager();
+    Eager& e = eager_of(dev);
     if (eager_init(d, e) != SMR_OK) return SMR_EUNSUPPORTED;
-    Hsa& h = hsa();
-    // a sequence replay still in flight on these queues (only with stream-side waits, $SMR_SEQ_STREAM_WAIT=1) comes first
+    // a sequence replay still in flight on these queues (asynchronous smr_seq_run) comes first
     for (int k = 0; k < SEQ_MAXQ; ++k)
         if (d.armed[k]) {
-            if (h.signal_load(d.done[k]) != 0) h.signal_wait(d.done[k], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
+            if (!wait_signal(d, d.done[k])) return SMR_EHIP;
             d.armed[k] = false;
         }
     // kernels first: anything that cannot be dispatched directly sends the whole execution through HIP
@@ -658,16 +979,17 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
         } else {
             rc = SMR_EUNSUPPORTED;
         }
-        const size_t hid = (l.args.size() + 7) & ~(size_t)7;
-        if (rc != SMR_OK || refs[j].private_size != 0 || std::max<size_t>(refs[j].kernarg_size, hid + 128) > EAGER_SLOT) {
+        KernargLayout lay;
+        if (rc != SMR_OK || refs[j].private_size != 0 || !kernarg_layout_of(refs[j], l.args.size(), lay) ||
+            std::max<size_t>(refs[j].kernarg_size, l.args.size()) > EAGER_SLOT) {
             ++e.n_fallback;
             return SMR_EUNSUPPORTED;
         }
     }
-    if (e.hip_pending) {  // copies the library queued on the stream through HIP come first
+    if (e.hip_pending.count(s)) {  // what the library queued on THIS stream through HIP (a copy, a fallback launch) comes first
         hipError_t he = hipStreamSynchronize(s);
         if (he != hipSuccess) return hip_error(he, "draining the stream before a direct launch");
-        e.hip_pending = false;
+        e.hip_pending.erase(s);
         e.sys_acquire = ~0u;
     }
     // which queue
@@ -700,7 +1022,7 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
         for (int i = 0; i < nconf; ++i)
             if (conf[i] != target) {
                 EagerQueue& o = e.q[conf[i]];
-                if (o.unsignaled > 0) (void)eager_marker(e, o, d.q[conf[i]], conf[i]);  // its last packet carries no signal: a marker behind it does
+                if (o.unsignaled > 0) (void)eager_marker(e, d, o, d.q[conf[i]], conf[i]);  // its last packet carries no signal: a marker behind it does
                 if (o.tail >= 0) {
                     bp.dep_signal[nd++] = o.sigs[o.tail];
                     o.dep_user[o.tail] |= (unsigned char)(1u << target);
@@ -708,7 +1030,7 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
             }
         const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                         (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
-        put_packet(hq, &bp, hdr, 0);
+        if (!put_packet(d, hq, &bp, hdr, 0)) return SMR_EHIP;
     }
     for (size_t j = 0; j < launches.size(); ++j) {
         const RecLaunch& l = launches[j];
@@ -717,21 +1039,22 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
         // 8th launch of a queue carries one (it retires its predecessors too; fences and cross-queue waits add a marker on demand);
         // with argument blocks in the per-launch ring slots every launch needs its own
         const bool want_sig = !e.arena || q.unsignaled >= 7;
-        const int si = want_sig ? eager_take_signal(e, q, target) : -1;
+        const int si = want_sig ? eager_take_signal(e, d, q, target) : -1;
+        if (d.failed.load()) return SMR_EHIP;
         // the argument block: a resident one when this plan's launch j was issued with these very bytes before (the hot loop of a
         // host program), else a fresh block -- in the arena when there is one (it becomes resident), in the launch's ring slot otherwise
         unsigned char* b = nullptr;
         bool fresh = true;
         if (e.arena) {
             for (Plan::ArgBlock& ab : plan.eager_args)
-                if (ab.launch == (int)j && ab.epoch == e.epoch && ab.bytes.size() == l.args.size() && std::memcmp(ab.bytes.data(), l.args.data(), l.args.size()) == 0) {
+                if (ab.launch == (int)j && ab.dev_index == dev && ab.epoch == e.epoch && ab.bytes.size() == l.args.size() && std::memcmp(ab.bytes.data(), l.args.data(), l.args.size()) == 0) {
                     b = (unsigned char*)ab.dev;
                     fresh = false;
                     ++e.n_arg_hits;
                     break;
                 }
             if (!b) {
-                const size_t need = (std::max<size_t>(refs[j].kernarg_size, ((l.args.size() + 7) & ~(size_t)7) + 128) + 255) & ~(size_t)255;
+                const size_t need = (std::max<size_t>(refs[j].kernarg_size, l.args.size()) + 255) & ~(size_t)255;
                 if (e.arena_used + need > e.arena_bytes) {  // start over: nothing in flight may still read an old block
                     for (int k = 0; k < EAGER_Q; ++k) eager_wait_queue(e, d, k);
                     e.arena_used = 0;
@@ -744,6 +1067,7 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
                 ab.launch = (int)j;
                 ab.bytes = l.args;
                 ab.dev = b;
+                ab.dev_index = dev;
                 ab.epoch = e.epoch;
                 plan.eager_args.push_back(std::move(ab));
             }
@@ -751,21 +1075,14 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
             b = q.kargs + (size_t)si * EAGER_SLOT;
         }
         if (fresh) {
-            std::memcpy(b, l.args.data(), l.args.size());
-            const size_t hid = (l.args.size() + 7) & ~(size_t)7;
-            if (refs[j].kernarg_size >= hid + 72) {
-                std::memset(b + hid, 0, std::min<size_t>(refs[j].kernarg_size - hid, 128));
-                uint32_t bc[3] = {l.grid, 1, 1};
-                uint16_t gs[6] = {(uint16_t)l.block, 1, 1, 0, 0, 0};
-                std::memcpy(b + hid, bc, 12);
-                std::memcpy(b + hid + 12, gs, 12);
-                uint16_t gd = 1;
-                std::memcpy(b + hid + 64, &gd, 2);
-                if (refs[j].kernarg_size >= hid + 124) {
-                    uint32_t dl = l.lds;
-                    std::memcpy(b + hid + 120, &dl, 4);
-                }
-            }
+            // explicit arguments, then the hidden ones at the offsets the code object's metadata names (block counts, group sizes,
+            // grid dims, dynamic LDS size); staged in host memory: the block itself may be device memory behind the BAR
+            KernargLayout lay;
+            (void)kernarg_layout_of(refs[j], l.args.size(), lay);
+            std::vector<unsigned char> img(std::max<size_t>(refs[j].kernarg_size, l.args.size()), 0);
+            std::memcpy(img.data(), l.args.data(), l.args.size());
+            if (img.size() >= (size_t)lay.kernarg_size) kmeta_fill_hidden(lay, img.data(), l.grid, l.block, l.lds);
+            std::memcpy(b, img.data(), img.size());
             if (e.kargs_device) {  // posted writes through the BAR: a read of the last byte written returns only after they have landed
                 const size_t used = std::max<size_t>(l.args.size(), refs[j].kernarg_size);
                 __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -786,7 +1103,7 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
         pk.completion_signal = si >= 0 ? q.sigs[si] : hsa_signal_t{0};
         // agent-scope fences like HIP's between kernels (the argument block is host-coherent memory, never cached in L2); the first
         // launch after a copy acquires at system scope
-        put_packet(hq, &pk, header_of(true, ((e.sys_acquire >> target) & 1u) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT), pk.setup);
+        if (!put_packet(d, hq, &pk, header_of(true, ((e.sys_acquire >> target) & 1u) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT), pk.setup)) return SMR_EHIP;
         e.sys_acquire &= ~(1u << target);
         Inflight f;
         f.sig = si;
@@ -802,29 +1119,69 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
     return SMR_OK;
 }
 
-// everything submitted directly has completed when this returns (host wait)
-void eager_fence_all() {
-    Direct& d = direct();
-    if (!d.ok) return;
-    std::lock_guard<std::mutex> g(d.mu);
-    Eager& e = eager();
-    if (!e.ready) return;
-    for (int k = 0; k < EAGER_Q; ++k) eager_wait_queue(e, d, k);
+// everything submitted directly -- on every device this process drove that way -- has completed when this returns (host wait).
+// SMR_OK, or SMR_EHIP when a device's direct path failed (now or earlier, reported once): its results are then undefined.
+// the replay in flight on this device's queues has completed when this returns SMR_OK (SMR_EHIP: the direct path failed)
+int wait_all(Direct& d) {
+    bool any = false;
+    int rc = SMR_OK;
+    for (int k = 0; k < SEQ_MAXQ; ++k)
+        if (d.armed[k]) {
+            if (rc == SMR_OK && !wait_signal(d, d.done[k])) rc = SMR_EHIP;
+            d.armed[k] = false;
+            any = true;
+        }
+    if (any && rc == SMR_OK) d.last_us = (now_s() - d.t_submit) * 1e6;
+    return rc;
 }
-void eager_note_hip_work() {
-    Direct& d = direct();
-    if (!d.ok) return;
-    std::lock_guard<std::mutex> g(d.mu);
-    eager().hip_pending = true;
+int eager_fence_all() {
+    int rc = SMR_OK;
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> g(g_direct_mu);
+        for (auto& kv : g_direct) devs.push_back(kv.first);
+    }
+    for (int dev : devs) {
+        Direct& d = direct_of(dev);
+        std::lock_guard<std::mutex> g(d.mu);
+        Eager& e = eager_of(dev);
+        const bool was_failed = d.failed.load();
+        if (e.ready)
+            for (int k = 0; k < EAGER_Q; ++k) eager_wait_queue(e, d, k);
+        (void)wait_all(d);  // a sequence replay submitted asynchronously (smr_seq_run) shares the queues
+        if (d.failed.load() && !(was_failed && e.fail_reported)) {
+            e.fail_reported = true;
+            rc = set_error(SMR_EHIP, "direct dispatch: " + (d.fail_why.empty() ? std::string("the HSA queue reported an error") : d.fail_why));
+        }
+    }
+    return rc;
 }
-void eager_request_sys_acquire() {  // device memory was written behind the queues' backs (a table upload by hipMemcpy)
-    Direct& d = direct();
+void eager_note_hip_work(hipStream_t s) {
+    const int dev = device_of(s);
+    Direct& d = direct_of(dev);
     if (!d.ok) return;
     std::lock_guard<std::mutex> g(d.mu);
-    eager().sys_acquire = ~0u;
+    eager_of(dev).hip_pending.insert(s);
+}
+void eager_forget_stream(hipStream_t s) {  // the stream is being destroyed (its handle may be reused)
+    for (int dev : eager_devices()) {
+        Direct& d = direct_of(dev);
+        std::lock_guard<std::mutex> g(d.mu);
+        eager_of(dev).hip_pending.erase(s);
+    }
+}
+void eager_request_sys_acquire(hipStream_t s) {  // device memory was written behind the queues' backs (a table upload by hipMemcpy)
+    const int dev = device_of(s);
+    Direct& d = direct_of(dev);
+    if (!d.ok) return;
+    std::lock_guard<std::mutex> g(d.mu);
+    eager_of(dev).sys_acquire = ~0u;
 }
 long eager_stat(int which) {
-    Eager& e = eager();
+    const int dev = current_device();
+    Direct& d = direct_of(dev);
+    std::lock_guard<std::mutex> g(d.mu);  // (the counters are written under the same lock)
+    Eager& e = eager_of(dev);
     switch (which) {
         case 0: return e.n_launch;
         case 1: return e.n_free;
@@ -836,14 +1193,14 @@ long eager_stat(int which) {
         default: return e.n_fallback;
     }
 }
-bool eager_available() { return direct().ok; }
+bool eager_available(hipStream_t s) { return direct_of(device_of(s)).ok; }
 // for paths that must not create the direct queues as a side effect (freeing memory, destroying plans)
-void eager_fence_if_active() {
+int eager_fence_if_active() {
     {
         std::lock_guard<std::mutex> g(g_direct_mu);
-        if (g_direct.empty()) return;
+        if (g_direct.empty()) return SMR_OK;
     }
-    if (eager().ready) eager_fence_all();
+    return eager_fence_all();
 }
 }  // namespace smr
 
@@ -858,6 +1215,8 @@ struct SeqItem {
 struct SeqPacket {
     hsa_kernel_dispatch_packet_t pk;  // header / completion signal filled in at replay
     bool barrier;
+    bool acquire;  // the launch reads bytes some launch of the sequence writes (read-after-write, accumulation, in-place update)
+    bool self_released;  // every store of the launch is written through and acknowledged before the kernel ends: no release fence needed
 };
 struct smr_seq {
     std::vector<SeqItem> items;
@@ -867,18 +1226,39 @@ struct smr_seq {
     std::vector<SeqPacket> packets[SEQ_MAXQ];  // one replay's packets, per hardware queue
     int nq = 0;                 // queues in use (= dependency components of the recorded list, at most max_queues)
     int max_queues = 4;         // measured: beyond 4 queues of its own a process is time-multiplexed by the hardware scheduler (6 queues: 6.0 -> 11.1 us per step)
-    int slices = 1;             // a component that is ONE independent-workgroup launch is cut into this many block ranges, one queue each
-                                // (off by default: 2 slices x 2 components = 4 queues bought 3.5 % on the bench step, profiles/r04_overlap.txt)
+    int slices = -1;            // a component that is ONE independent-workgroup launch is cut into this many block ranges, one queue each;
+                                // -1 (default): automatic, only the heaviest chain is cut (seq_build, step 3b); 1: never
+    std::map<int, int> comp_slices;  // "slices:<c>": block ranges of component c alone (asymmetric: only the long chain is cut)
     int nsliced = 0;            // components that were
     int ncomp = 0;
     void* d_kernargs = nullptr;
     std::vector<std::shared_ptr<void>> keep;  // runtime-compiled programs the packets name
     int64_t runs = 0;
-    int n_any = 0, n_barrier = 0;
-    int fence_scope_mid = 1;    // acquire / release scope of the packets inside a replay: 1 agent (default), 0 none, 2 system
+    int n_any = 0, n_barrier = 0, n_acquire = 0, n_self_released = 0;
+    // Fences of the packets INSIDE a replay (the first packet on a queue always acquires, the last always releases, at system scope).
+    //   acquire: -1 = by need (default): agent scope on a launch that reads bytes which some launch of the sequence WRITES -- a
+    //            read-after-write, a reduction accumulating into its destination, an in-place map -- and none on a launch whose
+    //            inputs nobody in the sequence writes: an acquire invalidates every XCD's L2, i.e. it throws away the read-only
+    //            inputs the next replay (and whatever runs concurrently on the other queues) would have hit there, and it is only
+    //            needed to observe another workgroup's writes.  0 none / 1 agent / 2 system force one scope (experiments).
+    //   release: 1 agent (default; the next writer of the same bytes may sit on another XCD: write-after-write needs the
+    //            write-back), 0 none (experiment: NOT safe in general), 2 system.
+    int acq_mid = -1, rel_mid = 1;
+    // Scope of a replay's FIRST acquire on every queue: -1 (default) = by the memory the sequence reads -- agent scope when every
+    // operand it reads lives in device-local memory of this GPU (hipMalloc): what an acquire has to do is drop THIS device's stale
+    // cache lines, and for local memory the agent-scope invalidate drops all of them, whoever wrote the new data (a DMA copy, the
+    // host through the BAR, a kernel of a peer device write to memory, not into these L2s; tests/test_gpu_round5.py replays after a
+    // DMA upload); system scope as soon as an operand is host memory (pinned, zero-copy) or managed, or its type cannot be told.
+    // Measured: the system-scope acquire costs a replay 6-7 us (profiles/r05_seq_fixed_cost.txt).  0 / 1 / 2 force a scope.
+    // The LAST release stays at system scope (default 2): measured no cheaper at agent scope.
+    int rel_self = 0;  // release scope of self-released launches' packets inside a replay: 0 none (default), 1 = like the others (experiment)
+    int acq_first = -1, rel_last = 2;
+    int acq_first_auto = 2;  // what -1 resolved to at build time
     bool all_ordered = false;   // experiment: every packet carries the barrier bit
     bool inflight = false;      // a replay was submitted and nobody waited for it yet
-    int device = -1;
+    int device = -1;            // the device the sequence was built for (its plans' tables and the kernarg blocks live there)
+    int async_mode = -1;        // smr_seq_run returns after the doorbells: -1 automatic (see smr_seq_run), 0 never (wait inside), 1 always
+    bool held = false;          // the last replay put a holding kernel on the caller's stream
 };
 
 namespace {
@@ -912,10 +1292,11 @@ int seq_build(smr_seq* q) {
     for (auto& v : q->packets) v.clear();
     q->keep.clear();
     q->aql = false;
-    q->n_any = q->n_barrier = 0;
+    q->n_any = q->n_barrier = q->n_acquire = q->n_self_released = 0;
     q->nq = 0;
     q->nsliced = 0;
-    Direct& d = direct();
+    q->device = current_device();  // the plans' tables are uploaded (prepare pass below) on the calling thread's device
+    Direct& d = direct_of(q->device);
     if (!d.ok) q->why_not_aql = d.why;
     // 1. record every launch of every item (tables uploaded / scratch allocated by a prepare pass first)
     struct Rec {
@@ -929,7 +1310,7 @@ int seq_build(smr_seq* q) {
         SeqItem& it = q->items[i];
         int rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, nullptr, true);
         if (rc) return rc;
-        set_recorder(&recs[i].launches);
+        set_recorder(&recs[i].launches, true);
         rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, nullptr, false);
         set_recorder(nullptr);
         if (rc) return rc;
@@ -959,6 +1340,12 @@ int seq_build(smr_seq* q) {
             if (k.private_size != 0) {
                 aql = false;
                 q->why_not_aql = "a kernel needs scratch memory: " + k.name;
+                break;
+            }
+            KernargLayout lay;
+            if (!kernarg_layout_of(k, l.args.size(), lay)) {
+                aql = false;
+                q->why_not_aql = "the recorded arguments of " + k.name + " do not match the kernarg layout in its code object's metadata";
                 break;
             }
             refs[i].push_back(k);
@@ -1004,14 +1391,55 @@ int seq_build(smr_seq* q) {
     //     _mapreduce_threaded! (src/mapreduce.jl:195-227: the box is bisected and the halves run as concurrent tasks): while one
     //     slice drains and releases, the next replay's other slice is already running.
     std::vector<int> cslices(ncomp, 1);
-    if (q->slices > 1 && ncomp * q->slices <= maxq)
-        for (int c = 0; c < ncomp; ++c) {
+    {
+        auto sliceable = [&](int c, int ns) {
             const Rec& r = recs[cfirst[c]];
-            if (csize[c] == 1 && r.launches.size() == 1 && r.launches[0].slice_kind != 0 && r.launches[0].grid >= (unsigned)(64 * q->slices)) {
-                cslices[c] = q->slices;
-                ++q->nsliced;
+            return ns > 1 && csize[c] == 1 && r.launches.size() == 1 && r.launches[0].slice_kind != 0 && r.launches[0].grid >= (unsigned)(64 * ns);
+        };
+        std::vector<int> want(ncomp, 1);
+        for (int c = 0; c < ncomp; ++c) {
+            auto it = q->comp_slices.find(c);
+            const int ns = it != q->comp_slices.end() ? it->second : std::max(1, q->slices);
+            if (sliceable(c, ns)) want[c] = ns;
+        }
+        // automatic ("slices" = -1, the default): with fewer components than 3 queues, the HEAVIEST single-launch component -- by the
+        // bytes its operands span, every view counted: the 4-way sum reads its buffer through four views -- is cut in two when it
+        // outweighs the lightest chain by half or more.  Measured on the bench step (profiles/r05_fence_ab.txt): perm | sum/2 | sum/2
+        // 5.44 us per step against 5.96 on two queues; cutting the light chain instead, or every chain, or the heavy one in three:
+        // 5.77-5.95 (every additional packet is one more release, i.e. one more write-back of all eight L2s).
+        if (q->slices < 0 && q->comp_slices.empty() && ncomp >= 2 && ncomp + 1 <= std::min(maxq, 3)) {
+            int heavy = -1;
+            size_t lightest = (size_t)-1;
+            for (int c = 0; c < ncomp; ++c) {
+                lightest = std::min(lightest, cbytes[c]);
+                if (sliceable(c, 2) && (heavy < 0 || cbytes[c] > cbytes[heavy])) heavy = c;
+            }
+            if (heavy >= 0 && cbytes[heavy] * 2 >= lightest * 3) want[heavy] = 2;
+            // ... and when every launch of the sequence is self-released (write-through stores, no release fence on its packet) a
+            // further packet costs no write-back: every chain that can be cut is cut in two, up to four queues (measured 4.6 us per
+            // step on four queues against 5.1 on three and 5.3 on two, profiles/r05_store_mode_ab.txt)
+            bool all_self = true;
+            for (size_t i = 0; i < ni; ++i)
+                for (const RecLaunch& l : recs[i].launches) all_self = all_self && l.self_released;
+            if (all_self) {
+                int total2 = 0;
+                std::vector<int> w2(ncomp, 1);
+                for (int c = 0; c < ncomp; ++c) {
+                    w2[c] = sliceable(c, 2) ? 2 : 1;
+                    total2 += w2[c];
+                }
+                if (total2 <= std::min(maxq, 4)) want = w2;
             }
         }
+        int total = 0;
+        for (int c = 0; c < ncomp; ++c) total += want[c];
+        if (total <= maxq)  // every component keeps at least one queue of its own; otherwise nothing is cut
+            for (int c = 0; c < ncomp; ++c)
+                if (want[c] > 1) {
+                    cslices[c] = want[c];
+                    ++q->nsliced;
+                }
+    }
     // queues: sliced components own cslices[c] queues each; the others share what is left, longest-processing-time first
     std::vector<int> cqueue(ncomp, 0);
     int nextq = 0;
@@ -1085,19 +1513,11 @@ int seq_build(smr_seq* q) {
                     v += (uint64_t)lo * l.slice_row;
                     std::memcpy(b + l.slice_off, &v, 8);
                 }
-                const size_t hid = (l.args.size() + 7) & ~(size_t)7;
-                if (refs[i][j].kernarg_size >= hid + 72) {  // hidden_block_count_[xyz], hidden_group_size_[xyz], remainders, global offsets, grid dims
-                    uint32_t bc[3] = {hi - lo, 1, 1};
-                    uint16_t gs[6] = {(uint16_t)l.block, 1, 1, 0, 0, 0};
-                    std::memcpy(b + hid, bc, 12);
-                    std::memcpy(b + hid + 12, gs, 12);
-                    uint16_t gd = 1;
-                    std::memcpy(b + hid + 64, &gd, 2);
-                    if (refs[i][j].kernarg_size >= hid + 124) {
-                        uint32_t dl = l.lds;
-                        std::memcpy(b + hid + 120, &dl, 4);  // hidden_dynamic_lds_size
-                    }
-                }
+                // the hidden arguments (block counts = this slice's, group sizes, grid dims, dynamic LDS size) at the offsets the code
+                // object's metadata names
+                KernargLayout lay;
+                (void)kernarg_layout_of(refs[i][j], l.args.size(), lay);
+                if (blocksize(i, j) >= (size_t)lay.kernarg_size) kmeta_fill_hidden(lay, b, hi - lo, l.block, l.lds);
             }
         }
     if (q->d_kernargs) (void)hipFree(q->d_kernargs);
@@ -1109,6 +1529,26 @@ int seq_build(smr_seq* q) {
     // 5. packets + ordering inside each queue: a launch that conflicts with none of the launches since the queue's last ordered one
     //    goes out without the barrier bit.  The decisions are those of the SECOND of two simulated replays (steady state: the first
     //    launch of a replay is judged against the tail of the previous replay on the same queue).
+    // which executions read something the sequence writes (their packets acquire; everything else reads only data that is constant
+    // for the whole replay and was made visible by the first packet's system-scope acquire)
+    std::vector<char> raw(ni, 0);
+    for (size_t i = 0; i < ni; ++i)
+        for (size_t j = 0; j < ni && !raw[i]; ++j)
+            if (overlaps(recs[j].wr, recs[i].rd)) raw[i] = 1;
+    // where the memory the sequence READS lives (first acquire: see smr_seq::acq_first)
+    q->acq_first_auto = HSA_FENCE_SCOPE_AGENT;
+    for (size_t i = 0; i < ni && q->acq_first_auto == HSA_FENCE_SCOPE_AGENT; ++i)
+        for (const auto& x : recs[i].rd) {
+            hipPointerAttribute_t at;
+            std::memset(&at, 0, sizeof at);
+            const bool local = x.second > x.first && hipPointerGetAttributes(&at, (const void*)x.first) == hipSuccess && at.type == hipMemoryTypeDevice &&
+                               !at.isManaged && at.device == q->device;
+            if (!local) {
+                (void)hipGetLastError();
+                q->acq_first_auto = HSA_FENCE_SCOPE_SYSTEM;
+                break;
+            }
+        }
     for (int k = 0; k < nq; ++k) {
         Spans wrd, wwr;
         for (int pass = 0; pass < 2; ++pass)
@@ -1133,7 +1573,11 @@ int seq_build(smr_seq* q) {
                     SeqPacket sp;
                     std::memset(&sp, 0, sizeof sp);
                     sp.barrier = j > 0 || !free_;  // later launches of one execution (folding passes) depend on the first
+                    sp.acquire = j > 0 || raw[i] != 0;  // ... and read its partials
+                    sp.self_released = l.self_released;
+                    if (sp.self_released) ++q->n_self_released;
                     (sp.barrier ? q->n_barrier : q->n_any)++;
+                    if (sp.acquire) ++q->n_acquire;
                     sp.pk.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
                     sp.pk.workgroup_size_x = (uint16_t)l.block;
                     sp.pk.workgroup_size_y = 1;
@@ -1155,7 +1599,7 @@ int seq_build(smr_seq* q) {
 // writes `reps` replays into the rings; the last packet on every queue signals that queue's d.done
 int seq_submit(smr_seq* q, Direct& d, int reps) {
     Hsa& h = hsa();
-    const int mid = q->fence_scope_mid;
+    const int acq_mid = q->acq_mid, rel_mid = q->rel_mid;
     uint64_t written[SEQ_MAXQ] = {}, totalp[SEQ_MAXQ] = {};
     int open_queues = 0;
     for (int k = 0; k < q->nq; ++k) {
@@ -1167,7 +1611,17 @@ int seq_submit(smr_seq* q, Direct& d, int reps) {
         }
     }
     d.t_submit = now_s();
+    unsigned idle_rounds = 0;
     while (open_queues > 0) {
+        // every ring full (the replay is longer than the rings: the packet processor has to catch up): spin briefly, then yield; bounded
+        if (++idle_rounds > 64) {
+            if (idle_rounds < 1024) __builtin_ia32_pause();
+            else sched_yield();
+            if ((idle_rounds & 1023) == 0 && (d.failed.load() || now_s() - d.t_submit > direct_timeout_s())) {
+                direct_fail(d, "the hardware queues stopped consuming packets during a replay");
+                return SMR_EHIP;
+            }
+        }
         for (int k = 0; k < q->nq; ++k) {
             if (written[k] >= totalp[k]) continue;
             hsa_queue_t* hq = d.q[k];
@@ -1188,10 +1642,15 @@ int seq_submit(smr_seq* q, Direct& d, int reps) {
                 pk.completion_signal = last ? d.done[k] : hsa_signal_t{0};
                 // body first, header last (release): the packet processor owns the slot once the header is valid
                 std::memcpy((char*)slot + 4, (const char*)&pk + 4, sizeof pk - 4);
-                const uint16_t hdr = header_of(sp.barrier || first, first ? HSA_FENCE_SCOPE_SYSTEM : mid, last ? HSA_FENCE_SCOPE_SYSTEM : mid);
+                const int acq = acq_mid >= 0 ? acq_mid : (sp.acquire ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
+                // release: the last packet on a queue at system scope; inside the replay agent scope -- none for a self-released
+                // launch (its stores were written through and acknowledged before it ended: nothing is dirty in an L2)
+                const int rel = (sp.self_released && q->rel_self == 0) ? HSA_FENCE_SCOPE_NONE : rel_mid;
+                const uint16_t hdr = header_of(sp.barrier || first, first ? (q->acq_first >= 0 ? q->acq_first : q->acq_first_auto) : acq, last ? q->rel_last : rel);
                 __atomic_store_n((uint32_t*)slot, (uint32_t)hdr | ((uint32_t)pk.setup << 16), __ATOMIC_RELEASE);
             }
             h.signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)(base + nthis - 1));
+            idle_rounds = 0;
             written[k] += nthis;
             if (written[k] >= totalp[k]) --open_queues;
         }
@@ -1199,16 +1658,27 @@ int seq_submit(smr_seq* q, Direct& d, int reps) {
     return SMR_OK;
 }
 
-void wait_all(Direct& d) {
-    Hsa& h = hsa();
-    bool any = false;
-    for (int k = 0; k < SEQ_MAXQ; ++k)
-        if (d.armed[k]) {
-            if (h.signal_load(d.done[k]) != 0) h.signal_wait(d.done[k], HSA_SIGNAL_CONDITION_EQ, 0, UINT64_MAX, HSA_WAIT_STATE_ACTIVE);
-            d.armed[k] = false;
-            any = true;
+// the holding kernel's view of the completion signals (device-visible host memory, one block per device, made on first use)
+struct HoldBlock {
+    const volatile long long** sigs = nullptr;  // [SEQ_MAXQ]
+    unsigned* gave_up = nullptr;
+};
+HoldBlock* hold_block(Direct& d) {
+    static std::mutex mu;
+    static std::map<int, HoldBlock> all;
+    std::lock_guard<std::mutex> g(mu);
+    HoldBlock& hb = all[d.dev];
+    if (!hb.sigs) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
         }
-    if (any) d.last_us = (now_s() - d.t_submit) * 1e6;
+        std::memset(p, 0, 256);
+        hb.sigs = (const volatile long long**)p;
+        hb.gave_up = (unsigned*)((char*)p + 128);
+    }
+    return &hb;
 }
 }  // namespace
 
@@ -1242,6 +1712,11 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
         int rc = seq_build(q);
         if (rc) return rc;
     }
+    if (q->aql && device_of(s) != q->device) return set_error(SMR_EINVAL, "smr_seq_run: the stream belongs to another device than the one the sequence was built on");
+    if (q->aql && !direct_of(q->device).ok) {  // the direct path failed after the sequence was built: from now on through HIP
+        q->aql = false;
+        q->why_not_aql = direct_of(q->device).why;
+    }
     if (!q->aql) {  // HIP path: the same launches, in order on the caller's stream
         for (int r = 0; r < reps; ++r)
             for (SeqItem& it : q->items) {
@@ -1251,12 +1726,11 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
         ++q->runs;
         return SMR_OK;
     }
-    Direct& d = direct();
-    eager_fence_all();  // launches a library-owned stream submitted directly share these queues: they come first
+    Direct& d = direct_of(q->device);
+    if (int rc = eager_fence_all()) return rc;  // launches a library-owned stream submitted directly share these queues: they come first
     std::lock_guard<std::mutex> g(d.mu);
-    Hsa& h = hsa();
     // the previous replay on these queues must have completed before the completion signals are re-armed
-    wait_all(d);
+    if (int rc = wait_all(d)) return rc;
     // whatever the caller queued on `stream` before comes first
     hipError_t e = hipStreamQuery(s);
     if (e == hipErrorNotReady) e = hipStreamSynchronize(s);
@@ -1264,8 +1738,22 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
     int rc = seq_submit(q, d, reps);
     if (rc) return rc;
     q->inflight = true;
+    q->held = false;
     ++q->runs;
-    // ... and whatever the caller queues on `stream` afterwards comes last
+    // ... and whatever is queued on `stream` afterwards comes last.  The call returns as soon as the doorbells are rung (the reference's
+    // @spawn returns at once and `wait` is separate, src/mapreduce.jl:214-223); what keeps later work on `stream` behind the replay:
+    //   * a library-owned stream (smr_stream_create): nothing -- all its work goes through this library, which waits for the replay
+    //     before anything it submits or does on the stream (eager_submit, the fences in smr_api.cpp);
+    //   * a HIP stream: hipStreamWaitValue64 on the completion signals where the device supports it ($SMR_SEQ_STREAM_WAIT=1),
+    //     otherwise a one-wave holding kernel on the stream that polls the signals (k_seq_hold; bounded).
+    // "async" = 0 restores the blocking call; smr_seq_wait is the host-side wait in every mode.
+    const bool owned = seq_stream_is_owned(s);
+    if (q->async_mode == 0) {
+        rc = wait_all(d);
+        q->inflight = false;
+        return rc;
+    }
+    if (owned) return SMR_OK;
     if (d.wait_value_ok) {
         e = hipSuccess;
         for (int k = 0; k < q->nq && e == hipSuccess; ++k)
@@ -1274,22 +1762,47 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
         (void)hipGetLastError();
         d.wait_value_ok = false;
     }
-    wait_all(d);  // no stream-side wait on this system: block here
+    HoldBlock* hb = hold_block(d);
+    int n = 0;
+    if (hb)
+        for (int k = 0; k < q->nq; ++k)
+            if (d.armed[k] && d.done_ptr[k]) hb->sigs[n++] = (const volatile long long*)d.done_ptr[k];
+    bool all_have_ptr = hb != nullptr;
+    for (int k = 0; k < q->nq; ++k)
+        if (d.armed[k] && !d.done_ptr[k]) all_have_ptr = false;
+    if (all_have_ptr && n > 0) {
+        (void)hipGetLastError();
+        // 100 MHz device clock: the limit in ticks
+        const unsigned long long limit = (unsigned long long)(direct_timeout_s() * 1e8);
+        hipLaunchKernelGGL(k_seq_hold, dim3(1), dim3(64), 0, s, (const volatile long long* const*)hb->sigs, n, limit, hb->gave_up);
+        if (hipGetLastError() == hipSuccess) {
+            q->held = true;
+            return SMR_OK;
+        }
+    }
+    rc = wait_all(d);  // no way to hold the stream back: block here
     q->inflight = false;
-    (void)h;
-    return SMR_OK;
+    return rc;
 }
 
 int smr_seq_wait(smr_seq* q) {
     if (!q) return set_error(SMR_EINVAL, "null sequence");
     if (!q->aql || !q->inflight) return SMR_OK;
-    Direct& d = direct();
+    Direct& d = direct_of(q->device);
+    int rc;
     {
         std::lock_guard<std::mutex> g(d.mu);
-        wait_all(d);
+        rc = wait_all(d);
     }
     q->inflight = false;
-    return SMR_OK;
+    if (rc == SMR_OK && q->held) {
+        HoldBlock* hb = hold_block(d);
+        if (hb && __atomic_load_n(hb->gave_up, __ATOMIC_RELAXED)) {
+            __atomic_store_n(hb->gave_up, 0u, __ATOMIC_RELAXED);
+            rc = set_error(SMR_EHIP, "smr_seq: the holding kernel on the caller's stream gave up before the replay completed");
+        }
+    }
+    return rc;
 }
 
 int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
@@ -1301,9 +1814,12 @@ int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
     if (q->aql) {
         size_t np = 0;
         for (const auto& v : q->packets) np += v.size();
-        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d sliced=%d queues=%d ordered=%d unordered=%d fence_mid=%d stream_wait=%s last_replay_us=%.3f",
-                      q->items.size(), np, q->ncomp, q->nsliced, q->nq, q->n_barrier, q->n_any, q->fence_scope_mid, direct().wait_value_ok ? "hipStreamWaitValue64" : "host",
-                      direct().last_us);
+        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d sliced=%d queues=%d ordered=%d unordered=%d acquire=%s(%d of %zu packets) first_acquire=%s release=%d self_released=%d kernarg_layout=%s stream_wait=%s last_replay_us=%.3f",
+                      q->items.size(), np, q->ncomp, q->nsliced, q->nq, q->n_barrier, q->n_any, q->acq_mid < 0 ? "by-need" : (q->acq_mid == 0 ? "none" : (q->acq_mid == 1 ? "agent" : "system")),
+                      q->n_acquire, np, (q->acq_first >= 0 ? q->acq_first : q->acq_first_auto) == 2 ? "system" : ((q->acq_first >= 0 ? q->acq_first : q->acq_first_auto) == 1 ? "agent" : "none"),
+                      q->rel_mid, q->n_self_released, layout_source(direct_of(q->device)),
+                      q->async_mode == 0 ? "host(blocking)" : (direct_of(q->device).wait_value_ok ? "hipStreamWaitValue64" : "holding-kernel|owned-stream"),
+                      direct_of(q->device).last_us);
     }
     else
         std::snprintf(buf, buflen, "backend=hip items=%zu (%s)", q->items.size(), q->why_not_aql.c_str());
@@ -1325,8 +1841,32 @@ int smr_seq_components(smr_seq* q, int32_t* comp, size_t cap) {
 
 int smr_seq_set(smr_seq* q, const char* name, int64_t value) {
     if (!q || !name) return set_error(SMR_EINVAL, "null argument");
-    if (std::strcmp(name, "fence_scope") == 0 && value >= 0 && value <= 2) {
-        q->fence_scope_mid = (int)value;
+    if (std::strcmp(name, "fence_scope") == 0 && value >= 0 && value <= 2) {  // both fences of every inner packet at one scope
+        q->acq_mid = q->rel_mid = (int)value;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "acquire") == 0 && value >= -1 && value <= 2) {
+        q->acq_mid = (int)value;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "release") == 0 && value >= 0 && value <= 2) {
+        q->rel_mid = (int)value;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "release_self") == 0 && value >= 0 && value <= 1) {
+        q->rel_self = (int)value;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "first_acquire") == 0 && value >= -1 && value <= 2) {
+        q->acq_first = (int)value;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "last_release") == 0 && value >= 0 && value <= 2) {
+        q->rel_last = (int)value;
+        return SMR_OK;
+    }
+    if (std::strcmp(name, "async") == 0 && value >= -1 && value <= 1) {
+        q->async_mode = (int)value;
         return SMR_OK;
     }
     if (q->inflight) return set_error(SMR_EINVAL, "smr_seq_set: a replay is in flight (smr_seq_wait first)");
@@ -1340,8 +1880,17 @@ int smr_seq_set(smr_seq* q, const char* name, int64_t value) {
         q->built = false;
         return SMR_OK;
     }
-    if (std::strcmp(name, "slices") == 0 && value >= 1 && value <= SEQ_MAXQ) {  // block ranges per single-launch component
+    if (std::strcmp(name, "slices") == 0 && (value == -1 || (value >= 1 && value <= SEQ_MAXQ))) {  // block ranges per single-launch component (-1: automatic)
         q->slices = (int)value;
+        q->comp_slices.clear();
+        q->built = false;
+        return SMR_OK;
+    }
+    if (std::strncmp(name, "slices:", 7) == 0 && value >= 1 && value <= SEQ_MAXQ) {  // ... of component <c> alone (numbered by first appearance)
+        char* end = nullptr;
+        const long c = std::strtol(name + 7, &end, 10);
+        if (end == name + 7 || *end || c < 0 || c > 4096) return set_error(SMR_EINVAL, "smr_seq_set: slices:<component>");
+        q->comp_slices[(int)c] = (int)value;
         q->built = false;
         return SMR_OK;
     }

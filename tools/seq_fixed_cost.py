@@ -30,22 +30,37 @@ def main():
     torch.cuda.synchronize()
     print("perf_counter pair                      : %7.2f us" % best(lambda: None))
     print("torch.cuda.synchronize(), idle device  : %7.2f us" % best(torch.cuda.synchronize))
-    for queues in (4, 1):
+    st = S.Stream()  # library-owned: smr_seq_run returns after the doorbells, no holding kernel on a HIP stream
+    variants = [("default (3 queues: perm | sum/2 | sum/2, acquire by need)", {}),
+                ("... first acquire at agent scope (experiment)", {"first_acquire": 1}),
+                ("... last release at agent scope (experiment)", {"last_release": 1}),
+                ("... both (experiment)", {"first_acquire": 1, "last_release": 1}),
+                ("2 queues, r04 fences", {"queues": 2, "slices": 1, "acquire": 1}),
+                ("1 queue", {"queues": 1})]
+    for name, opts in variants:
         q = S.Sequence().add(p2).add(p3)
-        q.set("queues", queues)
-        q.run(5, cur()); q.wait()
-        print("queues=%d | %s" % (queues, q.info()))
+        for k, v in opts.items():
+            q.set(k, v)
+        q.run(5, st.handle); q.wait()
+        print("%s | %s" % (name, q.info()))
         for K in (1, 2, 5, 10, 20, 50, 100, 500, 2000):
             def region():
-                q.run(K, cur()); q.wait()
+                q.run(K, st.handle); q.wait()
             w = best(region, 15)
             lib = float(q.info().split("last_replay_us=")[1])
 
             def bracketed():
-                q.run(K, cur()); q.wait(); torch.cuda.synchronize()
+                q.run(K, st.handle); q.wait(); torch.cuda.synchronize()
             wb = best(bracketed, 15)
-            print("  K=%5d  run+wait %9.2f us (%7.3f /step) | library doorbell->done %9.2f us | + torch.cuda.synchronize %9.2f us (%7.3f /step)"
-                  % (K, w, w / K, lib, wb, wb / K))
+
+            def run_only():
+                q.run(K, st.handle)
+            tr = 1e30
+            for _ in range(10):
+                t = pc(); q.run(K, st.handle); tr = min(tr, pc() - t); q.wait()
+            print("  K=%5d  run+wait %9.2f us (%7.3f /step) | run() alone returns after %6.2f us | library doorbell->done %9.2f us | + torch.cuda.synchronize %9.2f us (%7.3f /step)"
+                  % (K, w, w / K, tr * 1e6, lib, wb, wb / K))
+        del q
     # the graph form of r3 for comparison
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
