@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--extras", default="all", help="comma-separated subset of the secondary workloads: c1,hbm128,cold,c5,c4 (default: all)")
     ap.add_argument("--step-mode", choices=("seq", "seq1", "inorder", "chains"), default="seq",
                     help="seq: the library's own replay of the recorded step (smr_seq: AQL packets on its HSA queues, one queue per "
                          "dependency component -- the step's two operations are independent, both only read A -- results of in-order "
@@ -258,12 +259,19 @@ def main():
     import torch
     import strided_jl_amd as S
 
+    # Rendezvous: torch.distributed over RCCL ("nccl").  With $SMR_RCCL_LIB set -- the library's collective is then a stand-in
+    # (tests/libfake_rccl.so: N processes sharing ONE GPU) -- the ranks meet over gloo instead and all land on the devices there are:
+    # the rehearsal of the whole N-rank bench path (launcher, communicator, sharded config 4, JSON assembly) on a one-GPU box.
+    rehearsal = bool(os.environ.get("SMR_RCCL_LIB"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
+    ndev = max(1, torch.cuda.device_count())
+    local = local % ndev if rehearsal else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    red_dev = torch.device("cpu") if rehearsal else dev   # where the ranks' scalars are reduced (gloo: host tensors)
 
     def barrier():
         if world > 1:
@@ -361,7 +369,7 @@ def main():
         # (absent when the sequence replays through HIP: under a profiler, or with a kernel that needs scratch)
         replay_us = float(seq_info.split("last_replay_us=")[1].split()[0]) if "last_replay_us=" in seq_info else None
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     value = world * K * (bytes2 + bytes3) / dt / 1e9
@@ -460,7 +468,8 @@ def main():
     extra = {}
     if not args.no_extra:
         try:
-            extra = secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur)
+            extra = secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur,
+                              only=None if args.extras == "all" else set(args.extras.split(",")), red_dev=red_dev)
         except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
             extra = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
@@ -473,6 +482,8 @@ def main():
             "ms_per_step_replay": round(replay_us / K * 1e-3, 6) if (use_seq and replay_us is not None) else None,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rehearsal": ("$SMR_RCCL_LIB is set: %d ranks over gloo sharing %d GPU(s), the collective is a stand-in -- a rehearsal of the N-rank "
+                          "path, not a measurement" % (world, ndev)) if rehearsal else None,
             "config": {"workload": "configs[1]+configs[2]: permutedims!(B,A,(4,3,2,1)) then C .= sum of 4 permuted views of A (a third array C), "
                                    "32x32x32x32 Float64, one set of arrays (A, B, C) per GPU",
                        "algorithmic_bytes_per_step": bytes2 + bytes3,
@@ -498,10 +509,14 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur):
+def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur, only=None, red_dev=None):
     """The other BASELINE.json configs, short runs (not the headline value)."""
     res = {}
     fn = S.fn
+    red_dev = red_dev or dev
+
+    def want(name):
+        return only is None or name in only
 
     def timed(plan, reps=50):
         g = graph_of(torch, lambda: plan.execute(cur()), reps)
@@ -515,122 +530,145 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
         res[name] = {"us": round(ms * 1e3, 2), "GB/s": round(b / (ms * 1e-3) / 1e9, 1),
                      "frac_of_8TBs": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan": plan.describe()}
 
-    # C1 symmetrise 4000^2 f64
-    m = 4000
-    tA = torch.randn(m * m, dtype=torch.float64, device=dev)
-    tB = torch.empty_like(tA)
-    A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
-    p = S.make_plan(lambda x, y: (x + y) / 2, None, None, (m, m), (B, A, A.adjoint()))
-    rec("c1_symmetrise_4000_f64", p, timed(p))
-    # true-HBM variant of the headline: 128^4 f64 (2 GiB in, 2 GiB out)
-    n = 128
-    tA = torch.randn(n ** 4, dtype=torch.float64, device=dev)
-    tB = torch.empty_like(tA)
-    A, B = colmajor_view(S, tA, (n,) * 4), colmajor_view(S, tB, (n,) * 4)
-    p = S.make_plan(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))))
-    rec("permutedims_128^4_f64", p, timed(p, 5))
     perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
-    p = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (B,) + tuple(A.permutedims(q) for q in perms))
-    rec("broadcast4_128^4_f64", p, timed(p, 5))
-    del tA, tB
-    # "cold" variant of the headline kernels: rotate through 40 distinct (A, B) pairs =
-    # 640 MiB > the 256 MiB Infinity Cache, so every launch really reads HBM
-    n, npair = 32, 40
-    poolA = torch.randn(npair, n ** 4, dtype=torch.float64, device=dev)
-    poolB = torch.empty_like(poolA)
-    A, B = colmajor_view(S, poolA[0], (n,) * 4), colmajor_view(S, poolB[0], (n,) * 4)
-    esz = poolA.element_size() * n ** 4
-    for name, f, srcs in (("permutedims_32^4_f64_cold", lambda x: x, (A.permutedims((3, 2, 1, 0)),)),
-                          ("broadcast4_32^4_f64_cold", lambda a, b, c, d: a + b + c + d, tuple(A.permutedims(q) for q in perms))):
-        p = S.make_plan(f, None, None, A.size, (B,) + srcs)
-        p.execute(cur())
-        state = {"i": 0}
 
-        def rot():
-            i = state["i"] % npair
-            state["i"] += 1
-            p.execute(cur(), bases=[poolB.data_ptr() + i * esz] + [poolA.data_ptr() + i * esz] * len(srcs))
+    def sec_c1():
+        # C1 symmetrise 4000^2 f64
+        m = 4000
+        tA = torch.randn(m * m, dtype=torch.float64, device=dev)
+        tB = torch.empty_like(tA)
+        A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
+        p = S.make_plan(lambda x, y: (x + y) / 2, None, None, (m, m), (B, A, A.adjoint()))
+        rec("c1_symmetrise_4000_f64", p, timed(p))
 
-        g = graph_of(torch, rot, 4 * npair)
-        g.replay()
-        torch.cuda.synchronize()
-        rec(name, p, min(event_time_ms(torch, g.replay, 2) for _ in range(3)) / (4 * npair))
-        # the same 40 INDEPENDENT launches as a recorded sequence on two hardware queues (the boundary of one launch overlaps the next
-        # pair's kernel; two queues measured best, profiles/r04_seq_vs_eager.txt): wall clock around smr_seq_run + smr_seq_wait
-        q = S.Sequence()
-        for i in range(npair):
-            q.add(p, bases=[poolB.data_ptr() + i * esz] + [poolA.data_ptr() + i * esz] * len(srcs))
-        q.set("queues", 2)
-        q.set("async", 0)
-        q.run(2, cur()); q.wait()
-        best = 1e30
-        for _ in range(5):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            q.run(8, cur()); q.wait()
-            best = min(best, time.perf_counter() - t0)
-        rec(name + "_seq_2_queues", p, best / (8 * npair) * 1e3)
-        del q
-    del poolA, poolB
-    # C5 compute-bound map 8192^2 f32
-    m = 8192
-    tA = torch.rand(m * m, dtype=torch.float32, device=dev)
-    tB = torch.empty_like(tA)
-    A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
-    p = S.make_plan(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, (m, m), (B, A))
-    rec("c5_expr_8192_f32", p, timed(p, 20))
-    # C4 mapreduce(abs2,+) 4096x4096x64 f32, block-partitioned over the ranks on dim 3 (every rank holds ONLY its
-    # slab), executed through the library's own multi-GPU entry point: smr_shard_ex -> local kernel ->
-    # gather -> ONE ncclAllReduce (RCCL over xGMI, csrc/smr_comm.cpp) -> scatter
-    from strided_jl_amd import distributed as D
-    slab = 64 // world if 64 % world == 0 else 64
-    tA = (torch.rand(4096 * 4096 * slab, dtype=torch.float32, device=dev) * 2 - 1)
-    out = torch.zeros(1, dtype=torch.float32, device=dev)
-    dims = (4096, 4096, 64 if world > 1 and slab * world == 64 else slab)
-    A = S.StridedView(tA, dims, (1, 4096, 4096 * 4096), 0)  # logical box over the slab's memory
-    O = S.StridedView(out, dims, (0, 0, 0), 0)
-    sharded = world > 1 and slab * world == 64
-    if sharded:
-        import torch.distributed as dist
-        uid = [D.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        D.comm_init(world, rank, uid[0])
-        rccl_rank, rccl_ranks = D.comm_rank()
-        assert (rccl_rank, rccl_ranks) == (rank, world), "RCCL communicator disagrees with the launcher"
+    def sec_hbm128():
+        # true-HBM variant of the headline: 128^4 f64 (2 GiB in, 2 GiB out)
+        n = 128
+        tA = torch.randn(n ** 4, dtype=torch.float64, device=dev)
+        tB = torch.empty_like(tA)
+        A, B = colmajor_view(S, tA, (n,) * 4), colmajor_view(S, tB, (n,) * 4)
+        p = S.make_plan(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))))
+        rec("permutedims_128^4_f64", p, timed(p, 5))
+        perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+        p = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (B,) + tuple(A.permutedims(q) for q in perms))
+        rec("broadcast4_128^4_f64", p, timed(p, 5))
+        del tA, tB
 
-        def c4():
-            out.zero_()
-            D.comm_mapreduce_sharded_(fn.abs2, "+", None, dims, (O, A), local=(False, True))
-        desc = "smr_mapreduce_sharded_ex (C ABI): shards=%d, slab-local input, ncclAllReduce(1 x f32)" % world
-    else:
-        p = S.make_plan(fn.abs2, "+", None, dims, (O, A))
-
-        def c4():
-            out.zero_()
+    def sec_cold():
+        # "cold" variant of the headline kernels: rotate through 40 distinct (A, B) pairs =
+        # 640 MiB > the 256 MiB Infinity Cache, so every launch really reads HBM
+        n, npair = 32, 40
+        poolA = torch.randn(npair, n ** 4, dtype=torch.float64, device=dev)
+        poolB = torch.empty_like(poolA)
+        A, B = colmajor_view(S, poolA[0], (n,) * 4), colmajor_view(S, poolB[0], (n,) * 4)
+        esz = poolA.element_size() * n ** 4
+        for name, f, srcs in (("permutedims_32^4_f64_cold", lambda x: x, (A.permutedims((3, 2, 1, 0)),)),
+                              ("broadcast4_32^4_f64_cold", lambda a, b, c, d: a + b + c + d, tuple(A.permutedims(q) for q in perms))):
+            p = S.make_plan(f, None, None, A.size, (B,) + srcs)
             p.execute(cur())
-        desc = p.describe()
-    for _ in range(3):
+            state = {"i": 0}
+
+            def rot():
+                i = state["i"] % npair
+                state["i"] += 1
+                p.execute(cur(), bases=[poolB.data_ptr() + i * esz] + [poolA.data_ptr() + i * esz] * len(srcs))
+
+            g = graph_of(torch, rot, 4 * npair)
+            g.replay()
+            torch.cuda.synchronize()
+            rec(name, p, min(event_time_ms(torch, g.replay, 2) for _ in range(3)) / (4 * npair))
+            # the same 40 INDEPENDENT launches as a recorded sequence on two hardware queues (the boundary of one launch overlaps the next
+            # pair's kernel; two queues measured best, profiles/r04_seq_vs_eager.txt): wall clock around smr_seq_run + smr_seq_wait
+            q = S.Sequence()
+            for i in range(npair):
+                q.add(p, bases=[poolB.data_ptr() + i * esz] + [poolA.data_ptr() + i * esz] * len(srcs))
+            q.set("queues", 2)
+            q.set("async", 0)
+            q.run(2, cur()); q.wait()
+            best = 1e30
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                q.run(8, cur()); q.wait()
+                best = min(best, time.perf_counter() - t0)
+            rec(name + "_seq_2_queues", p, best / (8 * npair) * 1e3)
+            del q
+        del poolA, poolB
+
+    def sec_c5():
+        # C5 compute-bound map 8192^2 f32
+        m = 8192
+        tA = torch.rand(m * m, dtype=torch.float32, device=dev)
+        tB = torch.empty_like(tA)
+        A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
+        p = S.make_plan(lambda a: a * fn.exp(-2 * a) + fn.sin(a * a), None, None, (m, m), (B, A))
+        rec("c5_expr_8192_f32", p, timed(p, 20))
+
+    def sec_c4():
+        # C4 mapreduce(abs2,+) 4096x4096x64 f32, block-partitioned over the ranks on dim 3 (every rank holds ONLY its
+        # slab), executed through the library's own multi-GPU entry point: smr_shard_ex -> local kernel ->
+        # ONE ncclAllReduce (RCCL over xGMI, csrc/smr_comm.cpp), in place on the one-element destination
+        from strided_jl_amd import distributed as D
+        slab = 64 // world if 64 % world == 0 else 64
+        tA = (torch.rand(4096 * 4096 * slab, dtype=torch.float32, device=dev) * 2 - 1)
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        dims = (4096, 4096, 64 if world > 1 and slab * world == 64 else slab)
+        A = S.StridedView(tA, dims, (1, 4096, 4096 * 4096), 0)  # logical box over the slab's memory
+        O = S.StridedView(out, dims, (0, 0, 0), 0)
+        sharded = world > 1 and slab * world == 64
+        if sharded:
+            import torch.distributed as dist
+            uid = [D.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            D.comm_init(world, rank, uid[0])
+            rccl_rank, rccl_ranks = D.comm_rank()
+            assert (rccl_rank, rccl_ranks) == (rank, world), "RCCL communicator disagrees with the launcher"
+
+            def c4():
+                out.zero_()
+                D.comm_mapreduce_sharded_(fn.abs2, "+", None, dims, (O, A), local=(False, True))
+            desc = "smr_mapreduce_sharded_ex (C ABI): shards=%d, slab-local input, ncclAllReduce(1 x f32) in place on the destination" % world
+        else:
+            p = S.make_plan(fn.abs2, "+", None, dims, (O, A))
+
+            def c4():
+                out.zero_()
+                p.execute(cur())
+            desc = p.describe()
+        for _ in range(3):
+            c4()
+        torch.cuda.synchronize()
+        got = float(out.item())
+        # what ONE step issues: kernel launches of the library (the local reduction, on ranks != 0 the neutral fill) and all-reduces
+        # -- the all-reduce runs in place on the one-element destination: no gather / scatter launches (csrc/smr_comm.cpp)
+        c0 = (S.get_option("launches"), S.get_option("allreduces"), S.get_option("allreduces_inplace"))
         c4()
-    torch.cuda.synchronize()
-    got = float(out.item())
-    ms = min(event_time_ms(torch, c4, 10) for _ in range(3))
-    if world > 1:
-        tt = torch.tensor([ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms = float(tt.item())
-    b = 4 * 4096 * 4096 * slab * (world if sharded else 1)
-    truth = float((tA.double() ** 2).sum().item())
-    if sharded:
-        tt = torch.tensor([truth], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt)
-        truth = float(tt.item())
-        D.comm_destroy()
-    res["c4_mapreduce_abs2_4096x4096x64_f32"] = {
-        "us": round(ms * 1e3, 2), "GB/s_total": round(b / (ms * 1e-3) / 1e9, 1), "shards": world if sharded else 1,
-        "frac_of_8TBs_per_gpu": round(b / (world if sharded else 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "rel_err_vs_f64": abs(got - truth) / truth, "plan": desc,
-        "collective": "RCCL ncclAllReduce(1 x f32) issued by libstrided_hip (smr_comm.cpp)" if sharded else "none",
-        "rccl_ranks": rccl_ranks if sharded else 1}
+        torch.cuda.synchronize()
+        per_step = {"library_kernel_launches": S.get_option("launches") - c0[0], "allreduces": S.get_option("allreduces") - c0[1],
+                    "allreduces_in_place": S.get_option("allreduces_inplace") - c0[2]}
+        ms = min(event_time_ms(torch, c4, 10) for _ in range(3))
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([ms], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = float(tt.item())
+        b = 4 * 4096 * 4096 * slab * (world if sharded else 1)
+        truth = float((tA.double() ** 2).sum().item())
+        if sharded:
+            tt = torch.tensor([truth], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt)
+            truth = float(tt.item())
+            D.comm_destroy()
+        res["c4_mapreduce_abs2_4096x4096x64_f32"] = {
+            "us": round(ms * 1e3, 2), "GB/s_total": round(b / (ms * 1e-3) / 1e9, 1), "shards": world if sharded else 1,
+            "frac_of_8TBs_per_gpu": round(b / (world if sharded else 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "rel_err_vs_f64": abs(got - truth) / truth, "plan": desc,
+            "collective": "RCCL ncclAllReduce(1 x f32) issued by libstrided_hip (smr_comm.cpp)" if sharded else "none",
+            "rccl_ranks": rccl_ranks if sharded else 1, "per_step_rank0": per_step}
+
+    for name, sec in (("c1", sec_c1), ("hbm128", sec_hbm128), ("cold", sec_cold), ("c5", sec_c5), ("c4", sec_c4)):
+        if want(name):
+            sec()
     return res
 
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -177,6 +178,9 @@ int window_fence(hipStream_t s) {
 
 // for the other translation units (smr_comm.cpp: the RCCL collective is foreign work on the stream)
 int fence_for_foreign_work(hipStream_t s) { return window_fence(s); }
+
+static std::atomic<long> g_launches{0};
+void count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 
 unsigned take_launch_flags() {
     const unsigned f = tl_launch_flags;
@@ -906,6 +910,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "seq_self_release") o.seq_self_release = value;
+    else if (n == "allreduce_f64") o.allreduce_f64 = value;
     else if (n == "self_release_max_bytes") o.self_release_max_bytes = value;
     else if (n == "nt_load") o.nt_load = value;
     else if (n == "orbit_min") o.orbit_min = value;
@@ -990,6 +995,10 @@ int64_t smr_get_option(const char* name) {
     if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
     if (n == "seq_self_release") return o.seq_self_release;
+    if (n == "allreduce_f64") return o.allreduce_f64;
+    if (n == "launches") return g_launches.load();
+    if (n == "allreduces") return comm_stat(0);
+    if (n == "allreduces_inplace") return comm_stat(1);
     if (n == "self_release_max_bytes") return o.self_release_max_bytes;
     if (n == "nt_load") return o.nt_load;
     if (n == "orbit_min") return o.orbit_min;

@@ -10,16 +10,27 @@
 // existing destination content enter exactly once (rank 0); the other ranks start from the
 // neutral element.
 //
+// The collective step (round 5): when the kept destination elements are one dense run in the destination's own element type
+// (config 4: ONE Float32; sum(A; dims=3) into a contiguous matrix) the all-reduce runs IN PLACE on the destination -- a step is then
+// the local kernel(s) + one ncclAllReduce, nothing else.  Strided destinations and 16-bit integers are gathered into a dense staging
+// buffer and scattered back (two more launches).  Option "allreduce_f64" = 1 stages Float32 / ComplexF32 SUMS through Float64
+// (every rank's partial is converted exactly, the ranks' sum is exact in Float64 up to 2^29 terms' worth of headroom, ONE rounding at
+// the end) at the price of those two launches; the default keeps Float32 -- measured on config 4, the error of the whole sharded sum
+// against the Float64 truth is 2-5e-8 either way (the local tree reduction dominates; <= 7 further roundings across 8 ranks:
+// DESIGN section 6).
+//
 // RCCL is loaded lazily with dlopen (no link-time dependency; a single-GPU user never needs it).
 #include <dlfcn.h>
 #include <link.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 
 #include "smr_internal.h"
 
@@ -176,6 +187,32 @@ int fill_neutral(const smr_problem* p) {
     return smr_mapreduce(&f);
 }
 
+// Are the kept destination elements one dense run of `count` elements (positive strides, any dim order)?
+bool kept_is_dense(const smr_problem* p) {
+    int64_t ext[SMR_MAXN], str[SMR_MAXN];
+    int n = 0;
+    for (int i = 0; i < p->N; ++i)
+        if (p->ops[0].strides[i] != 0 && p->dims[i] > 1) {
+            if (p->ops[0].strides[i] < 0) return false;
+            ext[n] = p->dims[i];
+            str[n] = p->ops[0].strides[i];
+            ++n;
+        }
+    for (int i = 1; i < n; ++i)  // insertion sort by stride
+        for (int j = i; j > 0 && str[j] < str[j - 1]; --j) {
+            std::swap(str[j], str[j - 1]);
+            std::swap(ext[j], ext[j - 1]);
+        }
+    int64_t want = 1;
+    for (int i = 0; i < n; ++i) {
+        if (str[i] != want) return false;
+        want *= ext[i];
+    }
+    return true;
+}
+
+std::atomic<long> g_allreduces{0}, g_allreduces_inplace{0};
+
 // dense <-> strided copy of the kept destination elements (dir 0: gather into staging, 1: scatter back)
 int copy_kept(const smr_problem* p, void* dense, int stage_dtype, int dir) {
     smr_problem c;
@@ -331,9 +368,27 @@ int smr_mapreduce_sharded_ex(const smr_problem* p, uint32_t local_ops) {
     if (rc) return rc;
     int64_t kd[SMR_MAXN], count;
     kept_box(p, kd, &count);
-    const size_t bytes = (size_t)count * (size_t)dtype_size(stage);
+    static const ncclRedOp_t ops[] = {ncclSum, ncclSum, ncclProd, ncclMin, ncclMax, ncclMin /* & on 0/1 */, ncclMax /* | on 0/1 */};
+    // Float32 / ComplexF32 sums through Float64 staging on request (exact conversion, exact-enough sum, one rounding)
+    const bool via_f64 = options().allreduce_f64 && p->redop == SMR_RED_ADD && (p->ops[0].dtype == SMR_F32 || p->ops[0].dtype == SMR_C32);
+    if (via_f64) {
+        stage = p->ops[0].dtype == SMR_F32 ? SMR_F64 : SMR_C64;
+        t = ncclFloat64;
+    }
     std::lock_guard<std::mutex> g(s.mu);
     if (!s.comm) return set_error(SMR_EINVAL, "smr_comm_init has not been called");
+    if (!via_f64 && stage == p->ops[0].dtype && kept_is_dense(p)) {
+        // in place: the destination's kept elements are one dense run -- local kernel(s) + ONE all-reduce, no gather / scatter
+        rc = fence_for_foreign_work((hipStream_t)p->stream);  // the local kernels may have been submitted directly (library-owned stream)
+        if (rc) return rc;
+        char* dst = (char*)p->ops[0].base + p->ops[0].offset * (int64_t)dtype_size(p->ops[0].dtype);
+        ncclResult_t e2 = s.r.all_reduce(dst, dst, (size_t)count * mult, t, ops[p->redop], s.comm, (hipStream_t)p->stream);
+        if (e2 != ncclSuccess) return nccl_error(e2, "ncclAllReduce (in place)");
+        ++g_allreduces;
+        ++g_allreduces_inplace;
+        return SMR_OK;
+    }
+    const size_t bytes = (size_t)count * (size_t)dtype_size(stage);
     if (bytes > s.staging_bytes) {
         if (s.staging) {
             (void)hipStreamSynchronize((hipStream_t)p->stream);
@@ -348,8 +403,12 @@ int smr_mapreduce_sharded_ex(const smr_problem* p, uint32_t local_ops) {
     if (rc) return rc;
     rc = fence_for_foreign_work((hipStream_t)p->stream);  // the gather above may have been submitted directly (library-owned stream)
     if (rc) return rc;
-    static const ncclRedOp_t ops[] = {ncclSum, ncclSum, ncclProd, ncclMin, ncclMax, ncclMin /* & on 0/1 */, ncclMax /* | on 0/1 */};
     ncclResult_t e = s.r.all_reduce(s.staging, s.staging, (size_t)count * mult, t, ops[p->redop], s.comm, (hipStream_t)p->stream);
     if (e != ncclSuccess) return nccl_error(e, "ncclAllReduce");
+    ++g_allreduces;
     return copy_kept(p, s.staging, stage, 1);
 }
+
+namespace smr {
+long comm_stat(int which) { return which == 0 ? g_allreduces.load() : g_allreduces_inplace.load(); }
+}  // namespace smr

@@ -147,6 +147,7 @@ template <class... A> inline void record_launch(std::vector<RecLaunch>* rec, con
             ::smr::record_launch(smr_rec_, (const void*)(kern), (grid).x, (block).x, (size_t)(lds), __VA_ARGS__);      \
             break;                                                                                                     \
         }                                                                                                              \
+        ::smr::count_launch();                                                                                        \
         const unsigned smr_lf_ = ::smr::take_launch_flags();                                                           \
         if (smr_lf_) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)(lds), s, nullptr, nullptr, smr_lf_, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                               \

@@ -281,6 +281,7 @@ struct Options {
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
+    i64 allreduce_f64 = 0;      // smr_mapreduce_sharded: Float32 / ComplexF32 sums cross the ranks as Float64 (staging + two launches); default: in the destination's type
     i64 seq_self_release = 1;   // launches recorded for a sequence use write-through stores where the family can, and their packets drop the release fence
     i64 self_release_max_bytes = (i64)64 << 20;  // ... when the destination is at most this big (beyond, a launch lasts far longer than its fences)
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
@@ -378,6 +379,8 @@ std::vector<RecLaunch>* recorder();  // thread-local, nullptr when nothing recor
 struct Plan;
 int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::vector<std::pair<uintptr_t, uintptr_t>>& rd,
                  const std::vector<std::pair<uintptr_t, uintptr_t>>& wr, hipStream_t s);
+long comm_stat(int which);                        // smr_comm.cpp: 0 = all-reduces issued, 1 = of which in place
+void count_launch();                              // every kernel launch the library issues (through HIP or directly): option "launches"
 int eager_fence_all();                            // SMR_OK, or SMR_EHIP: a device's direct path failed (reported once)
 void eager_note_hip_work(hipStream_t s);          // the library queued HIP work on owned stream s: s's next direct launch drains it first
 void eager_forget_stream(hipStream_t s);

@@ -1115,6 +1115,7 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
         q.tail = si;
         q.unsignaled = si >= 0 ? 0 : q.unsignaled + 1;
         ++e.n_launch;
+        count_launch();
     }
     return SMR_OK;
 }
@@ -1392,9 +1393,20 @@ int seq_build(smr_seq* q) {
     //     slice drains and releases, the next replay's other slice is already running.
     std::vector<int> cslices(ncomp, 1);
     {
+        // (a component of SEVERAL executions can be cut when they are all the same execution recorded repeatedly -- same plan, same
+        // base pointers: an unrolled replay, slice k of one follows slice k of the previous one like the replays of a single one)
         auto sliceable = [&](int c, int ns) {
             const Rec& r = recs[cfirst[c]];
-            return ns > 1 && csize[c] == 1 && r.launches.size() == 1 && r.launches[0].slice_kind != 0 && r.launches[0].grid >= (unsigned)(64 * ns);
+            if (!(ns > 1 && r.launches.size() == 1 && r.launches[0].slice_kind != 0 && r.launches[0].grid >= (unsigned)(64 * ns))) return false;
+            const SeqItem& first = q->items[cfirst[c]];
+            for (size_t i = 0; i < ni; ++i)
+                if (recs[i].comp == c && (int)i != cfirst[c]) {
+                    const SeqItem& it = q->items[i];
+                    if (it.plan != first.plan || it.has_bases != first.has_bases || (it.has_bases && std::memcmp(it.bases, first.bases, sizeof it.bases) != 0) ||
+                        recs[i].launches.size() != 1 || recs[i].launches[0].grid != r.launches[0].grid)
+                        return false;
+                }
+            return true;
         };
         std::vector<int> want(ncomp, 1);
         for (int c = 0; c < ncomp; ++c) {
@@ -1513,6 +1525,18 @@ int seq_build(smr_seq* q) {
                     v += (uint64_t)lo * l.slice_row;
                     std::memcpy(b + l.slice_off, &v, 8);
                 }
+#if SMR_STAMP
+                // stamp build: the last explicit argument is the launch's stamp region (16 bytes per wave, indexed by the slice-relative
+                // blockIdx.x): every slice gets its own part of it
+                if (ns > 1 && l.args.size() >= 8) {
+                    uint64_t sp = 0;
+                    std::memcpy(&sp, b + l.args.size() - 8, 8);
+                    if (sp) {
+                        sp += (uint64_t)lo * ((l.block + 63) / 64) * 16;
+                        std::memcpy(b + l.args.size() - 8, &sp, 8);
+                    }
+                }
+#endif
                 // the hidden arguments (block counts = this slice's, group sizes, grid dims, dynamic LDS size) at the offsets the code
                 // object's metadata names
                 KernargLayout lay;

@@ -74,6 +74,7 @@ def main():
             local.append(bool(loc))
         del full
         torch.cuda.synchronize()  # torch prepared the operands on its own stream
+        before = (S.get_option("launches"), S.get_option("allreduces"), S.get_option("allreduces_inplace"))
         D.comm_mapreduce_sharded_(MC.F[case["f"]], case["op"], case["initop"], dims, (dest,) + tuple(ins), local=tuple(local),
                                   stream=lib_stream.handle if lib_stream else None)
         if lib_stream:
@@ -81,6 +82,20 @@ def main():
         torch.cuda.synchronize()
         res["dest_%d" % ci] = dparent.cpu().numpy()
         res["meta_%d" % ci] = np.array([need.value, sdim, start, stop])
+        # kernel launches / all-reduces / in-place all-reduces this call issued
+        res["counts_%d" % ci] = np.array([S.get_option("launches") - before[0], S.get_option("allreduces") - before[1], S.get_option("allreduces_inplace") - before[2]])
+        # Float32 / ComplexF32 sums once more with the ranks' partials crossing as Float64 (option allreduce_f64)
+        if case["op"] == "+" and case["ddt"] in (np.float32, np.complex64) and need.value:
+            S.copyto_(kept_view, case["dinit"])
+            torch.cuda.synchronize()
+            S.set_option("allreduce_f64", 1)
+            D.comm_mapreduce_sharded_(MC.F[case["f"]], case["op"], case["initop"], dims, (dest,) + tuple(ins), local=tuple(local),
+                                      stream=lib_stream.handle if lib_stream else None)
+            S.set_option("allreduce_f64", 0)
+            if lib_stream:
+                lib_stream.synchronize()
+            torch.cuda.synchronize()
+            res["dest64_%d" % ci] = dparent.cpu().numpy()
     if lib_stream:
         res["eager_launches"] = np.array(S.get_option("eager_launches"))
         lib_stream.close()

@@ -82,6 +82,17 @@ def test_ranks_sharing_one_gpu(world, tmp_path):
         elif case["op"] is not None:
             assert need == 1, case["name"]
         collectives += need
+        # round 5: a dense kept destination in a type RCCL knows is all-reduced IN PLACE -- the call is the local kernel(s) (+ the
+        # neutral fill on ranks != 0) + ONE all-reduce; strided destinations and 16-bit integers go through staging (two more launches)
+        for r in range(world):
+            launches, ar, ar_in = (int(v) for v in res[r]["counts_%d" % ci])
+            assert ar == need, (case["name"], r, ar)
+            if need:
+                dense = not case.get("dest_strides")
+                staged = np.dtype(case["ddt"]).itemsize == 2 or not dense
+                assert ar_in == (0 if staged else 1), (case["name"], r, ar_in)
+                if case["name"] == "c4_abs2_sum_f32":   # config 4: two reduction launches on rank 0 (+ the fill elsewhere), ONE collective, nothing else
+                    assert launches <= (2 if r == 0 else 3), (case["name"], r, launches)
         for r in range(world):
             parent = res[r]["dest_%d" % ci]
             got, idx = kept_elements(case, parent)
@@ -101,6 +112,11 @@ def test_ranks_sharing_one_gpu(world, tmp_path):
             mask = np.ones(parent.shape, dtype=bool)
             mask[idx.ravel()] = False
             assert np.all(parent[mask] == 77), (case["name"], r, "memory between the destination's elements was written")
+        if need and "dest64_%d" % ci in res[0].files:   # the Float64 crossing: same truth, bit-identical on every rank
+            for r in range(world):
+                g64, _ = kept_elements(case, res[r]["dest64_%d" % ci])
+                assert np.allclose(g64, want, rtol=tol, atol=tol * float(np.max(np.abs(want)))), (case["name"], "allreduce_f64", r)
+                assert np.array_equal(g64, kept_elements(case, res[0]["dest64_%d" % ci])[0])
         if need and not case["exact"]:
             for r in range(1, world):  # the collective leaves bit-identical results on every rank
                 assert np.array_equal(kept_elements(case, res[r]["dest_%d" % ci])[0], kept_elements(case, res[0]["dest_%d" % ci])[0]), case["name"]

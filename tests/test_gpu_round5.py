@@ -106,8 +106,8 @@ def test_acquire_only_where_the_sequence_reads_what_it_writes():
 def test_chains_are_cut_by_default_and_results_are_those_of_in_order_execution(n):
     import torch
     _, (A, B, Cc), (p2, p3), (w2, w3) = step_plans(n, 3)
-    cut = "3" if n == 32 else "2"   # (a launch of fewer than 128 workgroups is not cut: 16^4 has 72 orbits)
-    for lay, want_q in ((None, None), ({"slices": 1}, "2"), ({"slices:1": 2, "queues": 3}, cut), ({"slices:0": 2, "queues": 3}, "3")):
+    cut = "3" if n == 32 else "2"   # (a launch of fewer than 128 workgroups is not cut: 16^4 has 72 orbits / 64 tiles)
+    for lay, want_q in ((None, None), ({"slices": 1}, "2"), ({"slices:1": 2, "queues": 3}, cut), ({"slices:0": 2, "queues": 3}, cut)):
         q = S.Sequence().add(p2).add(p3)
         for k, v in (lay or {}).items():
             q.set(k, v)
