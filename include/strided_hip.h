@@ -215,6 +215,10 @@ int smr_stream_sync(void* stream);
  * ordered after everything in the window.  Inside an open window the caller must not put work of its
  * own on `stream` (or must call smr_overlap_fence(stream) first).  Windows nest; they survive stream
  * capture into a hipGraph.
+ * ON gfx942 / gfx950 THE WINDOW IS A NO-OP FOR LAUNCHES THAT GO THROUGH HIP: HIP accepts hipExtAnyOrderLaunch and ignores it on gfx9
+ * (measured with device stamps, profiles/r04_overlap.txt), so the library does not even run the analysis there unless option
+ * "overlap_window_hip" = 1 asks for it.  Independent launches DO overlap where the library dispatches by itself: on the streams of
+ * smr_stream_create (next paragraph) and in recorded sequences (smr_seq_*).
  * smr_stream_create returns a stream of the library's own -- the stream of a host (the Julia shim) that routes ALL its device work
  * through this library.  On MI355X its launches do not go through HIP at all: the library submits every launch itself as an AQL
  * packet on one of four HSA queues it owns, choosing the queue by the data -- a launch that conflicts with nothing in flight goes to

@@ -199,7 +199,10 @@ class overlap:
     """`with overlap(stream):` -- an overlap window (smr_overlap_begin / smr_overlap_end): launches issued inside on `stream`
     that touch none of the data of the launches still in flight start without waiting for them (the GPU form of the
     reference's spawn-what-is-independent, src/mapreduce.jl:203-223); results are those of in-order execution.  `stream` is a
-    raw hipStream_t handle (None = the null stream; with torch pass torch.cuda.current_stream().cuda_stream)."""
+    raw hipStream_t handle (None = the null stream; with torch pass torch.cuda.current_stream().cuda_stream).
+    On MI355X (gfx950) this is a NO-OP for an ordinary HIP stream: HIP ignores the any-order launch flag on gfx9, so the library skips
+    the analysis (option "overlap_window_hip" = 1 re-enables it).  Use `S.Stream()` (the library dispatches itself and overlaps what
+    is independent) or a recorded `S.Sequence()`."""
 
     def __init__(self, stream: int | None = None):
         self.stream = C.c_void_p(stream or 0)

@@ -116,6 +116,12 @@ void footprint(const Plan& plan, void* const* bases, std::vector<Span>& rd, std:
 // decides the ordering of the execution about to be launched on `s`
 void window_admit(const Plan& plan, void* const* bases, hipStream_t s) {
     tl_launch_flags = 0;
+    // HIP accepts hipExtAnyOrderLaunch and IGNORES it on gfx9 (hip_ext.h says so; device stamps confirm it, profiles/r04_overlap.txt):
+    // on gfx942 / gfx950 a window on a stream that launches through HIP cannot change anything.  The analysis below -- two mutex
+    // acquisitions, a footprint with vector allocations per launch, a fence kernel -- therefore runs only on request (option
+    // "overlap_window_hip" = 1, for a runtime that honours the flag); by default the window API is a no-op for HIP launches, and
+    // independent launches overlap where the library dispatches itself: library-owned streams and recorded sequences (smr_seq.cpp).
+    if (!options().overlap_window_hip) return;
     Windows& W = windows();
     std::lock_guard<std::mutex> g(W.mu);
     if (W.map.empty()) return;
@@ -910,6 +916,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "seq_self_release") o.seq_self_release = value;
+    else if (n == "overlap_window_hip") o.overlap_window_hip = value;
     else if (n == "allreduce_f64") o.allreduce_f64 = value;
     else if (n == "self_release_max_bytes") o.self_release_max_bytes = value;
     else if (n == "nt_load") o.nt_load = value;
@@ -995,6 +1002,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
     if (n == "seq_self_release") return o.seq_self_release;
+    if (n == "overlap_window_hip") return o.overlap_window_hip;
     if (n == "allreduce_f64") return o.allreduce_f64;
     if (n == "launches") return g_launches.load();
     if (n == "allreduces") return comm_stat(0);

@@ -281,6 +281,7 @@ struct Options {
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
+    i64 overlap_window_hip = 0; // 1: launches of an overlap window that go through HIP carry hipExtAnyOrderLaunch when independent (ignored by HIP on gfx9: default off)
     i64 allreduce_f64 = 0;      // smr_mapreduce_sharded: Float32 / ComplexF32 sums cross the ranks as Float64 (staging + two launches); default: in the destination's type
     i64 seq_self_release = 1;   // launches recorded for a sequence use write-through stores where the family can, and their packets drop the release fence
     i64 self_release_max_bytes = (i64)64 << 20;  // ... when the destination is at most this big (beyond, a launch lasts far longer than its fences)

@@ -234,10 +234,11 @@ int canonicalise(const smr_problem* p, Canon& c) {
     // 64-bit arithmetic like Julia's (typeof(op(...)) is the accumulator type, src/mapreduce.jl:55-72); narrower
     // destinations truncate on store.  UInt64 takes part in ring operations only (no order on the device).
     {
-        bool allint = true, has_u64 = false;
+        bool allint = true, has_u64 = false, has_signed = false, has_const = false, eqne = false;
         for (int k = 0; k < M0; ++k) {
             if (p->ops[k].dtype < SMR_I8) allint = false;
             if (p->ops[k].dtype == SMR_U64) has_u64 = true;
+            if (p->ops[k].dtype >= SMR_I8 && p->ops[k].dtype <= SMR_I64) has_signed = true;
         }
         bool closed = true, ordered = p->redop == SMR_RED_MIN || p->redop == SMR_RED_MAX;
         for (int pc = 0; pc < prog.len && closed; ++pc) {
@@ -245,11 +246,17 @@ int canonicalise(const smr_problem* p, Canon& c) {
             switch (op) {
                 case SMR_OP_ARG: case SMR_OP_NEG: case SMR_OP_ABS2: case SMR_OP_CONJ: case SMR_OP_REAL: case SMR_OP_IMAG:
                 case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
-                // == and != belong here too: Julia compares UInt64 with signed values mathematically, a 64-bit signed domain compares bit patterns
-                case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: case SMR_OP_EQ: case SMR_OP_NE:
+                case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE:
                     ordered = true;
                     break;
+                // == and !=: equality of bit patterns IS Julia's equality as long as nothing signed can meet a UInt64 -- Julia
+                // compares a UInt64 with a signed value mathematically (-1 != 0xffff...ff), a 64-bit domain compares the patterns.
+                // Signed values come from signed operands and from constants (integer literals are Int64: UInt8 - 10 is an Int64).
+                case SMR_OP_EQ: case SMR_OP_NE:
+                    eqne = true;
+                    break;
                 case SMR_OP_CONST: {
+                    has_const = true;
                     const double re = prog.consts[2 * prog.code[2 * pc + 1]], im = prog.consts[2 * prog.code[2 * pc + 1] + 1];
                     // integer-valued (or a +-Inf seed of a min / max reduction, which saturates to typemax / typemin)
                     if (im != 0.0 || !(re == std::floor(re) || std::isinf(re)) || (std::fabs(re) > 9223372036854775808.0 && !std::isinf(re))) closed = false;
@@ -262,6 +269,7 @@ int canonicalise(const smr_problem* p, Canon& c) {
             const double re = p->initarg[0], im = p->initarg[1];
             if (im != 0.0 || re != std::floor(re) || std::fabs(re) > 9223372036854775808.0) closed = false;
         }
+        if (eqne && has_u64 && (has_signed || has_const)) ordered = true;  // (round 5: all-unsigned equality tests are exact and stay on the device)
         if (allint && closed && !(has_u64 && ordered)) {
             if (!int_class_matches_julia(p, prog))
                 return set_error(SMR_EUNSUPPORTED,
@@ -1349,7 +1357,9 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
         // next to a cut lead only a short lead that is NOT a power of two counts ((2,2,256,2,2,256) and (64,2,64,2,16) permutations with a
         // 16-byte lead beside a 2-KiB one: TILED 3.2-3.9 us, this form 6.9-7.1)
         const bool anysize = o.flat2_long >= 100;  // tests / experiments: wherever the form applies
-        awkward = odd_short || (fill * 100 < (long double)o.flat2_long && (anysize || c.total * es >= ((i64)8 << 20))) ||
+        // (round 5: ... and under 1 GiB: at HBM size the padded 32 x 32 tiles win again -- permutedims!(4,3,2,1) of 136^4 Float64, 72 %
+        // fill: 1562 us in this form, 1373 us in TILED, profiles/r05_pow2.txt)
+        awkward = odd_short || (fill * 100 < (long double)o.flat2_long && (anysize || (c.total * es >= ((i64)8 << 20) && c.total * es < ((i64)1 << 30)))) ||
                   (novec && (anysize || c.total * es >= ((i64)3 << 20)));
     }
     if (!awkward) return false;

@@ -208,6 +208,7 @@ def test_advisor_probes_follow_julia_and_numpy():
 def test_what_is_admitted_and_what_is_refused():
     rng = np.random.default_rng(0)
     i8, u8, i16, i32, i64 = (fview(adversarial(rng, dt, 8)) for dt in (np.int8, np.uint8, np.int16, np.int32, np.int64))
+    u64, u32 = (fview(adversarial(rng, dt, 8)) for dt in (np.uint64, np.uint32))
     sim = lambda v, dt=None: v.similar(dt)  # noqa: E731
     admitted = [
         (lambda a, b: a * b + a, (sim(i32), i32, i32)),                 # ring operations, destination as narrow as the operands
@@ -218,6 +219,8 @@ def test_what_is_admitted_and_what_is_refused():
         (lambda a, b: (a + 0) * b, (sim(i64), i8, i16)),                # widened to Int64 before anything can wrap
         (lambda a, b: a * b, (sim(i64), i32, i64)),                     # Int32 * Int64 is an Int64
         (lambda a: fn.abs(a), (sim(i8), i8)),                           # abs(typemin(Int8)) == typemin(Int8), same low 8 bits
+        (lambda a, b: fn.eq(a, b), (sim(u64, np.uint8), u64, u64)),    # round 5: all-unsigned equality is equality of bit patterns
+        (lambda a, b: fn.ne(a, b), (sim(u64, np.uint8), u64, u32)),    # ... UInt32 is zero-extended, as Julia promotes it
     ]
     refused = [
         (lambda a, b: a * b, (sim(i32, np.int64), i32, i32)),           # 32-bit product observed at 64 bits
@@ -227,6 +230,9 @@ def test_what_is_admitted_and_what_is_refused():
         (lambda a: -a, (sim(u8, np.int64), u8)),                        # -UInt8(1) == 255
         (lambda a, b: (a < b) + a, (sim(i8, np.int64), i8, i8)),        # Bool + Int8 is an Int8
         (lambda a, b: fn.ifelse(a * a > b, a, b), (sim(i16), i16, i16)),  # the condition observes a wrapped square
+        (lambda a, b: fn.eq(a, b), (sim(u64, np.uint8), u64, i64)),    # UInt64 against a signed value: Julia compares mathematically
+        (lambda a, b: fn.eq(a - 10, b), (sim(u64, np.uint8), u8, u64)),  # a literal is an Int64: UInt8 - 10 may be negative
+        (lambda a, b: a < b, (sim(u64, np.uint8), u64, u64)),           # no order on UInt64 in a signed 64-bit domain
     ]
     for f, arrs in admitted:
         ok, desc = planned(f, None, arrs[0].size, arrs)
