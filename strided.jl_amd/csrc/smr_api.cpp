@@ -917,8 +917,11 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "seq_self_release") o.seq_self_release = value;
     else if (n == "overlap_window_hip") o.overlap_window_hip = value;
+    else if (n == "tiled_gorder") o.tiled_gorder = value;
+    else if (n == "tiled_xpose") o.tiled_xpose = value;
     else if (n == "allreduce_f64") o.allreduce_f64 = value;
     else if (n == "self_release_max_bytes") o.self_release_max_bytes = value;
+    else if (n == "self_release_max_total") o.self_release_max_total = value;
     else if (n == "nt_load") o.nt_load = value;
     else if (n == "orbit_min") o.orbit_min = value;
     else if (n == "orbit_few") o.orbit_few = value;
@@ -1003,11 +1006,14 @@ int64_t smr_get_option(const char* name) {
     if (n == "nt_store") return o.nt_store;
     if (n == "seq_self_release") return o.seq_self_release;
     if (n == "overlap_window_hip") return o.overlap_window_hip;
+    if (n == "tiled_gorder") return o.tiled_gorder;
+    if (n == "tiled_xpose") return o.tiled_xpose;
     if (n == "allreduce_f64") return o.allreduce_f64;
     if (n == "launches") return g_launches.load();
     if (n == "allreduces") return comm_stat(0);
     if (n == "allreduces_inplace") return comm_stat(1);
     if (n == "self_release_max_bytes") return o.self_release_max_bytes;
+    if (n == "self_release_max_total") return o.self_release_max_total;
     if (n == "nt_load") return o.nt_load;
     if (n == "orbit_min") return o.orbit_min;
     if (n == "orbit_few") return o.orbit_few;

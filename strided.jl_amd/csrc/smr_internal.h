@@ -138,6 +138,7 @@ struct TilePlan {
     std::vector<uint32_t> ord;
     int ord_groups = 0;
     bool no_persist = false;  // block-ordered lists run in the one-shot form
+    int gorder[MAXN] = {0, 1, 2, 3, 4, 5, 6, 7};  // order of the grid dims (canonical dims, fastest first; dims with one tile are skipped): plan_tiles
 };
 
 // Description for FAM_ORBIT (smr_k_orbit.hip).  Every input k is a view of one buffer whose strides are
@@ -281,9 +282,12 @@ struct Options {
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
+    i64 tiled_xpose = 1;        // HBM-sized transposing copies (one staged input, 128 x 32 tiles, whole tiles, 8- / 16-byte elements) run the lean kernel k_xpose_big
+    i64 tiled_gorder = -1;      // TILED grid-dim order: 0 canonical, 1 the staged input's split unit axis second, -1 = that for HBM-sized 128 x 32 transposes
     i64 overlap_window_hip = 0; // 1: launches of an overlap window that go through HIP carry hipExtAnyOrderLaunch when independent (ignored by HIP on gfx9: default off)
     i64 allreduce_f64 = 0;      // smr_mapreduce_sharded: Float32 / ComplexF32 sums cross the ranks as Float64 (staging + two launches); default: in the destination's type
     i64 seq_self_release = 1;   // launches recorded for a sequence use write-through stores where the family can, and their packets drop the release fence
+    i64 self_release_max_total = (i64)128 << 20; // ... and when everything the sequence touches is at most this big (half the Infinity Cache: write-through to HBM loses)
     i64 self_release_max_bytes = (i64)64 << 20;  // ... when the destination is at most this big (beyond, a launch lasts far longer than its fences)
     i64 orbit_lg = -1;       // tuning: force the log2 edge of the orbit tiles (-1 = planner's choice)
     i64 orbit_min = 150;     // pick the largest tile edge that still yields this many orbits (measured: tools/orbit_sweep.py)

@@ -911,12 +911,16 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     }
     if (std::getenv("SMR_DEBUG_SWIZZLE"))
         std::fprintf(stderr, "[smr] tiled swizzle: w=%d V=%d patterns=%zu conflict cost fold=%d searched=%d\n", w, V, pats.size(), cost0, cost1);
-    // grid dims: canonical dims with more than one tile, in canonical order
+    // grid dims: canonical dims with more than one tile, in the order the planner chose (TilePlan::gorder: canonical order, or --
+    // HBM-sized transposes -- the tile index along the INPUT's unit axis second: plan_tiles)
     int gof[MAXN], ng = 0;
-    for (int d = 0; d < c.N; ++d) {
-        gof[d] = -1;
-        if (t.ntiles[d] > 1) gof[d] = ng++;
+    for (int d = 0; d < c.N; ++d) gof[d] = -1;
+    for (int i = 0; i < c.N; ++i) {
+        const int d = t.gorder[i];
+        if (d >= 0 && d < c.N && gof[d] < 0 && t.ntiles[d] > 1) gof[d] = ng++;
     }
+    for (int d = 0; d < c.N; ++d)  // (anything the planner's order left out: canonical order behind it)
+        if (gof[d] < 0 && t.ntiles[d] > 1) gof[d] = ng++;
     for (int g = 0; g < MAXN; ++g) {
         a.ntiles[g] = 1;
         a.div_m[g] = 0;
@@ -1112,11 +1116,150 @@ static int go_tl(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool na
     return go3<T, F, MIXED, false, 1, THRLOG>(plan, s, f, tab);
 }
 
+// ---- XPOSE: the lean form of an HBM-sized transposing copy (round 5) -------------------------------------------------------------
+// One staged input, 128 x 32 tiles, every tiled extent a whole number of tiles, 16-byte accesses: permutedims! / adjoint! / copy! of
+// a permuted view / B .= c .* A' on arrays of 1 GiB and more.  The general kernel above carries lane tables (16 KiB of table rows per
+// 1024-lane workgroup: a quarter more L2 read requests than the payload), swizzle masks, tile-order lookups and edge code through its
+// prologue; at 65536 workgroups per launch that is 8 % of the run time (tools/xpose_proto.hip: 723 us against 782 us for the same
+// tile shape and grid order at 128^4 Float64).  Here the lane's place in the tile is two integer divisions of its id, the tile's
+// origin a handful of divisions of the workgroup id, every load of the tile is issued before the first LDS write, the LDS rows
+// carry a pitch of TQ + 2 elements, stores are non-temporal.  Grid order = TilePlan::gorder.
+struct XposeArgs {
+    const char* src;
+    char* dst;
+    int32_t ng, pad;
+    uint32_t ext[MAXN];     // extent of grid coordinate g (fastest first)
+    i64 sstep[MAXN];        // byte step of the input / the destination per unit of grid coordinate g
+    i64 dstep[MAXN];
+    i64 src_row, dst_row;   // byte stride of the input along the destination's unit dim / of the destination along the input's unit dim
+};
+
+template <class T, class F, int V, int T0, int TQ>
+__global__ void __launch_bounds__(1024) k_xpose_big(const XposeArgs a, F f) {
+    typedef TVec<T, V> VT;
+    constexpr int PITCH = TQ + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
+    T* lds = reinterpret_cast<T*>(smem_x);
+    uint32_t b = blockIdx.x;
+    i64 so = 0, dofs = 0;
+#pragma unroll 1
+    for (int g = 0; g < a.ng; ++g) {
+        const uint32_t q = b / a.ext[g], r = b - q * a.ext[g];
+        so += (i64)r * a.sstep[g];
+        dofs += (i64)r * a.dstep[g];
+        b = q;
+    }
+    const char* s0 = a.src + so;
+    char* d0 = a.dst + dofs;
+    const int tid = threadIdx.x;
+    // load: lanes along the input's unit axis (TQ / V lanes per row), rows along the destination's unit dim
+    constexpr int LPR = TQ / V, RPP = 1024 / LPR, NPASS = T0 / RPP;
+    const int lc = tid % LPR, lr = tid / LPR;
+    VT x[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) x[p] = *reinterpret_cast<const VT*>(s0 + (i64)(p * RPP + lr) * a.src_row + (i64)lc * (V * (int)sizeof(T)));
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        T* L = lds + (size_t)(p * RPP + lr) * PITCH + V * lc;  // row = position along the destination's unit dim
+#pragma unroll
+        for (int h = 0; h < V; ++h) L[h] = x[p].v[h];
+    }
+    __syncthreads();
+    // store: lanes along the destination's unit dim (T0 / V lanes per row), rows along the input's unit axis
+    constexpr int LPR2 = T0 / V, RPP2 = 1024 / LPR2, NPASS2 = TQ / RPP2;
+    const int sc = tid % LPR2, sr = tid / LPR2;
+#pragma unroll
+    for (int p = 0; p < NPASS2; ++p) {
+        const int iq = p * RPP2 + sr;
+        VT out;
+#pragma unroll
+        for (int h = 0; h < V; ++h) {
+            T arg[MAXIN];
+#pragma unroll
+            for (int i = 0; i < MAXIN; ++i) arg[i] = T{};
+            arg[0] = lds[(size_t)(V * sc + h) * PITCH + iq];
+            out.v[h] = f(arg);
+        }
+        store_vec_ct<true, VT>(d0 + (i64)iq * a.dst_row + (i64)sc * (V * (int)sizeof(T)), out);
+    }
+}
+
+// SMR_OK: launched; SMR_EUNSUPPORTED (no error text set): not this case, the caller takes the general kernel
+template <class T, class F>
+static int try_xpose_big(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+    const Canon& c = plan.c;
+    const TilePlan& t = plan.tile;
+    constexpr int V = 16 / (int)sizeof(T) >= 1 ? 16 / (int)sizeof(T) : 1;
+    constexpr int T0 = 128, TQ = 32;
+    if constexpr (is_jit<F>::value || !tr<T>::arith || sizeof(T) < 8 || (F::NIN >= 0 && F::NIN != 1)) {
+        return SMR_EUNSUPPORTED;
+    } else {
+        if (!options().tiled_xpose) return SMR_EUNSUPPORTED;
+        // (rank 2 -- a plain matrix transpose, or a permutation that fuses to one -- stays with the general kernel: 16384^2 700 vs 708 us)
+        if (c.M != 2 || c.mixed || c.N < 3 || c.N > MAXN || t.nt != 2 || t.tilelog != 12 || t.staged[1] < 0 || !t.ord.empty()) return SMR_EUNSUPPORTED;
+        if (t.tdim[0] != 0 || t.tlog[0] != 7 || t.tlog[1] != 5) return SMR_EUNSUPPORTED;
+        const int q = t.tdim[1];
+        if (c.strides[0][0] != 1 || c.strides[1][q] != 1 || c.dims[0] % T0 || c.dims[q] % TQ) return SMR_EUNSUPPORTED;
+        if (tab.conj[0] || tab.conj[1]) return SMR_EUNSUPPORTED;
+        if (c.algbytes < ((i64)512 << 20)) return SMR_EUNSUPPORTED;
+        const i64 es = (i64)sizeof(T);
+        if ((((uintptr_t)tab.base[0]) | ((uintptr_t)tab.base[1])) % 16) return SMR_EUNSUPPORTED;
+        for (int d = 0; d < c.N; ++d) {
+            if (d != 0 && (c.strides[0][d] * es) % 16) return SMR_EUNSUPPORTED;
+            if (d != q && (c.strides[1][d] * es) % 16) return SMR_EUNSUPPORTED;
+        }
+        XposeArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.src = (const char*)tab.base[1];
+        a.dst = (char*)tab.base[0];
+        a.src_row = c.strides[1][0] * es;
+        a.dst_row = c.strides[0][q] * es;
+        i64 grid = 1;
+        int ng = 0;
+        for (int i = 0; i < c.N; ++i) {
+            const int d = t.gorder[i] >= 0 && t.gorder[i] < c.N ? t.gorder[i] : -1;
+            if (d < 0) return SMR_EUNSUPPORTED;
+            const i64 tile = d == 0 ? T0 : (d == q ? TQ : 1);
+            const i64 n = c.dims[d] / tile;
+            if (n <= 1) continue;
+            if (n > 0xffffffffLL) return SMR_EUNSUPPORTED;
+            a.ext[ng] = (uint32_t)n;
+            a.sstep[ng] = c.strides[1][d] * es * tile;
+            a.dstep[ng] = c.strides[0][d] * es * tile;
+            grid *= n;
+            ++ng;
+        }
+        {   // gorder must be a permutation of the dims (every dim with more than one tile appears once)
+            bool seen[MAXN] = {false};
+            for (int i = 0; i < c.N; ++i) {
+                if (seen[t.gorder[i]]) return SMR_EUNSUPPORTED;
+                seen[t.gorder[i]] = true;
+            }
+        }
+        a.ng = ng;
+        if (grid < 1 || grid > 0x7fffffffLL) return SMR_EUNSUPPORTED;
+        if (jit_no_launch()) return SMR_OK;  // (prepare mode: this form has no tables to build)
+        const size_t lds = (size_t)T0 * (TQ + 2) * sizeof(T);
+        auto kern = k_xpose_big<T, F, V, T0, TQ>;
+        clear_sticky_error();
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
+        }
+        SMR_LAUNCH(kern, dim3((unsigned)grid), dim3(1024), lds, s, a, f);
+        return check_launch("k_xpose_big");
+    }
+}
+
 template <class T, class F, bool MIXED>
 static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     const Canon& c = plan.c;
     const TilePlan& t = plan.tile;
     const OpTab tab = make_optab(c, bases);
+    if constexpr (!MIXED) {  // HBM-sized transposing copies: the lean form
+        const int rc = try_xpose_big<T, F>(plan, s, f, tab);
+        if (rc != SMR_EUNSUPPORTED) return rc;
+    }
     // 32-bit within-tile byte offsets when every tiled stride is >= 0 and the tile spans < 4 GiB
     bool narrow = true;
     for (int k = 0; k < c.M && narrow; ++k) {

@@ -1116,6 +1116,46 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
     }
     t.lds_bytes = (size_t)nst * ((size_t)1 << total) * es;
     if (t.grid > 0x7fffffffLL) return false;
+    // Order of the grid dims (which tile coordinate varies fastest with the workgroup id).  Canonical order = by destination
+    // stride: consecutive workgroups continue the destination's memory.  For HBM-sized transposing copies whose input's unit axis is
+    // cut into several tiles (permutedims!(B, A, (4,3,2,1)) of 128^4: 128 x 32 tiles, four tiles along A's rows of 1 KiB) the tile
+    // index along THAT axis goes second: the ~512 workgroups resident at once then cover whole rows of the input as well as
+    // contiguous runs of the destination, instead of quarter rows of four different input rows -- tools/xpose_proto.hip: 843 -> 723
+    // us for the same tile shape.  In the library (tools/gorder_ab.py, profiles/r05_gorder_ab.txt, Float64): 144^4 (4,3,2,1) 1336 ->
+    // 1182 us, (256,128,128,64) reversed 879 -> 811, (64,64,64,64,16) reversed 834 -> 791, Float32 128^4 457 -> 434; neutral for 2-D
+    // transposes and when the input's axis is one tile; so: every transposing copy of >= 512 MiB with one staged input and rank >= 3.
+    for (int i = 0; i < MAXN; ++i) t.gorder[i] = i < c.N ? i : -1;
+    {
+        const i64 mode = o.tiled_gorder;
+        const bool big = c.algbytes >= ((i64)512 << 20);
+        if ((mode > 0 || (mode < 0 && big && na == 2 && nst == 1)) && c.N >= 3) {
+            // staged inputs' unit axes that are tiled AND split into several tiles, moved to position 1 (behind the fastest grid dim)
+            int order[MAXN], n = 0, first = -1;
+            for (int d = 0; d < c.N; ++d)
+                if (t.ntiles[d] > 1) {
+                    first = d;
+                    break;
+                }
+            if (first >= 0) {
+                order[n++] = first;
+                for (int k = 1; k < c.M; ++k) {
+                    if (t.staged[k] < 0) continue;
+                    const int q = fast_axis(c, k);
+                    if (q >= 0 && q != first && lg[q] > 0 && t.ntiles[q] > 1) {
+                        bool have = false;
+                        for (int i = 0; i < n; ++i) have = have || order[i] == q;
+                        if (!have) order[n++] = q;
+                    }
+                }
+                for (int d = 0; d < c.N; ++d) {
+                    bool have = false;
+                    for (int i = 0; i < n; ++i) have = have || order[i] == d;
+                    if (!have) order[n++] = d;
+                }
+                for (int i = 0; i < c.N; ++i) t.gorder[i] = order[i];
+            }
+        }
+    }
     t.ord.clear();
     t.ord_groups = 0;
     if (o.tile_order) plan_tile_order(c, t, lg);
@@ -1129,6 +1169,8 @@ static bool plan_tiles(const Canon& c, TilePlan& t) {
         plan_block_order(c, t, lg, o.tile_block > 0 ? (int)o.tile_block : (o.tile_block == -2 ? -1 : 4), xcd_runs);
         t.no_persist = t.no_persist || !t.ord.empty();  // measured: the one-shot form wins on block-ordered lists (128^4: 2715 vs 2773 us)
     }
+    if (!t.ord.empty())  // work lists hold linear tile ids in canonical grid order
+        for (int i = 0; i < MAXN; ++i) t.gorder[i] = i < c.N ? i : -1;
     return true;
 }
 

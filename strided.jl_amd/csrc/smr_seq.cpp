@@ -1311,14 +1311,38 @@ int seq_build(smr_seq* q) {
         SeqItem& it = q->items[i];
         int rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, nullptr, true);
         if (rc) return rc;
-        set_recorder(&recs[i].launches, true);
-        rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, nullptr, false);
-        set_recorder(nullptr);
-        if (rc) return rc;
-        if (recs[i].launches.empty()) return set_error(SMR_EINVAL, "smr_seq: a plan recorded no launch");
         seq_footprint(it.plan, it.has_bases ? it.bases : nullptr, recs[i].rd, recs[i].wr);
         for (const auto& x : recs[i].rd) recs[i].bytes += x.second - x.first;
         for (const auto& x : recs[i].wr) recs[i].bytes += x.second - x.first;
+    }
+    // Self-released launches (write-through stores, no release fence: smr_device.h) pay for the dropped fence with slower stores.
+    // That trade wins while everything the sequence touches stays in the caches (the bench step: 5.3 -> 4.6 us) and loses when the
+    // stores go to HBM -- 40 launches rotating over 640 MiB of operands: the 4-way sum's 32-byte runs 4.95 -> 5.92 us per launch
+    // (profiles/r05_bench_n1.json vs r04).  So: only when the union of all byte ranges of the sequence is at most
+    // "self_release_max_total" bytes (default 128 MiB, half the Infinity Cache).
+    bool allow_self;
+    {
+        Spans all;
+        for (const Rec& r : recs) {
+            all.insert(all.end(), r.rd.begin(), r.rd.end());
+            all.insert(all.end(), r.wr.begin(), r.wr.end());
+        }
+        std::sort(all.begin(), all.end());
+        uintptr_t total = 0, hi = 0;
+        for (const auto& x : all) {
+            const uintptr_t lo = std::max(x.first, hi);
+            if (x.second > lo) total += x.second - lo;
+            hi = std::max(hi, x.second);
+        }
+        allow_self = (i64)total <= options().self_release_max_total;
+    }
+    for (size_t i = 0; i < q->items.size(); ++i) {
+        SeqItem& it = q->items[i];
+        set_recorder(&recs[i].launches, allow_self);
+        int rc = seq_execute_plan(it.plan, it.has_bases ? it.bases : nullptr, nullptr, false);
+        set_recorder(nullptr);
+        if (rc) return rc;
+        if (recs[i].launches.empty()) return set_error(SMR_EINVAL, "smr_seq: a plan recorded no launch");
     }
     bool aql = d.ok;
     // 2. resolve kernels (the device's kernel map and queues are shared with the eager path: d.mu)

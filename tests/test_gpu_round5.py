@@ -318,3 +318,52 @@ def test_a_failed_selftest_switches_the_direct_path_off_and_everything_runs_thro
     assert r.returncode == 0 and "OK" in r.stdout.split(), r.stdout + r.stderr
     info = [l for l in r.stdout.splitlines() if l.startswith("INFO")][0]
     assert "backend=aql" in info and "kernarg_layout=v5-rule+verified" in info, info
+
+
+@pytest.mark.parametrize("shape,perm,dt", [((128, 64, 64, 128), (3, 2, 1, 0), "float64"), ((256, 64, 32, 128), (3, 2, 1, 0), "float64"),
+                                           ((512, 256, 512), (2, 1, 0), "float64"), ((128, 96, 64, 128), (3, 1, 2, 0), "complex128"),
+                                           ((128, 128, 32, 128), (3, 0, 1, 2), "int64")])
+def test_hbm_sized_transposing_copies_lean_kernel_and_grid_order_are_bit_exact(shape, perm, dt):
+    """>= 512 MiB transposing copies of rank >= 3 take the lean 128 x 32 kernel (k_xpose_big) and the planner's grid order; the general
+    kernel in canonical order is the comparison; truth = torch."""
+    import torch
+    n = int(np.prod(shape))
+    tdt = getattr(torch, dt)
+    if dt == "int64":
+        tA = torch.randint(-2 ** 62, 2 ** 62, (n,), dtype=tdt, device="cuda")
+    elif dt == "complex128":
+        tA = torch.randn(n, dtype=tdt, device="cuda")
+    else:
+        tA = torch.randn(n, dtype=tdt, device="cuda")
+    rank = len(shape)
+    oshape = tuple(shape[p] for p in perm)
+
+    def cm(t, sh):
+        st, s = [], 1
+        for d in sh:
+            st.append(s)
+            s *= d
+        return S.StridedView(t, sh, tuple(st), 0)
+
+    want = tA.reshape(tuple(reversed(shape))).permute(*[rank - 1 - perm[rank - 1 - i] for i in range(rank)]).contiguous().reshape(-1)
+    tB = torch.empty_like(tA)
+    A, B = cm(tA, shape), cm(tB, oshape)
+    for xp, go in ((1, -1), (0, 0), (0, 1)):
+        S.set_option("tiled_xpose", xp)
+        S.set_option("tiled_gorder", go)
+        try:
+            tB.zero_()
+            p = S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims(perm)))
+            assert "family=tiled" in p.describe() and "d0:128" in p.describe(), p.describe()
+            p.execute(cur())
+            torch.cuda.synchronize()
+            assert torch.equal(tB, want), (xp, go, p.describe())
+        finally:
+            S.set_option("tiled_xpose", 1)
+            S.set_option("tiled_gorder", -1)
+    # a scaled copy through the same path (a functor with a constant)
+    if dt == "float64":
+        p = S.make_plan(lambda x: 3 * x, None, None, B.size, (B, A.permutedims(perm)))
+        p.execute(cur())
+        torch.cuda.synchronize()
+        assert torch.equal(tB, 3 * want)
