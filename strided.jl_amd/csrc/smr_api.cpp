@@ -931,6 +931,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "orbit_wgs") o.orbit_wgs = value;
     else if (n == "orbit_minrun") o.orbit_minrun = value;
     else if (n == "orbit_skew") o.orbit_skew = value;
+    else if (n == "orbit_deal") o.orbit_deal = value;
     else if (n == "flat") o.flat = value;
     else if (n == "stamp_base" || n == "stamp_cap" || n == "stamp_used") {  // no plan depends on these: keep the cache
         (n == "stamp_base" ? o.stamp_base : (n == "stamp_cap" ? o.stamp_cap : o.stamp_used)) = value;
@@ -1023,6 +1024,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "orbit_wgs") return o.orbit_wgs;
     if (n == "orbit_minrun") return o.orbit_minrun;
     if (n == "orbit_skew") return o.orbit_skew;
+    if (n == "orbit_deal") return o.orbit_deal;
     if (n == "flat") return o.flat;
     if (n == "stamp_base") return o.stamp_base;
     if (n == "stamp_cap") return o.stamp_cap;

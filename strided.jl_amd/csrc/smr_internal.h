@@ -296,6 +296,7 @@ struct Options {
                              // next to each other on one XCD
     i64 stamp_base = 0, stamp_cap = 0, stamp_used = 0;  // SMR_STAMP builds: device buffer of 8-byte words for wave stamps
     i64 flat = 1;            // FAM_FLAT for transposing unary maps with short non-power-of-two leading dims (0 = TILED as in round 2)
+    i64 orbit_deal = 0;      // experiment: 1 = super-cell c runs on XCD c mod 8 (instead of one contiguous run of the list per XCD)
     i64 orbit_skew = 0;      // experiment: diagonal enumeration of the ORBIT super-cells (step per super-cell along the other dims)
     i64 orbit_minrun = 16;   // shortest contiguous run (bytes) an ORBIT tile edge may have (round 3: 16 -- Float32 4^4 cubes at 32^4:
                              // 5.60 -> 4.61 us, 24^4 3.41 -> 3.01 us; larger sizes keep the 8^4 cubes)

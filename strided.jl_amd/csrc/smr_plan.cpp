@@ -844,6 +844,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
     }
     std::vector<char> seen((size_t)o.ntiles_total, 0);
     std::vector<uint32_t> list;
+    std::vector<uint32_t> cell_of;  // super-cell (linear index, dim 0 fastest) every list entry came from
     i64 ncell[MAXN], cells = 1;
     int sub[MAXN];
     for (int d = 0; d < c.N; ++d) {
@@ -889,10 +890,24 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
             if (seen[(size_t)root]) continue;
             seen[(size_t)root] = 1;
             list.push_back((uint32_t)root);
+            cell_of.push_back((uint32_t)cell);
         }
     }
     o.norbits = (int)list.size();
     constexpr int NX = 8;
+    if (opt.orbit_deal == 1) {
+        // experiment (round 5): super-cell c runs on XCD c mod 8 -- consecutive super-cells step along dim 0, so at any time the eight
+        // XCDs work on eight neighbours along the buffer's unit axis (whole DRAM pages chip-wide) while the partner halves of every
+        // line still meet inside one XCD's L2
+        std::vector<uint32_t> perx[NX];
+        for (size_t i = 0; i < list.size(); ++i) perx[cell_of[i] % NX].push_back(list[i]);
+        size_t cs2 = 0;
+        for (int x = 0; x < NX; ++x) cs2 = std::max(cs2, perx[x].size());
+        o.list.assign(cs2 * NX, 0xffffffffu);
+        for (int x = 0; x < NX; ++x)
+            for (size_t sl = 0; sl < perx[x].size(); ++sl) o.list[sl * NX + x] = perx[x][sl];
+        return true;
+    }
     const size_t cs = (list.size() + NX - 1) / NX;
     o.list.assign(cs * NX, 0xffffffffu);
     for (size_t x = 0; x < (size_t)NX; ++x)

@@ -52,6 +52,13 @@ def run(opts):
 
 run({})
 if what == "sum":
+    run({"orbit_deal": 1})
+    run({"orbit_deal": 1, "orbit_pipe": 0})
+    run({"orbit_deal": 1, "orbit_group": 4})
+    run({"orbit_deal": 1, "orbit_group": 1})
+    run({"orbit_deal": 1, "nt_store": 2})
+    if len(sys.argv) > 3:
+        sys.exit(0)
     for g in (1, 4):
         run({"orbit_group": g})
     for sk in (1, 3, 5):
