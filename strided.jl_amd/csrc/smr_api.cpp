@@ -214,14 +214,13 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
             std::vector<Span> rd, wr;
             footprint(plan, bases, rd, wr);
             std::vector<RecLaunch> rec;
-            set_recorder(&rec);
+            // self-released launches (write-through stores, no release fence on the packet: smr_seq.cpp) while what this stream has
+            // been writing lately fits the caches
+            set_recorder(&rec, options().eager_self_release != 0 && !wr.empty() && eager_recent_writes_fit(wr[0].lo, wr[0].hi));
             int rc = execute_family(plan, bases, s);
             set_recorder(nullptr);
             if (rc) return rc;
-            if (!plan.eager_seen) {
-                plan.eager_seen = true;
-                eager_request_sys_acquire(s);
-            }
+            if (!__atomic_exchange_n(&plan.eager_seen, true, __ATOMIC_RELAXED)) eager_request_sys_acquire(s);  // (two threads may execute one plan)
             std::vector<std::pair<uintptr_t, uintptr_t>> r2, w2;
             for (const Span& x : rd) r2.emplace_back(x.lo, x.hi);
             for (const Span& x : wr) w2.emplace_back(x.lo, x.hi);
@@ -916,6 +915,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "seq_self_release") o.seq_self_release = value;
+    else if (n == "eager_self_release") o.eager_self_release = value;
     else if (n == "overlap_window_hip") o.overlap_window_hip = value;
     else if (n == "tiled_gorder") o.tiled_gorder = value;
     else if (n == "tiled_xpose") o.tiled_xpose = value;
@@ -1006,6 +1006,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
     if (n == "seq_self_release") return o.seq_self_release;
+    if (n == "eager_self_release") return o.eager_self_release;
     if (n == "overlap_window_hip") return o.overlap_window_hip;
     if (n == "tiled_gorder") return o.tiled_gorder;
     if (n == "tiled_xpose") return o.tiled_xpose;

@@ -286,6 +286,7 @@ struct Options {
     i64 tiled_gorder = -1;      // TILED grid-dim order: 0 canonical, 1 the staged input's split unit axis second, -1 = that for HBM-sized 128 x 32 transposes
     i64 overlap_window_hip = 0; // 1: launches of an overlap window that go through HIP carry hipExtAnyOrderLaunch when independent (ignored by HIP on gfx9: default off)
     i64 allreduce_f64 = 0;      // smr_mapreduce_sharded: Float32 / ComplexF32 sums cross the ranks as Float64 (staging + two launches); default: in the destination's type
+    i64 eager_self_release = 1; // launches of library-owned streams use write-through stores and their packets drop the release fence while the recently written destinations fit the caches (profiles/r05_eager_self_release.txt: bench step issued eagerly 6.19 -> 5.35 us, dependent chain 3.24 -> 2.93, independent launches 2.17 -> 1.62 us)
     i64 seq_self_release = 1;   // launches recorded for a sequence use write-through stores where the family can, and their packets drop the release fence
     i64 self_release_max_total = (i64)128 << 20; // ... and when everything the sequence touches is at most this big (half the Infinity Cache: write-through to HBM loses)
     i64 self_release_max_bytes = (i64)64 << 20;  // ... when the destination is at most this big (beyond, a launch lasts far longer than its fences)
@@ -394,6 +395,7 @@ void eager_request_sys_acquire(hipStream_t s);
 long eager_stat(int which);
 bool eager_available(hipStream_t s);              // (of the stream's device)
 int eager_fence_if_active();
+bool eager_recent_writes_fit(uintptr_t dest_lo, uintptr_t dest_hi);  // smr_seq.cpp: the eager path's "are the recent destinations cache-resident" estimate
 void mark_sliceable(int kind, unsigned off, unsigned row);  // applies to the NEXT recorded launch of the calling thread (no-op when nothing records)
 void mark_self_released();                                  // likewise: RecLaunch::self_released
 void take_slice_mark(RecLaunch& r);

@@ -68,6 +68,23 @@ bool want_self_release(const Plan& plan) {
     }
     return (hi - lo + 1) * (i64)c.esize[0] <= o.self_release_max_bytes;
 }
+// Eager path: is the recent write set of this process small enough to stay in the Infinity Cache?  (Write-through stores pay off
+// while the destinations are cache-resident and lose on partial lines that go to HBM: profiles/r05_bench_n1.json, cold 4-way sum.)
+// A 16-slot direct-mapped table of recently written destinations (base address -> bytes); O(1) per call.
+bool eager_recent_writes_fit(uintptr_t dest_lo, uintptr_t dest_hi) {
+    static std::mutex mu;
+    static uintptr_t key[16] = {};
+    static size_t bytes[16] = {}, total = 0;
+    std::lock_guard<std::mutex> g(mu);
+    const unsigned slot = (unsigned)((dest_lo >> 12) * 0x9E3779B1u >> 28) & 15u;
+    if (key[slot] != dest_lo || bytes[slot] != dest_hi - dest_lo) {
+        total -= bytes[slot];
+        key[slot] = dest_lo;
+        bytes[slot] = dest_hi - dest_lo;
+        total += bytes[slot];
+    }
+    return (i64)total <= options().self_release_max_total;
+}
 static thread_local int tl_slice_kind = 0;
 static thread_local unsigned tl_slice_off = 0, tl_slice_row = 0;
 void mark_sliceable(int kind, unsigned off, unsigned row) {
@@ -1103,7 +1120,11 @@ int eager_submit(const Plan& plan, std::vector<RecLaunch>& launches, const std::
         pk.completion_signal = si >= 0 ? q.sigs[si] : hsa_signal_t{0};
         // agent-scope fences like HIP's between kernels (the argument block is host-coherent memory, never cached in L2); the first
         // launch after a copy acquires at system scope
-        if (!put_packet(d, hq, &pk, header_of(true, ((e.sys_acquire >> target) & 1u) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT), pk.setup)) return SMR_EHIP;
+        // (a self-released launch -- write-through stores, acknowledged before its waves end -- leaves nothing dirty in an L2: no release)
+        if (!put_packet(d, hq, &pk,
+                        header_of(true, ((e.sys_acquire >> target) & 1u) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT, l.self_released ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT),
+                        pk.setup))
+            return SMR_EHIP;
         e.sys_acquire &= ~(1u << target);
         Inflight f;
         f.sig = si;
