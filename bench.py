@@ -442,6 +442,25 @@ def main():
                        "smr_seq_run + smr_seq_wait (the replay does not run on a HIP stream); eager_*: 1000 steps issued call by call from Python, wall clock "
                        "including the final synchronisation")
     check_outputs("after the long replays")
+    # the same kernels replayed ALONE by the library (its own AQL packets: self-released launch, no fences inside the replay), host
+    # wall clock / launches: what a launch costs where the library dispatches itself (a sequence, a library-owned stream)
+    def replay_alone_us(plan, opts, nl=2000):
+        q = S.Sequence().add(plan)
+        for k, v in opts.items():
+            q.set(k, v)
+        stq = S.Stream()
+        q.run(50, stq.handle); q.wait()
+        best = 1e30
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            q.run(nl, stq.handle); q.wait()
+            best = min(best, time.perf_counter() - t)
+        del q
+        stq.close()
+        return round(best / nl * 1e6, 3)
+    replay = {name: {"one_queue_us": replay_alone_us(pl, {"queues": 1, "slices": 1}), "cut_in_two_us": replay_alone_us(pl, {"queues": 2, "slices": 2})}
+              for name, pl in (("permutedims", plan2), ("broadcast4", plan3))} if use_seq else {}
     dom = ("broadcast4", ms3, bytes3, plan3) if ms3 >= ms2 else ("permutedims", ms2, bytes2, plan2)
     achieved = dom[2] / (dom[1] * 1e-3) / 1e9
     traffic = None
@@ -461,8 +480,12 @@ def main():
             "broadcast4": {"us": round(ms3 * 1e3, 3), "us_median": round(med3 * 1e3, 3), "GB/s": round(bytes3 / (ms3 * 1e-3) / 1e9, 1),
                            "frac": round(bytes3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan": plan3.describe()},
         },
+        "library_replay_alone": replay,
         "note": "32^4 f64 = 8 MiB in + 8 MiB out per launch: the working set is L2/Infinity-Cache resident across "
-                "back-to-back launches, so 'achieved' is effective (algorithmic bytes / launch time), not DRAM traffic",
+                "back-to-back launches, so 'achieved' is effective (algorithmic bytes / launch time), not DRAM traffic. 'achieved' / 'frac' / "
+                "'per_kernel' time the kernel as ANY caller launches it through HIP (HIP events on the launch stream, hipGraph of 500 launches: "
+                "the figure rocprofv3 can be compared with); 'library_replay_alone' is the same kernel replayed alone by the library's own "
+                "dispatch (host wall clock; HIP events cannot see those queues)",
     }
 
     extra = {}

@@ -310,11 +310,16 @@ void direct_fail(Direct& d, const std::string& why) {
     if (first) d.fail_why = why;
     d.ok = false;
     d.why = "direct dispatch failed earlier: " + d.fail_why;
+    // a holding kernel on some HIP stream may be polling the replay's completion signals (asynchronous smr_seq_run): let it go
+    for (int k = 0; k < SEQ_MAXQ; ++k)
+        if (d.q[k] && d.done_ptr[k]) hsa().signal_store_relaxed(d.done[k], 0);
     set_error(SMR_EHIP, "direct dispatch: " + d.fail_why);
 }
 
-// Bounded wait for a completion signal.  false: the queue reported an error or the time ran out -- the device's direct path is
-// marked failed (the caller unwinds; nothing waits on these queues again).
+// Bounded wait for a completion signal.  false: the queue reported an error or NOTHING MOVED for the time limit -- the device's
+// direct path is marked failed (the caller unwinds; nothing waits on these queues again).  The limit is on the absence of progress,
+// not on the wait: a replay of a million launches is allowed to take its time, the clock restarts whenever any of the device's
+// queues has consumed packets since the last look.
 bool wait_signal(Direct& d, hsa_signal_t sig) {
     Hsa& h = hsa();
     if (h.signal_load(sig) == 0) return true;
@@ -322,7 +327,11 @@ bool wait_signal(Direct& d, hsa_signal_t sig) {
         direct_fail(d, "the HSA queue reported an error");
         return false;
     }
-    const double t0 = now_s(), limit = direct_timeout_s();
+    double t0 = now_s();
+    const double limit = direct_timeout_s();
+    uint64_t seen[SEQ_MAXQ] = {};
+    for (int k = 0; k < SEQ_MAXQ; ++k)
+        if (d.q[k]) seen[k] = h.load_read_index(d.q[k]);
     for (;;) {
         // timeout hint in timestamp ticks (100 MHz on this part: ~2 ms per slice)
         if (h.signal_wait(sig, HSA_SIGNAL_CONDITION_EQ, 0, 200000, HSA_WAIT_STATE_ACTIVE) == 0) return true;
@@ -330,8 +339,16 @@ bool wait_signal(Direct& d, hsa_signal_t sig) {
             direct_fail(d, "the HSA queue reported an error");
             return false;
         }
+        for (int k = 0; k < SEQ_MAXQ; ++k)
+            if (d.q[k]) {
+                const uint64_t r = h.load_read_index(d.q[k]);
+                if (r != seen[k]) {
+                    seen[k] = r;
+                    t0 = now_s();
+                }
+            }
         if (now_s() - t0 > limit) {
-            direct_fail(d, "a completion signal did not arrive within the time limit ($SMR_DIRECT_TIMEOUT_MS)");
+            direct_fail(d, "no hardware queue made progress and the completion signal did not arrive within the time limit ($SMR_DIRECT_TIMEOUT_MS)");
             return false;
         }
     }
@@ -1800,10 +1817,16 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
     std::lock_guard<std::mutex> g(d.mu);
     // the previous replay on these queues must have completed before the completion signals are re-armed
     if (int rc = wait_all(d)) return rc;
-    // whatever the caller queued on `stream` before comes first
-    hipError_t e = hipStreamQuery(s);
-    if (e == hipErrorNotReady) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return hip_error(e, "smr_seq_run: draining the caller's stream");
+    // whatever the caller queued on `stream` before comes first (a library-owned stream holds HIP work only when the library put it
+    // there: a copy, a fallback launch -- tracked per stream; nothing pending = nothing to ask HIP about)
+    hipError_t e = hipSuccess;
+    const bool owned_idle = seq_stream_is_owned(s) && eager_of(q->device).hip_pending.count(s) == 0;
+    if (!owned_idle) {
+        e = hipStreamQuery(s);
+        if (e == hipErrorNotReady) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return hip_error(e, "smr_seq_run: draining the caller's stream");
+        eager_of(q->device).hip_pending.erase(s);
+    }
     int rc = seq_submit(q, d, reps);
     if (rc) return rc;
     q->inflight = true;
@@ -1841,8 +1864,9 @@ int smr_seq_run(smr_seq* q, int reps, void* stream) {
         if (d.armed[k] && !d.done_ptr[k]) all_have_ptr = false;
     if (all_have_ptr && n > 0) {
         (void)hipGetLastError();
-        // 100 MHz device clock: the limit in ticks
-        const unsigned long long limit = (unsigned long long)(direct_timeout_s() * 1e8);
+        // 100 MHz device clock: the kernel's own limit in ticks -- a backstop far above the host's no-progress limit (a host that
+        // declares the path failed zeroes the signals, which releases the kernel: direct_fail)
+        const unsigned long long limit = (unsigned long long)(std::max(direct_timeout_s() * 20.0, 600.0) * 1e8);
         hipLaunchKernelGGL(k_seq_hold, dim3(1), dim3(64), 0, s, (const volatile long long* const*)hb->sigs, n, limit, hb->gave_up);
         if (hipGetLastError() == hipSuccess) {
             q->held = true;
