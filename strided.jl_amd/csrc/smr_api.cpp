@@ -919,6 +919,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "overlap_window_hip") o.overlap_window_hip = value;
     else if (n == "tiled_gorder") o.tiled_gorder = value;
     else if (n == "tiled_xpose") o.tiled_xpose = value;
+    else if (n == "stream_ua") o.stream_ua = value;
     else if (n == "allreduce_f64") o.allreduce_f64 = value;
     else if (n == "self_release_max_bytes") o.self_release_max_bytes = value;
     else if (n == "self_release_max_total") o.self_release_max_total = value;
@@ -1010,6 +1011,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "overlap_window_hip") return o.overlap_window_hip;
     if (n == "tiled_gorder") return o.tiled_gorder;
     if (n == "tiled_xpose") return o.tiled_xpose;
+    if (n == "stream_ua") return o.stream_ua;
     if (n == "allreduce_f64") return o.allreduce_f64;
     if (n == "launches") return g_launches.load();
     if (n == "allreduces") return comm_stat(0);

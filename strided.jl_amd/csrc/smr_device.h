@@ -86,12 +86,14 @@ template <> struct tr<b16> { typedef float real; static constexpr bool cx = fals
 // packet processor) has nothing left to do, and a recorded sequence drops it (smr_seq.cpp).  A later reader still acquires.
 template <bool NT, class VT>
 SMR_DEV void store_vec_ct(char* p, const VT& v) {
+    // (the vector types carry 4-byte alignment: callers may hand in element-aligned addresses -- STREAM's UVec -- and the hardware
+    // takes dwordx2 / dwordx4 accesses at any dword address; the instruction selected is the same)
     if constexpr (NT && sizeof(VT) == 16) {
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(p));
+        typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
+        __builtin_nontemporal_store(*reinterpret_cast<const u4a*>(&v), reinterpret_cast<u4a*>(p));
     } else if constexpr (NT && sizeof(VT) == 8) {
-        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-        __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(p));
+        typedef uint32_t u2a __attribute__((ext_vector_type(2), aligned(4)));
+        __builtin_nontemporal_store(*reinterpret_cast<const u2a*>(&v), reinterpret_cast<u2a*>(p));
     } else if constexpr (NT && sizeof(VT) == 4) {
         __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(p));
     } else {

@@ -207,6 +207,7 @@ struct Plan {
     // STREAM
     int vec = 1;        // elements per vector access
     // reductions
+    bool vec_ua = false;      // STREAM: `vec` elements per access at ELEMENT alignment, rows end in a partial vector (round 5)
     mutable bool eager_seen = false;  // the plan's device tables (uploaded by hipMemcpy on its first execution) have been made visible to the direct queues
     void* scratch = nullptr;  // partials (owned), followed by RED_COUNTERS arrival counters (zero between launches)
     size_t scratch_bytes = 0;
@@ -282,6 +283,7 @@ struct Options {
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
+    i64 stream_ua = 1;          // STREAM: element-aligned 16-byte vectors + a partial vector per row for rows that are not whole aligned vectors
     i64 tiled_xpose = 1;        // HBM-sized transposing copies (one staged input, 128 x 32 tiles, whole tiles, 8- / 16-byte elements) run the lean kernel k_xpose_big
     i64 tiled_gorder = -1;      // TILED grid-dim order: 0 canonical, 1 the staged input's split unit axis second, -1 = that for HBM-sized 128 x 32 transposes
     i64 overlap_window_hip = 0; // 1: launches of an overlap window that go through HIP carry hipExtAnyOrderLaunch when independent (ignored by HIP on gfx9: default off)

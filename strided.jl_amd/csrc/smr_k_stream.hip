@@ -13,7 +13,9 @@ namespace smr {
 struct StreamArgs {
     OpTab ops;
     int32_t N, M;
-    i64 n0v;   // vectors along dim 0
+    i64 n0v;   // whole vectors along dim 0
+    i64 n0t;   // column slots along dim 0 = n0v, + 1 when the rows end in a partial vector (round 5)
+    int32_t tail, pad2;  // elements of that partial vector (0 < tail < V), 0: rows are whole vectors
     i64 rows;  // product of the outer dims
     i64 bpr;   // workgroups per row
     int32_t txlog, nts;   // nts: non-temporal stores (big streaming outputs, Options::nt_store); txlog 8: a workgroup covers U x 256 vectors of ONE row; < 8 (short rows): 2^txlog lanes
@@ -26,6 +28,14 @@ struct StreamArgs {
 
 template <class T, int V>
 struct alignas(sizeof(T) * V) Vec {
+    T v[V];
+};
+// the same 16 bytes with ELEMENT alignment: what the global accesses use.  The hardware takes a dwordx4 access at any dword address
+// (the compiler emits it for align 4 / 8: checked in the ISA), so rows that start at odd element offsets -- odd row lengths, views
+// that begin in the middle of a vector -- move as vectors too, plus one partial vector per row (round 5; before: 8-byte accesses,
+// (257,129,65) (0,2,1) 2.66 TB/s)
+template <class T, int V>
+struct alignas(sizeof(T)) UVec {
     T v[V];
 };
 
@@ -60,7 +70,9 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
         }
     }
     typedef Vec<T, V> VT;
+    typedef UVec<T, V> GT;  // global-memory view of a vector
     VT in[U][MAXIN];
+    bool part[U];           // this slot is the partial vector at the end of its row
     i64 col[U];
     i64 joff[U][MAXM];  // offset of this lane's dim-1 entry (short-row form), 0 otherwise
     bool live[U];
@@ -69,21 +81,22 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
         i64 j = 0;
         if (flat) {
             col[u] = (cb * U + u) * 256 + threadIdx.x;
-            live[u] = col[u] < a.n0v;
+            live[u] = col[u] < a.n0t;
         } else {
             if constexpr (FORM == 2) {
                 const int cc = u % ncc, jj = u / ncc;
                 col[u] = tx + ((i64)cc << 8);
                 j = cb * rpw + jj;
-                live[u] = col[u] < a.n0v && j < a.dims[1] && jj < rpw;
+                live[u] = col[u] < a.n0t && j < a.dims[1] && jj < rpw;
             } else {
                 col[u] = tx;
                 j = (cb * U + u) * TY + ty;
-                live[u] = tx < a.n0v && j < a.dims[1];
+                live[u] = tx < a.n0t && j < a.dims[1];
             }
         }
 #pragma unroll
         for (int k = 0; k < MAXM; ++k) joff[u][k] = (k < a.M) ? (flat ? roff[k] : roff[k] + j * a.strides[k][1]) : 0;
+        part[u] = V > 1 && a.tail != 0 && col[u] == a.n0v;
         if (live[u]) {
 #pragma unroll
             for (int k = 0; k < MAXIN; ++k) {
@@ -95,7 +108,15 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
                     } else if constexpr (MIXED || V == 1) {
                         in[u][k].v[0] = load_op<T, MIXED>(a.ops, k + 1, joff[u][k + 1] + col[u] * a.strides[k + 1][0]);
                     } else {
-                        in[u][k] = *reinterpret_cast<const VT*>((const T*)a.ops.base[k + 1] + joff[u][k + 1] + col[u] * V);
+                        const T* src = (const T*)a.ops.base[k + 1] + joff[u][k + 1] + col[u] * V;
+                        if (!part[u]) {
+                            const GT g = *reinterpret_cast<const GT*>(src);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) in[u][k].v[e] = g.v[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) in[u][k].v[e] = e < a.tail ? src[e] : T{};
+                        }
                         if constexpr (tr<T>::cx) {
                             if (a.ops.conj[k + 1]) {
 #pragma unroll
@@ -138,7 +159,12 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
         auto put = [&](auto NT) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (live[u]) store_vec_ct<decltype(NT)::value, VT>(reinterpret_cast<char*>((T*)a.ops.base[0] + joff[u][0] + col[u] * V), out[u]);
+                if (live[u] && !part[u]) {
+                    GT g;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] = out[u].v[e];
+                    store_vec_ct<decltype(NT)::value, GT>(reinterpret_cast<char*>((T*)a.ops.base[0] + joff[u][0] + col[u] * V), g);
+                }
         };
         if (a.nts) {
             nt_block_guard();
@@ -146,6 +172,16 @@ SMR_DEV void stream_map_body(const StreamArgs a, F f) {
             nt_block_guard();
         } else {
             put(BoolC<false>{});
+        }
+        if (a.tail != 0) {  // the partial vector at the end of a row: element by element
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (live[u] && part[u]) {
+                    T* dst = (T*)a.ops.base[0] + joff[u][0] + col[u] * V;
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+                        if (e < a.tail) dst[e] = out[u].v[e];
+                }
         }
     }
 }
@@ -173,6 +209,8 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.N = c.N;
     a.M = c.M;
     a.n0v = c.dims[0] / V;
+    a.tail = (int32_t)(c.dims[0] % V);
+    a.n0t = a.n0v + (a.tail ? 1 : 0);
     {
         // Vector stores of this family are non-temporal at EVERY size (nt_stream_min = 0).  Measured
         // (profiles/r02_nt_store_ab.txt): configs[4] 8192^2 f32 91.8 -> 80.2 us, 2048^2 copy 5.38 -> 3.88 us, and a
@@ -188,15 +226,15 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.txlog = 8;
     a.ncc = 1;
     a.packed = 0;
-    if (c.N >= 2 && a.n0v <= 128) {
+    if (c.N >= 2 && a.n0t <= 128) {
         a.txlog = 0;
-        while ((1 << a.txlog) < a.n0v) ++a.txlog;
+        while ((1 << a.txlog) < a.n0t) ++a.txlog;
         a.packed = 1;
-    } else if (c.N >= 2 && U >= 2 && a.n0v <= 128 * U && options().stream_pack_rows) {
+    } else if (c.N >= 2 && U >= 2 && a.n0t <= 128 * U && options().stream_pack_rows) {
         // measured (tools/stream_pack_ab.py, profiles/r04_stream_pack_ab.txt): one or two column chunks per row win (rows of 257 Float64
         // 13.5 -> 12.0 us, 300 / 400 11.5 -> 8.4 us, Float32 rows of 700 / 1000 11.9 -> 8.7 / 12.2 -> 10.7 us), three lose
         // (513, 561: 15.3 -> 18.0 us), and so do problems that are left with fewer than ~1000 workgroups ((257,33,31): 3.3 -> 4.4 us)
-        const int ncc = (int)((a.n0v + 255) / 256);
+        const int ncc = (int)((a.n0t + 255) / 256);
         i64 nrows = 1;
         for (int i = 1; i < c.N; ++i) nrows *= c.dims[i];
         if (ncc <= 2 && nrows / (U / ncc) >= 1024) {
@@ -207,7 +245,7 @@ static int go(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     a.rows = 1;
     for (int i = (a.packed ? 2 : 1); i < c.N; ++i) a.rows *= c.dims[i];
     const i64 rows_per_wg = (i64)(256 >> a.txlog) * (U / a.ncc);
-    a.bpr = !a.packed ? (a.n0v + 256 * U - 1) / (256 * U) : (c.dims[1] + rows_per_wg - 1) / rows_per_wg;
+    a.bpr = !a.packed ? (a.n0t + 256 * U - 1) / (256 * U) : (c.dims[1] + rows_per_wg - 1) / rows_per_wg;
     for (int i = 0; i < MAXN; ++i) a.dims[i] = (i < c.N) ? c.dims[i] : 1;
     for (int k = 0; k < MAXM; ++k)
         for (int i = 0; i < MAXN; ++i) a.strides[k][i] = (k < c.M && i < c.N) ? c.strides[k][i] : 0;
@@ -244,9 +282,10 @@ static int go_vec(const Plan& plan, void* const* bases, hipStream_t s, F f) {
     constexpr int VMAX = (sizeof(T) >= 16) ? 1 : (int)(16 / sizeof(T));
     if constexpr (VMAX > 1) {
         if (plan.vec == VMAX) {
-            // the plan chose vectors for the pointers it was created with; re-check rebound ones
+            // the plan chose vectors for the pointers it was created with; re-check rebound ones (element-aligned vectors --
+            // Plan::vec_ua -- take any element address)
             bool aligned = true;
-            if (bases) {
+            if (bases && !plan.vec_ua) {
                 const OpTab tab = make_optab(plan.c, bases);
                 for (int k = 0; k < plan.c.M; ++k)
                     if (plan.c.strides[k][0] != 0 && ((uintptr_t)tab.base[k]) % 16) aligned = false;

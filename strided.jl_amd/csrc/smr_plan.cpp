@@ -1622,6 +1622,23 @@ int make_plan(const smr_problem* p, Plan& plan) {
             v >>= 1;
         }
         plan.vec = v;
+        plan.vec_ua = false;
+        // Round 5: rows that are not whole aligned vectors (odd lengths, odd row strides, views starting inside a vector) still move
+        // as 16-byte vectors -- at element alignment, plus one partial vector per row (smr_k_stream.hip: UVec) -- when the elements
+        // are 4 or 8 bytes and a row holds at least four vectors.
+        {
+            const int vmax = (c.mixed || es >= 16) ? 1 : 16 / es;
+            bool unit = true;
+            for (int k = 0; k < c.M; ++k)
+                if (c.strides[k][0] != 1 && c.strides[k][0] != 0) unit = false;
+            // (short rows with a long tail lose: rows of 63 Float32 = 15 vectors + 3 single elements 24.9 -> 27.1 us; rows of 17
+            // Float64 = 8 vectors + 1 element gain 9 %: a tail of one element, or at least 32 vectors per row.  tools/stream_ua_ab.py,
+            // profiles/r05_stream_ua_ab.txt: (257,129,65) (0,2,1) 12.3 -> 9.5 us, (999,1001) axpy 4.7 -> 3.1 us, (1001,999,5) f32 10.9 -> 8.0)
+            if (o.stream_ua && v < vmax && unit && es >= 4 && c.dims[0] >= 4 * vmax && (c.dims[0] % vmax <= 1 || c.dims[0] >= 32 * vmax)) {
+                plan.vec = vmax;
+                plan.vec_ua = true;
+            }
+        }
     }
     if (fam == FAM_REDUCE_ALL || fam == FAM_REDUCE_PART) {
         const int es = dtype_size(c.ct);
@@ -1808,7 +1825,7 @@ void describe(Plan& plan) {
         n += std::snprintf(buf + n, sizeof buf - n, " flat_side=%s run=%dx%d(d%d)%s line=d%d:%d", fp.dir == 0 ? "dest" : "input", fp.R, 1 << fp.tplog, fp.p,
                            fp.fuse ? "+line" : (fp.lshare ? " shared-lead" : ""), fp.q, 1 << fp.tqlog);
     } else if (plan.family == FAM_STREAM) {
-        n += std::snprintf(buf + n, sizeof buf - n, " vec=%d", plan.vec);
+        n += std::snprintf(buf + n, sizeof buf - n, " vec=%d%s", plan.vec, plan.vec_ua ? "(element-aligned+tail)" : "");
     } else if (plan.family == FAM_REDUCE_ALL) {
         n += std::snprintf(buf + n, sizeof buf - n, " blocks=%d", plan.red_blocks);
     } else if (plan.family == FAM_REDUCE_PART) {

@@ -367,3 +367,59 @@ def test_hbm_sized_transposing_copies_lean_kernel_and_grid_order_are_bit_exact(s
         p.execute(cur())
         torch.cuda.synchronize()
         assert torch.equal(tB, 3 * want)
+
+
+@pytest.mark.parametrize("shape,perm,dt", [((257, 129, 65), (0, 2, 1), "float64"), ((17, 33, 65, 31), (0, 2, 1, 3), "float64"),
+                                           ((999, 77), (0, 1), "float32"), ((1001, 5, 9), (0, 2, 1), "float32"),
+                                           ((35, 64, 7), (0, 2, 1), "complex64"), ((131, 40, 3), (0, 2, 1), "int32")])
+def test_rows_that_are_not_whole_aligned_vectors_move_as_vectors_plus_a_tail(shape, perm, dt):
+    """STREAM, round 5: odd row lengths / rows starting at odd element offsets use 16-byte accesses at element alignment and one
+    partial vector per row; compared with the scalar form (option stream_ua = 0) and with NumPy; also an n-ary map, a view that starts
+    inside a vector, and a broadcast operand."""
+    import torch
+    rng = np.random.default_rng(11)
+    npdt = np.dtype(dt)
+    if npdt.kind == "c":
+        a = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(npdt)
+    elif npdt.kind == "i":
+        a = rng.integers(-1000, 1000, shape).astype(npdt)
+    else:
+        a = rng.standard_normal(shape).astype(npdt)
+    A = dview(a)
+    want = np.transpose(a, perm)
+    for ua in (1, 0):
+        S.set_option("stream_ua", ua)
+        try:
+            B = dview(np.zeros(want.shape, dtype=npdt))
+            p = S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims(perm)))
+            d = p.describe()
+            assert "family=stream" in d, d
+            vmax = 16 // npdt.itemsize
+            if ua and npdt.itemsize in (4, 8) and shape[0] >= 4 * vmax and (shape[0] % vmax <= 1 or shape[0] >= 32 * vmax) and npdt.kind != "c":
+                assert "element-aligned+tail" in d, d
+            p.execute(cur())
+            torch.cuda.synchronize()
+            assert np.array_equal(host(B), want), (ua, d)
+        finally:
+            S.set_option("stream_ua", 1)
+    if npdt.kind == "f":
+        # n-ary map with a broadcast operand (stride 0 along dim 0) and a view that starts one element into the parent
+        b = rng.standard_normal(want.shape).astype(npdt)
+        col = rng.standard_normal((1,) + want.shape[1:]).astype(npdt)
+        Bv, Cv = dview(b), dview(col)
+        out = dview(np.zeros(want.shape, dtype=npdt))
+        colb = S.StridedView(Cv.parent, want.shape, (0,) + Cv.strides[1:], 0)
+        p = S.make_plan(lambda x, y, z: x * 2 + y - z, None, None, out.size, (out, A.permutedims(perm), Bv, colb))
+        p.execute(cur())
+        torch.cuda.synchronize()
+        assert np.array_equal(host(out), want * 2 + b - col), p.describe()
+        # a sub-view that drops the first and the last element of every row: starts inside a vector, odd or even length
+        n0 = want.shape[0]
+        big = dview(np.zeros(want.shape, dtype=npdt))
+        sub_out = S.StridedView(big.parent, (n0 - 2,) + want.shape[1:], big.strides, 1)
+        sub_in = S.StridedView(Bv.parent, (n0 - 2,) + want.shape[1:], Bv.strides, 1)
+        p = S.make_plan(lambda x: x + 1, None, None, sub_out.size, (sub_out, sub_in))
+        p.execute(cur())
+        torch.cuda.synchronize()
+        got = host(big)
+        assert np.array_equal(got[1:-1], b[1:-1] + 1) and np.all(got[0] == 0) and np.all(got[-1] == 0), p.describe()
