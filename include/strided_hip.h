@@ -426,7 +426,19 @@ int smr_mapreduce_sharded_ex(const smr_problem* problem, uint32_t local_ops);
  * smr_get_option: "jit_compiles", "jit_hits", "jit_failures", "jit_compile_ms", "overlap_any" / "overlap_ordered" /
  * "overlap_fences" (launches dispatched without / with the barrier bit inside overlap windows, fences issued); "eager_launches",
  * "eager_free" / "eager_same" / "eager_cross" (direct launches; executions that conflicted with nothing / one queue / several),
- * "eager_fallback" (executions sent through HIP).      */
+ * "eager_fallback" (executions sent through HIP).
+ * Round 5: "seq_self_release" (1: launches recorded for a sequence issue agent-scope write-through stores where the family can and
+ * their packets carry no release fence), "eager_self_release" (1: the same on library-owned streams), "self_release_max_bytes"
+ * (64 MiB: largest destination for which that is done), "self_release_max_total" (128 MiB: largest footprint of a whole sequence /
+ * of the recently written destinations), "nt_store" = 2 (force write-through stores), "tiled_gorder" (-1: HBM-sized transposing
+ * copies walk the tile index along the input's unit axis second; 0 canonical; 1 always), "tiled_xpose" (1: the lean kernel for
+ * HBM-sized transposing copies), "stream_ua" (1: element-aligned 16-byte vectors + a partial vector per row in STREAM),
+ * "allreduce_f64" (0; 1: Float32 / ComplexF32 sums cross the ranks as Float64), "overlap_window_hip" (0; see smr_overlap_begin),
+ * "orbit_deal" (experiment).  Read-only: "launches" (kernel launches the library issued, through HIP or directly), "allreduces",
+ * "allreduces_inplace".  Environment: $SMR_DIRECT_TIMEOUT_MS (30000: no-progress limit of waits on the direct queues),
+ * $SMR_DIRECT_SELFTEST (0 skips, "fail" forces the failure path), $SMR_DIRECT_METADATA (0: code-object-v5 rule instead of the
+ * metadata), $SMR_SEQ_DIRECT (0: sequences replay through HIP), $SMR_SEQ_STREAM_WAIT (1: hipStreamWaitValue64 where supported),
+ * $SMR_RCCL_LIB (which collective library to dlopen).      */
 int smr_set_option(const char* name, int64_t value);
 int64_t smr_get_option(const char* name);
 
