@@ -278,6 +278,11 @@ int smr_seq_info(smr_seq* seq, char* buf, size_t buflen);
 /* The dependency analysis alone (host arithmetic on strides and base pointers, no device needed): comp[i] = dependency component
  * of recorded execution i (numbered in order of first appearance); returns the number of components or a negative status.      */
 int smr_seq_components(smr_seq* seq, int32_t* comp, size_t cap);
+/* The fence analysis alone (host arithmetic too): acquire[i] = 1 when execution i reads bytes some execution of the sequence writes
+ * (only those packets acquire inside a replay), *footprint = bytes of the union of every range the sequence touches,
+ * *cache_resident = 1 when that is within option "self_release_max_total" (launches may then be self-released).  Returns the number
+ * of recorded executions or a negative status.                                                                                       */
+int smr_seq_fences(smr_seq* seq, int32_t* acquire, size_t cap, int64_t* footprint, int32_t* cache_resident);
 /* "queues" (1..8, default 4: hardware queues a replay may spread over; 1 = everything in recorded order on one queue; more than 4
  * are time-multiplexed by the hardware scheduler); "slices" (-1 | 1..8: a component that consists of ONE launch of independent
  * workgroups is cut into that many contiguous block ranges, one queue each -- the device form of _mapreduce_threaded!'s bisection;

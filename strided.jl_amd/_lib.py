@@ -77,7 +77,7 @@ EXPORTS = [
     "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_plan_flat_batched", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank", "smr_comm_library",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option", "smr_overlap_begin", "smr_overlap_end", "smr_overlap_fence", "smr_stream_create", "smr_stream_destroy",
-    "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_components", "smr_seq_set", "smr_seq_destroy", "smr_debug_kernarg_layout",
+    "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_components", "smr_seq_fences", "smr_seq_set", "smr_seq_destroy", "smr_debug_kernarg_layout",
 ]
 
 
@@ -171,6 +171,7 @@ def load():
     lib.smr_seq_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.smr_seq_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.smr_seq_components.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_size_t]
+    lib.smr_seq_fences.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.smr_seq_destroy.argtypes = [C.c_void_p]
     if lib.smr_abi_version() != 1:
         raise ImportError("libstrided_hip.so ABI version mismatch; rebuild")
@@ -289,6 +290,16 @@ class Sequence:
         if rc < 0:
             check(rc)
         return list(buf)[:n]
+
+    def fences(self):
+        """(acquire flags per recorded execution, footprint in bytes, cache-resident?) -- host-only analysis of what a replay fences."""
+        n = len(self._keep)
+        buf = (C.c_int32 * max(1, n))()
+        fp, res = C.c_int64(0), C.c_int32(0)
+        rc = self._lib.smr_seq_fences(self._h, buf, n, C.byref(fp), C.byref(res))
+        if rc < 0:
+            check(rc)
+        return list(buf)[:n], int(fp.value), bool(res.value)
 
     def __del__(self):
         try:

@@ -1932,6 +1932,37 @@ int smr_seq_components(smr_seq* q, int32_t* comp, size_t cap) {
     return n;
 }
 
+// Host-only view of the fence analysis (no device needed): acquire[i] = 1 when recorded execution i reads bytes some execution of the
+// sequence writes (its packets acquire inside a replay; all others do not), *footprint = bytes of the union of every range the
+// sequence touches, *cache_resident = 1 when that is within "self_release_max_total" (launches may then be self-released).
+int smr_seq_fences(smr_seq* q, int32_t* acquire, size_t cap, int64_t* footprint, int32_t* cache_resident) {
+    if (!q) return set_error(SMR_EINVAL, "null sequence");
+    const size_t ni = q->items.size();
+    std::vector<Spans> rd(ni), wr(ni);
+    for (size_t i = 0; i < ni; ++i) seq_footprint(q->items[i].plan, q->items[i].has_bases ? q->items[i].bases : nullptr, rd[i], wr[i]);
+    for (size_t i = 0; i < ni && i < cap; ++i) {
+        int raw = 0;
+        for (size_t j = 0; j < ni && !raw; ++j)
+            if (overlaps(wr[j], rd[i])) raw = 1;
+        if (acquire) acquire[i] = raw;
+    }
+    Spans all;
+    for (size_t i = 0; i < ni; ++i) {
+        all.insert(all.end(), rd[i].begin(), rd[i].end());
+        all.insert(all.end(), wr[i].begin(), wr[i].end());
+    }
+    std::sort(all.begin(), all.end());
+    uintptr_t total = 0, hi = 0;
+    for (const auto& x : all) {
+        const uintptr_t lo = std::max(x.first, hi);
+        if (x.second > lo) total += x.second - lo;
+        hi = std::max(hi, x.second);
+    }
+    if (footprint) *footprint = (int64_t)total;
+    if (cache_resident) *cache_resident = (i64)total <= options().self_release_max_total ? 1 : 0;
+    return (int)ni;
+}
+
 int smr_seq_set(smr_seq* q, const char* name, int64_t value) {
     if (!q || !name) return set_error(SMR_EINVAL, "null argument");
     if (std::strcmp(name, "fence_scope") == 0 && value >= 0 && value <= 2) {  // both fences of every inner packet at one scope

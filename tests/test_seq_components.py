@@ -99,3 +99,35 @@ def test_rebound_base_pointers_decide():
     for i in (0, 1, 2, 1):
         q.add(p, bases=[pool[i].ctypes.data, a.ctypes.data])
     assert q.components() == [0, 1, 2, 1]
+
+
+def test_which_packets_acquire_and_when_launches_may_be_self_released():
+    """Round 5 (csrc/smr_seq.cpp): inside a replay only executions that READ what the sequence WRITES acquire; launches are
+    self-released (write-through stores, no release fence) only while the whole footprint fits half the Infinity Cache."""
+    n = 16
+    a = np.zeros((n,) * 4, order="F")
+    A, B, C = view(a), view(np.zeros_like(a)), view(np.zeros_like(a))
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    p2 = copy_plan(B, A.permutedims((3, 2, 1, 0)))
+    p3 = S.make_plan(lambda w, x, y, z: w + x + y + z, None, None, A.size, (C,) + tuple(A.permutedims(p) for p in perms))
+    acq, fp, resident = seq_of(p2, p3).fences()
+    assert acq == [0, 0] and resident                      # the bench step: nobody writes A
+    assert fp == 3 * a.nbytes                              # A, B, C once each (A's four views are one range)
+    m = np.zeros((40, 30), order="F")
+    X, Y, Z, ACC = (view(np.zeros_like(m)) for _ in range(4))
+    r1 = copy_plan(Y, X)                                   # reads X only
+    r2 = S.make_plan(lambda u, v: u + v, None, None, Z.size, (Z, Y, X))   # reads what r1 wrote
+    r3 = S.make_plan(lambda u, v: u + v, None, None, ACC.size, (ACC, ACC, Z))   # in place: reads its own destination
+    red = S.make_plan(lambda u: u, "+", None, X.size, (S.StridedView(np.zeros(1), X.size, (0, 0), 0), X))
+    assert seq_of(r1, r2, r3).fences()[0] == [0, 1, 1]
+    assert seq_of(r1, red).fences()[0] == [0, 1]           # a reduction accumulates into (reads) its destination
+    assert seq_of(r2, r1).fences()[0] == [1, 0]            # order in the list does not matter: the next replay's r2 follows this one's r1
+    big = np.zeros((4096, 4096), order="F")                # 128 MiB each: two of them exceed the 128 MiB default
+    P, Q = view(big), view(np.zeros_like(big))
+    acq, fp, resident = seq_of(copy_plan(Q, P.permutedims((1, 0)))).fences()
+    assert acq == [0] and fp == 2 * big.nbytes and not resident
+    S.set_option("self_release_max_total", 1 << 40)
+    try:
+        assert seq_of(copy_plan(Q, P.permutedims((1, 0)))).fences()[2]
+    finally:
+        S.set_option("self_release_max_total", 128 << 20)
