@@ -70,7 +70,10 @@ typedef enum {
  * (+ - * neg abs abs2 min max comparisons select, integer-valued constants; reductions + * min max & |),
  * the call computes in wrapping 64-bit two's-complement arithmetic like Julia's Int64 (sum of an Int64
  * view above 2^53, overflow wrap-around) and truncates on store to a narrower destination type (= the
- * wrapped result of Julia's arithmetic in that type for + - * chains).  UInt64 operands take part in ring
+ * wrapped result of Julia's arithmetic in that type for + - * chains); where Julia would observe a narrow
+ * intermediate result at its own width (an order / equality test on it, a conversion to a wider type, a wider
+ * destination) the library re-wraps the 64-bit value to that type (SMR_OP_WRAP_*, inserted by the planner),
+ * so Int32 a .* b into an Int64 array is the wrapped 32-bit product.  UInt64 operands take part in ring
  * operations only (no order: min / max / < / abs are refused with SMR_EUNSUPPORTED, as is any 64-bit integer
  * input that meets floating-point arithmetic).  Pure moves (copy!/permutedims!) of any integer width are
  * bit copies; integers mixed with floats compute in Float64.                                             */
@@ -140,6 +143,15 @@ typedef enum {
     SMR_OP_WIDEN = 22,   /* identity; its presence makes the call compute in the 64-bit class although no
                             operand is 64-bit: a Float64 / ComplexF64 scalar meets Float32 arrays
                             (`B32 .= A32 .* 0.1` multiplies in Float64 in Julia and rounds once on store) */
+    /* 23..28 are the library's own: a user program holding one is malformed (SMR_EINVAL).  The integer class inserts them where
+       Julia would have observed a narrow intermediate result at its own width (Int32 a .* b into an Int64 destination, UInt8
+       min(a - b, c), ...): the 64-bit value is reduced to its low 8 / 16 / 32 bits, sign- or zero-extended (csrc/smr_plan.cpp) */
+    SMR_OP_WRAP_I8 = 23,
+    SMR_OP_WRAP_I16 = 24,
+    SMR_OP_WRAP_I32 = 25,
+    SMR_OP_WRAP_U8 = 26,
+    SMR_OP_WRAP_U16 = 27,
+    SMR_OP_WRAP_U32 = 28,
     /* binary: pop b, pop a, push a (op) b */
     SMR_OP_ADD = 32,
     SMR_OP_SUB = 33,
@@ -300,6 +312,12 @@ int smr_seq_destroy(smr_seq* seq);
  * grid_dims, dynamic_lds_size offsets (-1 = not declared), needs_runtime, private_size, group_static.  `symbol` = "<mangled>.kd", or
  * NULL with index >= 0 to enumerate (the symbol is copied to name_out).  Returns the number of kernels, negative on a parse error. */
 int smr_debug_kernarg_layout(const void* elf, size_t bytes, const char* symbol, int index, int32_t* out, char* name_out, size_t name_cap);
+/* Test hook, host-only: the f-program the kernels of this problem would run -- the caller's program after canonicalisation, i.e.
+   with the SMR_OP_WRAP_* instructions of the integer class in place.  code receives min(2 * length, cap) bytes (opcode, immediate
+   pairs; SMR_OP_ARG immediates number the canonical operands: orig[j], SMR_MAXM entries, is the caller's index of operand j, -1 past
+   the end -- unused and repeated operands are dropped); *nwraps the number of added instructions, *compute_class the SMR_* dtype
+   computed in (-1: a bit copy).  Output pointers may be null.  Returns the length in instructions, or the (negative) error code. */
+int smr_debug_canon_prog(const smr_problem* problem, uint8_t* code, int cap, int* nwraps, int* compute_class, int32_t* orig);
 
 
 /* ---- the hot path --------------------------------------------------------------------- */

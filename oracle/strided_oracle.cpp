@@ -1000,7 +1000,7 @@ void julia_int_types(const smr_problem* p, Prog& prog) {
                 const bool bools = a.bits == 1 && b.bits == 1;
                 a = promote(a, b);
                 if (op == SMR_OP_ADD || op == SMR_OP_SUB || op == SMR_OP_MUL) {
-                    if (bools) a = Ty{64, true};
+                    if (bools && op != SMR_OP_MUL) a = Ty{64, true};  // Bool (+,-) Bool is an Int, Bool * Bool a Bool (base/bool.jl)
                     arith = true;
                 }
             }

@@ -77,7 +77,7 @@ EXPORTS = [
     "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_plan_flat_batched", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank", "smr_comm_library",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option", "smr_overlap_begin", "smr_overlap_end", "smr_overlap_fence", "smr_stream_create", "smr_stream_destroy",
-    "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_components", "smr_seq_fences", "smr_seq_set", "smr_seq_destroy", "smr_debug_kernarg_layout",
+    "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_components", "smr_seq_fences", "smr_seq_set", "smr_seq_destroy", "smr_debug_kernarg_layout", "smr_debug_canon_prog",
 ]
 
 

@@ -664,6 +664,20 @@ int smr_plan_describe(const smr_plan* plan, char* buf, size_t buflen) {
     return SMR_OK;
 }
 
+// the f-program the kernels will run, after canonicalisation (host-only: no device, no launch)
+int smr_debug_canon_prog(const smr_problem* problem, uint8_t* code, int cap, int* nwraps, int* compute_class, int32_t* orig) {
+    Canon c;
+    const int rc = canonicalise(problem, c);
+    if (rc) return rc;
+    if (nwraps) *nwraps = c.int_wraps;
+    if (compute_class) *compute_class = c.bitcopy ? -1 : c.ct;
+    if (orig)
+        for (int j = 0; j < SMR_MAXM; ++j) orig[j] = j < c.M ? c.orig[j] : -1;
+    if (code)
+        for (int i = 0; i < 2 * c.prog.len && i < cap; ++i) code[i] = c.prog.code[i];
+    return c.prog.len;
+}
+
 int64_t smr_plan_algorithmic_bytes(const smr_plan* plan) { return plan ? plan->plan.c.algbytes : 0; }
 
 int smr_mapreduce_scalar(const smr_problem* problem, void* host_result) {

@@ -266,6 +266,13 @@ template <> struct mathx<ix64> {
             case SMR_OP_ABS: return a < 0 ? (ix64)(U(0) - (U)a) : a;  // abs(typemin) = typemin, like Julia
             case SMR_OP_ABS2: return (ix64)((U)a * (U)a);
             case SMR_OP_IMAG: return 0;
+            // Julia's narrow integer types, where their wrapping would be observed (inserted by the planner, csrc/smr_plan.cpp)
+            case SMR_OP_WRAP_I8: return (ix64)(signed char)a;
+            case SMR_OP_WRAP_I16: return (ix64)(short)a;
+            case SMR_OP_WRAP_I32: return (ix64)(int)a;
+            case SMR_OP_WRAP_U8: return a & 0xff;
+            case SMR_OP_WRAP_U16: return a & 0xffff;
+            case SMR_OP_WRAP_U32: return a & 0xffffffffLL;
         }
         return a;  // conj, real, round32 / widen (never emitted for integers)
     }

@@ -113,6 +113,7 @@ struct Canon {
     int redop = 0, initop = 0;
     double initarg[2] = {0, 0};
     ProgD prog;
+    int int_wraps = 0;  // SMR_OP_WRAP_* instructions the integer class added to prog (0: the caller's program as given)
     int fkind = FK_PROG;
     double fc[4] = {0, 0, 0, 0};  // constants of the recognised functor: c=(fc0,fc1) d=(fc2,fc3)
     i64 total = 1;                // number of box elements

@@ -18,6 +18,9 @@ import strided_jl_amd as S
 from util import fview, run_oracle
 
 fn = S.fn
+from strided_jl_amd.stridedview import smr_dtype  # noqa: E402
+
+I64 = smr_dtype(np.int64)
 DTYPES = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64]
 
 
@@ -56,7 +59,7 @@ def julia_eval(tree, args):
     if op in ("add", "sub", "mul"):
         a, b = xs
         bits, sgn = promote(a, b)
-        if a.bits == 1 and b.bits == 1:
+        if a.bits == 1 and b.bits == 1 and op != "mul":   # Bool (+,-) Bool is an Int; Bool * Bool stays a Bool
             bits, sgn = 64, True
         r = {"add": a.v + b.v, "sub": a.v - b.v, "mul": a.v * b.v}[op]
         return Val(wrap(r, bits, sgn), bits, sgn)
@@ -87,37 +90,59 @@ def julia_eval(tree, args):
     raise ValueError(op)
 
 
-def wide_eval(tree, args):
-    """the device's integer class: everything in wrapping signed 64-bit arithmetic"""
-    op = tree[0]
-    if op == "arg":
-        return args[tree[1]].v
-    if op == "const":
-        return tree[1]
-    xs = [wide_eval(t, args) for t in tree[1:]]
+# ---- the device's integer class on Python integers ----------------------------------------------------------------------------
+WRAPS = {23: (8, True), 24: (16, True), 25: (32, True), 26: (8, False), 27: (16, False), 28: (32, False)}   # SMR_OP_WRAP_*
+OPN = {v: k for k, v in S._lib.OPCODES.items()}
+
+
+def canon_prog(f, op, dims, arrays):
+    """the program the kernels would run: (code pairs, constants, wraps added, caller's index of every canonical operand), or None if refused"""
+    import ctypes as C
+    p, keep = S.build_problem(f, op, None, dims, arrays, stream=0)
+    lib = S._lib.load()
+    code = (C.c_uint8 * (2 * S._lib.SMR_MAXPROG))()
+    nw, ct, orig = C.c_int(0), C.c_int(0), (C.c_int32 * 8)()
+    n = lib.smr_debug_canon_prog(C.byref(p), code, len(code), C.byref(nw), C.byref(ct), orig)
+    if n < 0:
+        assert n == S._lib.SMR_EUNSUPPORTED, n
+        return None
+    consts = [p.fconsts[2 * i] for i in range(p.nconsts)]
+    return [(code[2 * i], code[2 * i + 1]) for i in range(n)], consts, nw.value, list(orig), ct.value
+
+
+def wide_eval(prog, consts, orig, argvals):
+    """everything in wrapping signed 64-bit arithmetic (csrc/smr_device.h: mathx<ix64>); argvals[k] = value of the caller's operand k"""
     w = lambda v: wrap(v, 64, True)  # noqa: E731
-    if op == "add":
-        return w(xs[0] + xs[1])
-    if op == "sub":
-        return w(xs[0] - xs[1])
-    if op == "mul":
-        return w(xs[0] * xs[1])
-    if op == "neg":
-        return w(-xs[0])
-    if op == "abs":
-        return w(abs(xs[0]))
-    if op == "abs2":
-        return w(xs[0] * xs[0])
-    if op == "min":
-        return xs[1] if xs[1] < xs[0] else xs[0]
-    if op == "max":
-        return xs[1] if xs[0] < xs[1] else xs[0]
-    if op in ("lt", "le", "gt", "ge", "eq", "ne"):
-        a, b = xs
-        return int({"lt": a < b, "le": a <= b, "gt": a > b, "ge": a >= b, "eq": a == b, "ne": a != b}[op])
-    if op == "ifelse":
-        return xs[1] if xs[0] != 0 else xs[2]
-    raise ValueError(op)
+    st = []
+    for op, imm in prog:
+        name = OPN.get(op)
+        if name == "ARG":
+            st.append(w(argvals[orig[imm]]))
+        elif name == "CONST":
+            st.append(w(int(consts[imm])))
+        elif op in WRAPS:
+            st[-1] = wrap(st[-1], *WRAPS[op])
+        elif name == "NEG":
+            st[-1] = w(-st[-1])
+        elif name == "ABS":
+            st[-1] = w(abs(st[-1]))
+        elif name == "ABS2":
+            st[-1] = w(st[-1] * st[-1])
+        elif name in ("ADD", "SUB", "MUL", "MIN", "MAX", "LT", "LE", "GT", "GE", "EQ", "NE"):
+            y = st.pop()
+            x = st.pop()
+            st.append({"ADD": lambda: w(x + y), "SUB": lambda: w(x - y), "MUL": lambda: w(x * y), "MIN": lambda: y if y < x else x,
+                       "MAX": lambda: y if x < y else x, "LT": lambda: int(x < y), "LE": lambda: int(x <= y), "GT": lambda: int(x > y),
+                       "GE": lambda: int(x >= y), "EQ": lambda: int(x == y), "NE": lambda: int(x != y)}[name]())
+        elif name == "SELECT":
+            e = st.pop()
+            t = st.pop()
+            c = st.pop()
+            st.append(t if c != 0 else e)
+        else:
+            raise ValueError((op, name))
+    assert len(st) == 1
+    return st[0]
 
 
 def to_lambda(tree):
@@ -145,6 +170,19 @@ def _args_of(t):
     for u in t[1:]:
         out += _args_of(u)
     return out
+
+
+def const_only(t):
+    return t[0] == "const" or (t[0] != "arg" and all(const_only(u) for u in t[1:]))
+
+
+def folds(t):
+    """an operation on literals only: Python evaluates it (in unbounded integers, comparisons to True / False) before the tracer sees
+    anything, so the host passes one Int64 literal where Julia has a wrapped Int64 or a Bool (UInt16 - true is a UInt16, UInt16 - 1 an
+    Int64) -- not a program the mirror can express"""
+    if t[0] in ("arg", "const"):
+        return False
+    return const_only(t) or any(folds(u) for u in t[1:])
 
 
 def random_tree(rng, depth, nargs):
@@ -183,14 +221,25 @@ def planned(f, op, dims, arrays):
 
 
 # ---- the advisor's two probes, with NumPy as a further witness ---------------------------------------------------------------
+def wraps_of(f, op, dims, arrays):
+    """(admitted into the integer class, SMR_OP_WRAP_* instructions the planner added)"""
+    cp = canon_prog(f, op, dims, arrays)
+    if cp is None:
+        return False, 0
+    return cp[4] == I64, cp[2]
+
+
 def test_advisor_probes_follow_julia_and_numpy():
     a, b, c = (np.array([v], dtype=np.uint8) for v in (1, 2, 10))
     out = np.zeros(1, dtype=np.uint8)
     f = lambda x, y, z: fn.min(x - y, z)  # noqa: E731
     got = run_oracle(f, None, None, (1,), (fview(out), fview(a), fview(b), fview(c)))
     assert got[0] == np.minimum(a - b, c)[0] == 10          # UInt8(1) - UInt8(2) == 255, min(255, 10) == 10
-    ok, _ = planned(f, None, (1,), (fview(out), fview(a), fview(b), fview(c)))
-    assert not ok                                            # an order test on a value Julia wrapped at 8 bits
+    arrs = (fview(out), fview(a), fview(b), fview(c))
+    assert wraps_of(f, None, (1,), arrs) == (True, 1)        # an order test on a value Julia wrapped at 8 bits: re-wrapped before the min
+    prog, consts, nw, orig, _ = canon_prog(f, None, (1,), arrs)
+    assert [o for o, _ in prog] == [0, 0, 33, 26, 0, 36]     # a b SUB WRAP_U8 c MIN
+    assert wide_eval(prog, consts, orig, [0, 1, 2, 10]) == 10
     x = np.array([2 ** 20], dtype=np.int32)
     wide = np.zeros(1, dtype=np.int64)
     g = lambda u, v: u * v  # noqa: E731
@@ -198,11 +247,10 @@ def test_advisor_probes_follow_julia_and_numpy():
         want = (x * x).astype(np.int64)                      # 2^40 wraps to 0 in Int32, then widens
     got = run_oracle(g, None, None, (1,), (fview(wide), fview(x), fview(x)))
     assert got[0] == want[0] == 0
-    ok, _ = planned(g, None, (1,), (fview(wide), fview(x), fview(x)))
-    assert not ok                                            # a 32-bit product observed at 64 bits
+    assert wraps_of(g, None, (1,), (fview(wide), fview(x), fview(x))) == (True, 1)   # a 32-bit product observed at 64 bits: one wrap at the end
     narrow = np.zeros(1, dtype=np.int32)
     ok, desc = planned(g, None, (1,), (fview(narrow), fview(x), fview(x)))
-    assert ok and " ct=i64" in desc                          # the same product stored to Int32: congruent modulo 2^32
+    assert ok and " ct=i64" in desc and "int_wraps" not in desc   # the same product stored to Int32: congruent modulo 2^32, nothing added
 
 
 def test_what_is_admitted_and_what_is_refused():
@@ -222,43 +270,53 @@ def test_what_is_admitted_and_what_is_refused():
         (lambda a, b: fn.eq(a, b), (sim(u64, np.uint8), u64, u64)),    # round 5: all-unsigned equality is equality of bit patterns
         (lambda a, b: fn.ne(a, b), (sim(u64, np.uint8), u64, u32)),    # ... UInt32 is zero-extended, as Julia promotes it
     ]
+    rewrapped = [   # (f, arrays, wraps added): before round 5 the planner refused these
+        (lambda a, b: a * b, (sim(i32, np.int64), i32, i32), 1),           # 32-bit product observed at 64 bits
+        (lambda a, b: fn.min(a - b, b), (sim(u8), u8, u8), 1),             # order on a wrapped difference
+        (lambda a, b: (a + b) < b, (sim(i8, np.uint8), i8, i8), 1),        # comparison of a wrapped sum
+        (lambda a: fn.abs(a), (sim(i8, np.int16), i8), 1),                 # abs(typemin(Int8)) is -128 in Julia, +128 at 64 bits
+        (lambda a: -a, (sim(u8, np.int64), u8), 1),                        # -UInt8(1) == 255
+        (lambda a, b: (a < b) + a, (sim(i8, np.int64), i8, i8), 1),        # Bool + Int8 is an Int8
+        (lambda a, b: fn.ifelse(a * a > b, a, b), (sim(i16), i16, i16), 1),  # the condition observes a wrapped square
+        (lambda a, b, c: (a * b + c) * a, (sim(i32), i16, i16, i32), 1),   # Int16 product, converted to Int32 before the sum: exact first
+        (lambda a, b, c: (a * b + c) * a, (sim(i32), i32, i32, i32), 0),   # ... all Int32: a ring at one width, nothing to do
+        (lambda a, b: fn.max(a * b, a) - fn.abs(b - a), (sim(i64), i8, i8), 3),
+    ]
     refused = [
-        (lambda a, b: a * b, (sim(i32, np.int64), i32, i32)),           # 32-bit product observed at 64 bits
-        (lambda a, b: fn.min(a - b, b), (sim(u8), u8, u8)),             # order on a wrapped difference
-        (lambda a, b: (a + b) < b, (sim(i8, np.uint8), i8, i8)),        # comparison of a wrapped sum
-        (lambda a: fn.abs(a), (sim(i8, np.int16), i8)),                 # abs(typemin(Int8)) is -128 in Julia, +128 at 64 bits
-        (lambda a: -a, (sim(u8, np.int64), u8)),                        # -UInt8(1) == 255
-        (lambda a, b: (a < b) + a, (sim(i8, np.int64), i8, i8)),        # Bool + Int8 is an Int8
-        (lambda a, b: fn.ifelse(a * a > b, a, b), (sim(i16), i16, i16)),  # the condition observes a wrapped square
         (lambda a, b: fn.eq(a, b), (sim(u64, np.uint8), u64, i64)),    # UInt64 against a signed value: Julia compares mathematically
         (lambda a, b: fn.eq(a - 10, b), (sim(u64, np.uint8), u8, u64)),  # a literal is an Int64: UInt8 - 10 may be negative
         (lambda a, b: a < b, (sim(u64, np.uint8), u64, u64)),           # no order on UInt64 in a signed 64-bit domain
+        (lambda a, b: fn.ifelse(a < b, a, b) + a, (sim(i64), i8, i32)),  # ifelse(::Bool, ::Int8, ::Int32) + Int8: the sum's type depends on the data
     ]
+    for f, arrs, nw in rewrapped:
+        assert wraps_of(f, None, arrs[0].size, arrs) == (True, nw), (nw, canon_prog(f, None, arrs[0].size, arrs))
     for f, arrs in admitted:
         ok, desc = planned(f, None, arrs[0].size, arrs)
-        assert ok and " ct=i64" in desc, desc
+        assert ok and " ct=i64" in desc and "int_wraps" not in desc, desc
     for f, arrs in refused:
         ok, desc = planned(f, None, arrs[0].size, arrs)
         assert not ok, desc
     # reductions: the accumulator observes f's value at the destination's width; min / max need it exact
     r64 = S.StridedView(np.zeros(1, dtype=np.int64), i32.size, (0,), 0)
     r32 = S.StridedView(np.zeros(1, dtype=np.int32), i32.size, (0,), 0)
-    assert planned(lambda a: a, "+", i32.size, (r64, i32))[0]
-    assert planned(fn.abs2, "+", i32.size, (r32, i32))[0]
-    assert not planned(fn.abs2, "+", i32.size, (r64, i32))[0]         # abs2(::Int32) wraps at 32 bits before it is summed at 64
-    assert not planned(lambda a, b: a - b, "max", i32.size, (r32, i32, i32))[0]
-    assert planned(lambda a, b: fn.max(a, b), "max", i32.size, (r32, i32, i32))[0]
+    assert wraps_of(lambda a: a, "+", i32.size, (r64, i32)) == (True, 0)
+    assert wraps_of(fn.abs2, "+", i32.size, (r32, i32)) == (True, 0)
+    assert wraps_of(fn.abs2, "+", i32.size, (r64, i32)) == (True, 1)   # abs2(::Int32) wraps at 32 bits before it is summed at 64
+    assert wraps_of(lambda a, b: a - b, "max", i32.size, (r32, i32, i32)) == (True, 1)
+    assert wraps_of(lambda a, b: fn.max(a, b), "max", i32.size, (r32, i32, i32)) == (True, 0)
 
 
 # ---- the property ------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(60))
 def test_admitted_calls_compute_what_julia_computes(seed):
     rng = np.random.default_rng(1000 + seed)
-    n, nadmit, nrefuse = 24, 0, 0
+    n, nadmit, nrefuse, nwrapped = 24, 0, 0, 0
     for trial in range(120):
         nargs = int(rng.integers(1, 4))
         tree = random_tree(rng, int(rng.integers(1, 4)), nargs)
         used = sorted(set(_args_of(tree)))
+        if folds(tree):
+            continue
         if tree[0] in ("arg", "const") and trial % 3:
             continue
         dts = [DTYPES[int(rng.integers(0, len(DTYPES)))] for _ in range(nargs)]
@@ -279,15 +337,68 @@ def test_admitted_calls_compute_what_julia_computes(seed):
         for i in range(n):
             args = [Val(int(a[i]), a.dtype.itemsize * 8, np.issubdtype(a.dtype, np.signedinteger)) for a in ins[:need]]
             jl.append(wrap(julia_eval(tree, args).v, dbits, dsgn))
-            wide.append(wrap(wide_eval(tree, args), dbits, dsgn))
         u64_in = any(dt == np.uint64 for dt in dts[:need]) or ddt == np.uint64
         ordered = any(k in repr(tree) for k in ("min", "max", "lt", "le", "gt", "ge", "eq", "ne", "abs'"))
         if not (u64_in and ordered):  # UInt64 has no order in a signed 64-bit domain: both sides refuse such calls
             assert [int(v) for v in got] == jl, ("oracle vs Julia's typing", tree, dts, ddt)
-        ok, desc = planned(f, None, (n,), (dest,) + views)
-        if ok and " ct=i64" in desc:
+        cp = canon_prog(f, None, (n,), (dest,) + views)
+        if cp is not None and cp[4] == I64:
+            prog, consts, nw, orig, _ = cp
             nadmit += 1
-            assert wide == jl, ("the planner admitted a call whose 64-bit evaluation differs from Julia's", tree, dts[:need], ddt, used)
+            nwrapped += nw > 0
+            for i in range(n):
+                vals = [0] + [int(a[i]) for a in ins[:need]]
+                wide.append(wrap(wide_eval(prog, consts, orig, vals), dbits, dsgn))
+            assert wide == jl, ("the planner admitted a call whose 64-bit evaluation differs from Julia's", tree, dts[:need], ddt, used, prog)
         else:
             nrefuse += 1
-    assert nadmit >= 20 and nrefuse >= 10, (nadmit, nrefuse)
+    assert nadmit >= 40 and nwrapped >= 5, (nadmit, nwrapped, nrefuse)
+
+
+# ---- on the device --------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [1, 0])
+def test_hip_rewrapped_programs_equal_the_oracle(jit):
+    """Round 5: programs the integer class used to refuse now run with SMR_OP_WRAP_* instructions where Julia's narrow types are
+    observed -- compiled functors (hiprtc) and the interpreter, bit for bit against the oracle (which types every operation like
+    Julia) and, for the two advisor probes, against NumPy's fixed-width arithmetic."""
+    from util import run_device
+    rng = np.random.default_rng(77)
+    n = 4096
+    old = S.get_option("jit")
+    S.set_option("jit", old if jit else 0)
+    try:
+        x, y = adversarial(rng, np.int32, n), adversarial(rng, np.int32, n)
+        got = run_device(lambda u, v: u * v, None, None, (n,), (fview(np.zeros(n, dtype=np.int64)), fview(x), fview(y)))
+        with np.errstate(over="ignore"):
+            assert np.array_equal(got, (x * y).astype(np.int64))
+        a, b, c = (adversarial(rng, np.uint8, n) for _ in range(3))
+        got = run_device(lambda p, q, r: fn.min(p - q, r), None, None, (n,), (fview(np.zeros(n, dtype=np.uint8)), fview(a), fview(b), fview(c)))
+        assert np.array_equal(got, np.minimum(a - b, c))
+        r64 = np.zeros(1, dtype=np.int64)
+        got = run_device(fn.abs2, "+", None, (n,), (S.StridedView(r64, (n,), (0,), 0), fview(x)))
+        with np.errstate(over="ignore"):
+            assert int(np.asarray(got).ravel()[0]) == int((x * x).astype(np.int64).sum())    # abs2(::Int32) wraps at 32 bits, the sum runs at 64
+        nrun = nwrapped = 0
+        for trial in range(400 if jit == 0 else 120):
+            nargs = int(rng.integers(1, 4))
+            tree = random_tree(rng, int(rng.integers(1, 4)), nargs)
+            if folds(tree) or tree[0] in ("arg", "const"):
+                continue
+            dts = [DTYPES[int(rng.integers(0, len(DTYPES)))] for _ in range(nargs)]
+            ddt = DTYPES[int(rng.integers(0, len(DTYPES)))]
+            ins = [adversarial(rng, dt, 192) for dt in dts]
+            f, need = to_lambda(tree)
+            views = tuple(fview(v) for v in ins[:need])
+            dest = fview(np.zeros(192, dtype=ddt))
+            cp = canon_prog(f, None, (192,), (dest,) + views)
+            if cp is None or cp[4] != I64 or (jit and cp[2] == 0):     # (compiled functors: only the re-wrapped programs, hiprtc takes ~0.3 s each)
+                continue
+            got = run_device(f, None, None, (192,), (fview(np.zeros(192, dtype=ddt)),) + views)
+            want = run_oracle(f, None, None, (192,), (dest,) + views)
+            assert np.array_equal(got, want), (tree, dts[:need], ddt, cp[0])
+            nrun += 1
+            nwrapped += cp[2] > 0
+        assert nwrapped >= (10 if jit else 25), (nrun, nwrapped)
+    finally:
+        S.set_option("jit", old)

@@ -65,7 +65,7 @@ def test_opcode_tables_match_the_header():
     assert set(bi) == set(names) and all(bi[k] == ops[v] for k, v in names.items())
     m = re.search(r"const OP_ARG, OP_CONST, OP_ROUND32, OP_WIDEN, OP_SELECT = (0x\w+), (0x\w+), (0x\w+), (0x\w+), (0x\w+)", SRC)
     assert [int(x, 16) for x in m.groups()] == [ops["ARG"], ops["CONST"], ops["ROUND32"], ops["WIDEN"], ops["SELECT"]]
-    assert ops == {k: v for k, v in L.OPCODES.items()}  # and the ctypes mirror agrees with the header too
+    assert {k: v for k, v in ops.items() if not k.startswith("WRAP_")} == dict(L.OPCODES)  # the ctypes mirror agrees too (WRAP_*: the library's own)
 
 
 def test_dtype_redop_initop_codes_match_the_header():
