@@ -86,11 +86,13 @@ typedef enum {
     SMR_I16 = 5,
     SMR_I32 = 6,
     SMR_I64 = 7,
-    SMR_U8 = 8, /* also Bool */
+    SMR_U8 = 8,
     SMR_U16 = 9,
     SMR_U32 = 10,
     SMR_U64 = 11,
-    SMR_DTYPE_COUNT = 12
+    SMR_BOOL = 12, /* Julia's Bool / NumPy's bool_: one byte holding 0 or 1.  Moves and computes like a UInt8; what differs is Julia's
+                      typing of f (Bool yields to every integer type: true + Int8(1) is an Int8, -true and true + true are Ints) */
+    SMR_DTYPE_COUNT = 13
 } smr_dtype;
 
 /* Reduction operator `op` (neutral elements follow _init_reduction!,

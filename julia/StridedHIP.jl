@@ -116,7 +116,7 @@ struct SmrProblem
 end
 
 const DTYPES = Dict(Float32 => 0, Float64 => 1, ComplexF32 => 2, ComplexF64 => 3, Int8 => 4, Int16 => 5, Int32 => 6, Int64 => 7,
-                    UInt8 => 8, Bool => 8, UInt16 => 9, UInt32 => 10, UInt64 => 11)
+                    UInt8 => 8, Bool => 12, UInt16 => 9, UInt32 => 10, UInt64 => 11)
 dtypecode(T) = get(() -> throw(Unsupported("eltype $T")), DTYPES, T)
 
 pad(t::NTuple{N,Int}, v) where {N} = ntuple(i -> i <= N ? Int64(t[i]) : Int64(v), MAXN)

@@ -47,7 +47,7 @@ int dtype_size(int dt) {
         case SMR_F64: return 8;
         case SMR_C32: return 8;
         case SMR_C64: return 16;
-        case SMR_I8: case SMR_U8: return 1;
+        case SMR_I8: case SMR_U8: case SMR_BOOL: return 1;
         case SMR_I16: case SMR_U16: return 2;
         case SMR_I32: case SMR_U32: return 4;
         case SMR_I64: case SMR_U64: return 8;
@@ -312,7 +312,7 @@ inline T load_as(const void* base, i64 idx, int dt) {
     if constexpr (std::is_same<T, ix64>::value) {  // sign / zero extension
         switch (dt) {
             case SMR_I8: return ((const int8_t*)base)[idx];
-            case SMR_U8: return ((const uint8_t*)base)[idx];
+            case SMR_U8: case SMR_BOOL: return ((const uint8_t*)base)[idx];
             case SMR_I16: return ((const int16_t*)base)[idx];
             case SMR_U16: return ((const uint16_t*)base)[idx];
             case SMR_I32: return ((const int32_t*)base)[idx];
@@ -328,7 +328,7 @@ inline T load_as(const void* base, i64 idx, int dt) {
         case SMR_C32: return make<T>(R(((const float*)base)[2 * idx]), R(((const float*)base)[2 * idx + 1]));
         case SMR_C64: return make<T>(R(((const double*)base)[2 * idx]), R(((const double*)base)[2 * idx + 1]));
         case SMR_I8: return make<T>(R(((const int8_t*)base)[idx]), R(0));
-        case SMR_U8: return make<T>(R(((const uint8_t*)base)[idx]), R(0));
+        case SMR_U8: case SMR_BOOL: return make<T>(R(((const uint8_t*)base)[idx]), R(0));
         case SMR_I16: return make<T>(R(((const int16_t*)base)[idx]), R(0));
         case SMR_U16: return make<T>(R(((const uint16_t*)base)[idx]), R(0));
         case SMR_I32: return make<T>(R(((const int32_t*)base)[idx]), R(0));
@@ -342,7 +342,7 @@ template <class T>
 inline void store_as(void* base, i64 idx, int dt, T v) {
     if constexpr (std::is_same<T, ix64>::value) {  // truncation = the wrapped value in the narrower type
         switch (dt) {
-            case SMR_I8: case SMR_U8: ((uint8_t*)base)[idx] = (uint8_t)v; break;
+            case SMR_I8: case SMR_U8: case SMR_BOOL: ((uint8_t*)base)[idx] = (uint8_t)v; break;
             case SMR_I16: case SMR_U16: ((uint16_t*)base)[idx] = (uint16_t)v; break;
             case SMR_I32: case SMR_U32: ((uint32_t*)base)[idx] = (uint32_t)v; break;
             case SMR_I64: case SMR_U64: ((long long*)base)[idx] = v; break;
@@ -357,7 +357,7 @@ inline void store_as(void* base, i64 idx, int dt, T v) {
         case SMR_C32: ((float*)base)[2 * idx] = (float)re; ((float*)base)[2 * idx + 1] = (float)im; break;
         case SMR_C64: ((double*)base)[2 * idx] = (double)re; ((double*)base)[2 * idx + 1] = (double)im; break;
         case SMR_I8: ((int8_t*)base)[idx] = (int8_t)std::llrint((double)re); break;
-        case SMR_U8: ((uint8_t*)base)[idx] = (uint8_t)std::llrint((double)re); break;
+        case SMR_U8: case SMR_BOOL: ((uint8_t*)base)[idx] = (uint8_t)std::llrint((double)re); break;
         case SMR_I16: ((int16_t*)base)[idx] = (int16_t)std::llrint((double)re); break;
         case SMR_U16: ((uint16_t*)base)[idx] = (uint16_t)std::llrint((double)re); break;
         case SMR_I32: ((int32_t*)base)[idx] = (int32_t)std::llrint((double)re); break;
@@ -963,7 +963,7 @@ void julia_int_types(const smr_problem* p, Prog& prog) {
     };
     auto of_dtype = [](int dt) {
         Ty t;
-        t.bits = 8 << ((dt - SMR_I8) & 3);
+        t.bits = dt == SMR_BOOL ? 1 : 8 << ((dt - SMR_I8) & 3);
         t.sgn = dt < SMR_U8;
         return t;
     };
@@ -1017,10 +1017,11 @@ void julia_int_types(const smr_problem* p, Prog& prog) {
 // the integer class applies when every operand is an integer type and f is closed over the integers (the same rule as
 // the device planner, csrc/smr_plan.cpp: canonicalise)
 bool integer_class(const smr_problem* p, const Prog& prog) {
-    bool has_u64 = false;
+    bool has_u64 = false, has_signed = false, has_const = false, eqne = false;
     for (int k = 0; k < p->M; ++k) {
         if (p->ops[k].dtype < SMR_I8) return false;
         if (p->ops[k].dtype == SMR_U64) has_u64 = true;
+        if (p->ops[k].dtype >= SMR_I8 && p->ops[k].dtype <= SMR_I64) has_signed = true;
     }
     bool ordered = p->redop == SMR_RED_MIN || p->redop == SMR_RED_MAX;
     for (int pc = 0; pc < prog.len; ++pc) {
@@ -1028,11 +1029,16 @@ bool integer_class(const smr_problem* p, const Prog& prog) {
         switch (op) {
             case SMR_OP_ARG: case SMR_OP_NEG: case SMR_OP_ABS2: case SMR_OP_CONJ: case SMR_OP_REAL: case SMR_OP_IMAG:
             case SMR_OP_ADD: case SMR_OP_SUB: case SMR_OP_MUL: case SMR_OP_SELECT: case SMR_OP_WIDEN: break;
-            // == and != belong here too: Julia compares UInt64 with signed values mathematically, a 64-bit signed domain compares bit patterns
-            case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE: case SMR_OP_EQ: case SMR_OP_NE:
+            case SMR_OP_ABS: case SMR_OP_MIN: case SMR_OP_MAX: case SMR_OP_LT: case SMR_OP_LE: case SMR_OP_GT: case SMR_OP_GE:
                 ordered = true;
                 break;
+            // == and !=: Julia compares a UInt64 with a signed value mathematically, a 64-bit signed domain compares bit patterns; among
+            // unsigned values (no signed operand, no literal: literals are Int64) the two are the same
+            case SMR_OP_EQ: case SMR_OP_NE:
+                eqne = true;
+                break;
             case SMR_OP_CONST: {
+                has_const = true;
                 const double re = prog.consts[2 * prog.code[2 * pc + 1]], im = prog.consts[2 * prog.code[2 * pc + 1] + 1];
                 if (im != 0.0 || !(re == std::floor(re) || std::isinf(re)) || (std::fabs(re) > 9223372036854775808.0 && !std::isinf(re))) return false;
                 break;
@@ -1044,6 +1050,7 @@ bool integer_class(const smr_problem* p, const Prog& prog) {
         const double re = p->initarg[0], im = p->initarg[1];
         if (im != 0.0 || re != std::floor(re) || std::fabs(re) > 9223372036854775808.0) return false;
     }
+    if (eqne && has_u64 && (has_signed || has_const)) ordered = true;
     return !(has_u64 && ordered);
 }
 

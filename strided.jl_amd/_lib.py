@@ -20,7 +20,7 @@ SMR_OK, SMR_EINVAL, SMR_EUNSUPPORTED, SMR_EHIP, SMR_ENOMEM, SMR_ENODEVICE = 0, -
 
 # smr_dtype
 (SMR_F32, SMR_F64, SMR_C32, SMR_C64, SMR_I8, SMR_I16, SMR_I32, SMR_I64,
- SMR_U8, SMR_U16, SMR_U32, SMR_U64) = range(12)
+ SMR_U8, SMR_U16, SMR_U32, SMR_U64, SMR_BOOL) = range(13)
 
 # smr_redop / smr_initop
 SMR_RED_NONE, SMR_RED_ADD, SMR_RED_MUL, SMR_RED_MIN, SMR_RED_MAX, SMR_RED_AND, SMR_RED_OR = range(7)

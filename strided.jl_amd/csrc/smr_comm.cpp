@@ -135,7 +135,7 @@ bool nccl_type(int dtype, int redop, ncclDataType_t* t, size_t* mult, int* stage
         case SMR_C32: *t = ncclFloat32; *mult = 2; return redop == SMR_RED_ADD;  // sums are component-wise
         case SMR_C64: *t = ncclFloat64; *mult = 2; return redop == SMR_RED_ADD;
         case SMR_I8: *t = ncclInt8; return true;
-        case SMR_U8: *t = ncclUint8; return true;
+        case SMR_U8: case SMR_BOOL: *t = ncclUint8; return true;
         case SMR_I32: *t = ncclInt32; return true;
         case SMR_U32: *t = ncclUint32; return true;
         case SMR_I64: *t = ncclInt64; return true;
@@ -167,7 +167,7 @@ int fill_neutral(const smr_problem* p) {
     if (p->redop == SMR_RED_MUL || p->redop == SMR_RED_AND) c[0] = 1;
     if (p->redop == SMR_RED_MIN) c[0] = __builtin_huge_val();
     if (p->redop == SMR_RED_MAX) c[0] = -__builtin_huge_val();
-    const int dt = p->ops[0].dtype;
+    const int dt = p->ops[0].dtype == SMR_BOOL ? SMR_U8 : p->ops[0].dtype;
     if (dt >= SMR_I8 && (p->redop == SMR_RED_MIN || p->redop == SMR_RED_MAX)) {
         // integer destination: typemax / typemin of ITS type (the integer class saturates +-Inf to the Int64 limits;
         // -1 stored into a UInt64 is all ones)

@@ -41,7 +41,7 @@ inline int dtype_size(int dt) {
         case SMR_F64: return 8;
         case SMR_C32: return 8;
         case SMR_C64: return 16;
-        case SMR_I8: case SMR_U8: return 1;
+        case SMR_I8: case SMR_U8: case SMR_BOOL: return 1;
         case SMR_I16: case SMR_U16: return 2;
         case SMR_I32: case SMR_U32: return 4;
         case SMR_I64: case SMR_U64: return 8;

@@ -24,7 +24,7 @@ _NP2SMR = {
     np.dtype(np.float32): L.SMR_F32, np.dtype(np.float64): L.SMR_F64,
     np.dtype(np.complex64): L.SMR_C32, np.dtype(np.complex128): L.SMR_C64,
     np.dtype(np.int8): L.SMR_I8, np.dtype(np.int16): L.SMR_I16, np.dtype(np.int32): L.SMR_I32,
-    np.dtype(np.int64): L.SMR_I64, np.dtype(np.uint8): L.SMR_U8, np.dtype(np.bool_): L.SMR_U8,
+    np.dtype(np.int64): L.SMR_I64, np.dtype(np.uint8): L.SMR_U8, np.dtype(np.bool_): L.SMR_BOOL,
     np.dtype(np.uint16): L.SMR_U16, np.dtype(np.uint32): L.SMR_U32, np.dtype(np.uint64): L.SMR_U64,
 }
 

@@ -22,6 +22,7 @@ from strided_jl_amd.stridedview import smr_dtype  # noqa: E402
 
 I64 = smr_dtype(np.int64)
 DTYPES = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64]
+INPUTS = DTYPES + [np.bool_, np.bool_]   # operands may be Bool arrays (SMR_BOOL); destinations of arithmetic are integers
 
 
 # ---- Julia's semantics on Python integers ------------------------------------------------------------------------------------
@@ -204,6 +205,8 @@ def random_tree(rng, depth, nargs):
 
 
 def adversarial(rng, dtype, n):
+    if dtype == np.bool_:
+        return np.asfortranarray(rng.integers(0, 2, size=n).astype(np.bool_))
     info = np.iinfo(dtype)
     edge = [info.min, info.min + 1, -1, 0, 1, 2, info.max - 1, info.max, info.max // 2, info.min // 2, 127, 128, 255, 256]
     edge = [e for e in edge if info.min <= e <= info.max]
@@ -319,10 +322,10 @@ def test_admitted_calls_compute_what_julia_computes(seed):
             continue
         if tree[0] in ("arg", "const") and trial % 3:
             continue
-        dts = [DTYPES[int(rng.integers(0, len(DTYPES)))] for _ in range(nargs)]
+        dts = [INPUTS[int(rng.integers(0, len(INPUTS)))] for _ in range(nargs)]
         if rng.random() < 0.4:  # homogeneous operands are the common case
             dts = [dts[0]] * nargs
-        ddt = DTYPES[int(rng.integers(0, len(DTYPES)))] if rng.random() < 0.6 else dts[0]
+        ddt = DTYPES[int(rng.integers(0, len(DTYPES)))] if rng.random() < 0.6 or dts[0] == np.bool_ else dts[0]
         ins = [adversarial(rng, dt, n) for dt in dts]
         f, need = to_lambda(tree)
         views = tuple(fview(a) for a in ins[:need])
@@ -335,7 +338,7 @@ def test_admitted_calls_compute_what_julia_computes(seed):
         dbits, dsgn = np.dtype(ddt).itemsize * 8, np.issubdtype(ddt, np.signedinteger)
         jl, wide = [], []
         for i in range(n):
-            args = [Val(int(a[i]), a.dtype.itemsize * 8, np.issubdtype(a.dtype, np.signedinteger)) for a in ins[:need]]
+            args = [Val(int(a[i]), 1 if a.dtype == np.bool_ else a.dtype.itemsize * 8, np.issubdtype(a.dtype, np.signedinteger)) for a in ins[:need]]
             jl.append(wrap(julia_eval(tree, args).v, dbits, dsgn))
         u64_in = any(dt == np.uint64 for dt in dts[:need]) or ddt == np.uint64
         ordered = any(k in repr(tree) for k in ("min", "max", "lt", "le", "gt", "ge", "eq", "ne", "abs'"))
@@ -379,13 +382,19 @@ def test_hip_rewrapped_programs_equal_the_oracle(jit):
         got = run_device(fn.abs2, "+", None, (n,), (S.StridedView(r64, (n,), (0,), 0), fview(x)))
         with np.errstate(over="ignore"):
             assert int(np.asarray(got).ravel()[0]) == int((x * x).astype(np.int64).sum())    # abs2(::Int32) wraps at 32 bits, the sum runs at 64
+        m1, m2 = adversarial(rng, np.bool_, n), adversarial(rng, np.bool_, n)    # SMR_BOOL: -true == -1, true + true is an Int
+        i8 = adversarial(rng, np.int8, n)
+        got = run_device(lambda p, q, x: (p + q) * 200 - p + (q + x), None, None, (n,), (fview(np.zeros(n, dtype=np.int64)), fview(m1), fview(m2), fview(i8)))
+        with np.errstate(over="ignore"):
+            want = (m1.astype(np.int64) + m2) * 200 - m1 + (q8 := (i8 + m2.astype(np.int8))).astype(np.int64)
+        assert np.array_equal(got, want) and int((q8 == -128).sum()) > 0
         nrun = nwrapped = 0
         for trial in range(400 if jit == 0 else 120):
             nargs = int(rng.integers(1, 4))
             tree = random_tree(rng, int(rng.integers(1, 4)), nargs)
             if folds(tree) or tree[0] in ("arg", "const"):
                 continue
-            dts = [DTYPES[int(rng.integers(0, len(DTYPES)))] for _ in range(nargs)]
+            dts = [INPUTS[int(rng.integers(0, len(INPUTS)))] for _ in range(nargs)]
             ddt = DTYPES[int(rng.integers(0, len(DTYPES)))]
             ins = [adversarial(rng, dt, 192) for dt in dts]
             f, need = to_lambda(tree)
@@ -402,3 +411,33 @@ def test_hip_rewrapped_programs_equal_the_oracle(jit):
         assert nwrapped >= (10 if jit else 25), (nrun, nwrapped)
     finally:
         S.set_option("jit", old)
+
+
+def test_bool_operands_are_typed_like_julia():
+    """SMR_BOOL (round 5; before, Bool arrays were passed as UInt8): Bool yields to every integer type, -true and true + true are Ints."""
+    m1 = np.array([True, True, False, True])
+    m2 = np.array([True, False, False, True])
+    a = np.array([127, -128, 5, -1], dtype=np.int8)
+    out = lambda dt=np.int64: fview(np.zeros(4, dtype=dt))  # noqa: E731
+    cases = [
+        (lambda p: -p, (m1,), [-1, -1, 0, -1], 0),                                   # -true == -1 (a UInt8 would give 255)
+        (lambda p, q: (p + q) * 200, (m1, m2), [400, 200, 0, 400], 0),                # true + true is an Int (a UInt8 sum times 200 would wrap to 144)
+        (lambda p, x: p + x, (m1, a), [-128, -127, 5, 0], 1),                         # Bool + Int8 is an Int8: 127 + true wraps to -128
+        (lambda p, q: p * q, (m1, m2), [1, 0, 0, 1], 0),                              # Bool * Bool stays a Bool
+        (lambda p, x: fn.ifelse(p, x, -x), (m1, a), [127, -128, -5, -1], 1),          # -Int8(-128) == -128 observed at 64 bits
+        (lambda p, x: p * x * x, (m1, a), [1, 0, 0, 1], 1),                           # Int8 products wrap at 8 bits: 127 * 127 == 1
+    ]
+    for f, ins, want, nw in cases:
+        views = tuple(fview(np.asfortranarray(v)) for v in ins)
+        got = run_oracle(f, None, None, (4,), (out(),) + views)
+        assert [int(v) for v in got] == want, (want, got)
+        cp = canon_prog(f, None, (4,), (out(),) + views)
+        assert cp is not None and cp[4] == I64 and cp[2] == nw, cp
+        prog, consts, _, orig, _ = cp
+        for i in range(4):
+            assert wide_eval(prog, consts, orig, [0] + [int(v[i]) for v in ins]) == want[i]
+    # a Bool array still moves as bytes and counts as before
+    r = S.StridedView(np.zeros(1, dtype=np.int64), (4,), (0,), 0)
+    assert int(run_oracle(lambda p: p, "+", None, (4,), (r, fview(m1)))[0]) == 3
+    plan = S.make_plan(lambda p: p, None, None, (4,), (fview(np.zeros(4, dtype=np.bool_)), fview(m1)))
+    assert "(bitcopy)" in plan.describe()

@@ -69,10 +69,10 @@ def test_opcode_tables_match_the_header():
 
 
 def test_dtype_redop_initop_codes_match_the_header():
-    dt = _enum("SMR_(?=[FCIU]\\d)")
+    dt = _enum("SMR_(?=[FCIU]\\d|BOOL)")
     jl = _dict("DTYPES")
     want = {"Float32": "F32", "Float64": "F64", "ComplexF32": "C32", "ComplexF64": "C64", "Int8": "I8", "Int16": "I16", "Int32": "I32",
-            "Int64": "I64", "UInt8": "U8", "Bool": "U8", "UInt16": "U16", "UInt32": "U32", "UInt64": "U64"}
+            "Int64": "I64", "UInt8": "U8", "Bool": "BOOL", "UInt16": "U16", "UInt32": "U32", "UInt64": "U64"}
     assert set(jl) == set(want) and all(jl[k] == dt[v] for k, v in want.items())
     red = _enum("SMR_RED_")
     jr = _dict("REDOPS")
