@@ -27,7 +27,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // MODE 0: read + write (copy); 1: read only (sum into a sink); 2: write only
 // ORDER: how box indices are dealt to workgroups.  0: in memory order (dim 0 fastest); 1: dim 3 fastest; 2: scattered (odd multiplier modulo the
-// power-of-two box count: neighbours in time are far apart in memory); 3: dim 0 fastest, dims 1..3 scattered
+// power-of-two box count: neighbours in time are far apart in memory); 3: dim 0 fastest, dims 1..3 scattered; 4 / 5: memory order, but
+// the 2 / 4 boxes that share a 128-byte line / a 256-byte stretch run on the same XCD (same L2) one after the other
 template <int R0, int R1, int R2, int R3, int MODE, bool NT, int ORDER = 0>
 __global__ void __launch_bounds__(1024) k_box(const double* __restrict__ A, double* __restrict__ B, int n, double* sink) {
     static_assert(R0 * R1 * R2 * R3 == 4096, "32 KiB boxes");
@@ -35,6 +36,11 @@ __global__ void __launch_bounds__(1024) k_box(const double* __restrict__ A, doub
     unsigned b = blockIdx.x;
     int b0, b1, b2, b3;
     if (ORDER == 2) b = (b * 40503u) & (gridDim.x - 1);  // (power-of-two grids only)
+    if (ORDER == 4 || ORDER == 5) {  // 2 (4) boxes adjacent along dim 0 go to the SAME XCD in consecutive slots (workgroup x runs on XCD x % 8)
+        constexpr unsigned G = ORDER == 4 ? 2 : 4;
+        const unsigned xcd = b % 8, j = b / 8;
+        b = G * ((j / G) * 8 + xcd) + j % G;
+    }
     if (ORDER == 3) { const unsigned lo = b % nb0, hi = b / nb0; b = lo + nb0 * ((hi * 40503u) & (gridDim.x / nb0 - 1)); }
     if (ORDER == 1) {
         const int nb3 = n / R3;
@@ -77,7 +83,8 @@ static double run(const double* A, double* B, int n, double* sink) {
     if (n % R0 || n % R1 || n % R2 || n % R3) return 0;
     const unsigned grid = (unsigned)(((size_t)n * n * n * n) / 4096);
     auto kern = k_box<R0, R1, R2, R3, MODE, NT, ORDER>;
-    if (ORDER >= 2 && (grid & (grid - 1))) return 0;
+    if ((ORDER == 2 || ORDER == 3) && (grid & (grid - 1))) return 0;
+    if (ORDER >= 4 && (grid % 32 || (n / R0) % 4)) return 0;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -105,7 +112,8 @@ static void row(const double* A, double* B, int n, double* sink) {
     std::printf("  rows of %4d B (box %2d x %2d x %2d x %2d): copy %6.0f GB/s (%.2f of 8 TB/s), nt stores %6.0f (%.2f) | read only %6.0f | write only %6.0f\n", R0 * 8, R0,
                 R1, R2, R3, c, c / 8000, cn, cn / 8000, r, w);
     const double o1 = run<R0, R1, R2, R3, 0, false, 1>(A, B, n, sink), o2 = run<R0, R1, R2, R3, 0, false, 2>(A, B, n, sink), o3 = run<R0, R1, R2, R3, 0, false, 3>(A, B, n, sink);
-    std::printf("                 boxes dealt dim 3 fastest: copy %6.0f GB/s; scattered: %6.0f; dim 0 fastest, the rest scattered: %6.0f\n", o1, o2, o3);
+    const double o4 = run<R0, R1, R2, R3, 0, false, 4>(A, B, n, sink), o5 = run<R0, R1, R2, R3, 0, false, 5>(A, B, n, sink);
+    std::printf("                 boxes dealt dim 3 fastest: copy %6.0f GB/s; scattered: %6.0f; dim 0 fastest, the rest scattered: %6.0f; pairs / quads along dim 0 on one XCD: %6.0f / %6.0f\n", o1, o2, o3, o4, o5);
     std::fflush(stdout);
 }
 
