@@ -14,6 +14,9 @@
 //   (ii) the planner known-answers hand-traced from the reference code.
 //
 // Every function cites the reference lines it follows (paths relative to /root/reference).
+// ONE deliberate deviation from the letter of the reference: src/mapreduce.jl:409 (`init_i &= stride_i_1 > 0`) is read as `!= 0`
+// -- with a reversed (negative-stride) destination the literal line leaves block-size-dependent elements uninitialised; see
+// Kernel::blockloop, oracle_set_literal_409 and tests/test_oracle_numpy.py::test_initop_with_a_reversed_destination.
 // Indices here are 0-based; the reference is 1-based.
 
 #include "../include/strided_hip.h"
@@ -36,6 +39,7 @@ constexpr int MAXN = SMR_MAXN;
 constexpr int MAXM = SMR_MAXM;
 
 thread_local std::string g_err;
+bool g_literal_409 = false;  // see Kernel::blockloop
 int fail(int code, const std::string& m) {
     g_err = m;
     return code;
@@ -796,7 +800,13 @@ struct Kernel {
             } else {
                 blockloop(level - 1, init);
             }
-            init = init && (L.strides[0][level] > 0);  // :409
+            // :409 reads `init_i &= stride_i_1 > 0`.  Taken literally, a NEGATIVE destination stride along a kept dim switches initop off for
+            // every block after the first along that dim: those destination elements are accumulated onto their stale contents, and
+            // which elements they are depends on the block sizes (the cache-size constant) and on the thread count (every task starts
+            // with init = true again).  No reference test has a reversed destination with an initop; `!= 0` is what the line is for
+            // (a reduced dim, stride 0, must not be initialised twice).  The oracle follows the intent; the literal reading is kept
+            // selectable (oracle_set_literal_409) so that tests/test_oracle_numpy.py can show the difference against NumPy.
+            init = init && (g_literal_409 ? L.strides[0][level] > 0 : L.strides[0][level] != 0);
             for (int k = 0; k < M; ++k) I[k] += d[level] * L.strides[k][level];
         }
         for (int k = 0; k < M; ++k) I[k] -= dims[level] * L.strides[k][level];
@@ -1121,6 +1131,9 @@ int load_prog(const smr_problem* p, Prog& prog) {
 extern "C" {
 
 const char* oracle_last_error(void) { return g_err.c_str(); }
+
+// 1: read src/mapreduce.jl:409 literally (see Kernel::blockloop); default 0
+void oracle_set_literal_409(int on) { g_literal_409 = on != 0; }
 
 // Full reference path on host memory: _mapreduce_fuse! -> ... -> _mapreduce_kernel!
 int oracle_mapreduce(const smr_problem* p, int nthreads) {

@@ -56,6 +56,11 @@ def mapreduce(problem, nthreads=1):
         raise RuntimeError(f"oracle error {rc}: {load().oracle_last_error().decode()}")
 
 
+def set_literal_409(on):
+    """src/mapreduce.jl:409 read literally (`stride > 0`): initop is skipped for later blocks along a reversed kept dim of the destination"""
+    load().oracle_set_literal_409(1 if on else 0)
+
+
 def plan(problem):
     info = oracle_plan_info()
     rc = load().oracle_plan(C.byref(problem), C.byref(info))

@@ -66,6 +66,10 @@ def _random_view(rng, mk, data, dims):
     return W
 
 
+# tools/fuzz_more.py runs the same problems on a library-owned stream, which is not ordered against torch's: it synchronises here
+HOOKS = {"before": lambda: None, "after": lambda: None}
+
+
 def _problem(seed, T):
     """Returns run(mk) -> result array, plus whether bit-exactness is expected."""
     rng0 = np.random.default_rng(seed)
@@ -104,11 +108,13 @@ def _problem(seed, T):
             ins.append(_random_view(rng, mk, data, d_k))
         odims = [1 if i in reduce_dims else dims[i] for i in range(N)]
         out = _random_view(rng, mk, data, odims)
+        HOOKS["before"]()
         if op is None:
             # looked up at call time: the oracle run patches the funnel in the module
             sys.modules["strided_jl_amd.mapreduce"]._mapreduce_fuse_(f, None, None, tuple(dims), S.promoteshape(tuple(dims), out, *ins))
         else:
             S._mapreducedim_(f, op, initop, tuple(dims), (out, *ins))
+        HOOKS["after"]()
         r = out.toarray()
         return r
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """More seeds of tests/test_gpu_fuzz.py's randomised GPU-vs-oracle comparison (GPU box only).
-Usage: python tools/fuzz_more.py [first_seed] [count]"""
+Usage: [BIG=1] [OWN_STREAM=1] python tools/fuzz_more.py [first_seed] [count]
+BIG: two or three long dims (a few million elements); OWN_STREAM: every call runs on a library-owned stream (eager direct dispatch,
+self-released launches) instead of HIP's."""
 import os
 import sys
 
@@ -14,6 +16,11 @@ import oraclelib  # noqa: E402
 import strided_jl_amd as S  # noqa: E402
 import test_gpu_fuzz as F  # noqa: E402
 from util import fview, rtol  # noqa: E402
+
+
+# a library-owned stream is not ordered against torch's streams (S.Stream's contract): operands torch uploaded must be complete before
+# the call, the stream synchronised before torch reads the result
+HOOKS = {"before": lambda: None, "after": lambda: None}
 
 
 def problem_big(seed, T):
@@ -62,10 +69,12 @@ def problem_big(seed, T):
         odims = [1 if i in reduce_dims else dims[i] for i in range(N)]
         out = F._random_view(rng, mk, data, odims)
         mod = sys.modules["strided_jl_amd.mapreduce"]
+        HOOKS["before"]()
         if op is None:
             mod._mapreduce_fuse_(f, None, None, tuple(dims), S.promoteshape(tuple(dims), out, *ins))
         else:
             S._mapreducedim_(f, op, initop, tuple(dims), (out, *ins))
+        HOOKS["after"]()
         return out.toarray()
 
     return run, exact, dict(N=N, dims=dims, nin=nin, reduce=reduce_dims, op=op, initop=initop, alias=alias)
@@ -83,6 +92,10 @@ def main():
         return arrays[0]
 
     bad = 0
+    own = S.Stream() if os.environ.get("OWN_STREAM") else None
+    if own is not None:
+        HOOKS["before"] = F.HOOKS["before"] = torch.cuda.synchronize
+        HOOKS["after"] = F.HOOKS["after"] = own.synchronize
     for seed in range(first, first + count):
         for T in (np.float32, np.float64, np.complex64, np.complex128):
             run, exact, info = (problem_big if os.environ.get("BIG") else F._problem)(seed, T)
@@ -91,7 +104,11 @@ def main():
                 want = run(fview)
             finally:
                 mod._mapreduce_fuse_ = real
-            got = run(F.dview)
+            if own is not None:
+                with own:
+                    got = run(F.dview)
+            else:
+                got = run(F.dview)
             torch.cuda.synchronize()
             ok = got.shape == want.shape
             if ok:
