@@ -223,7 +223,7 @@ class Stream:
     are ordered; ~1.8 us of host time per call instead of 3.8) and fences by itself before every copy / synchronisation it performs on it.
     `with S.Stream() as st:` makes the front ends (broadcast `copyto_`, `map_`, `sum`, ...) launch on it; operands that torch produced
     on its own streams must be complete before (torch.cuda.synchronize()), and `st.synchronize()` (done on leaving the block) before
-    torch reads the results."""
+    torch reads the results (`view.toarray()` inside the block synchronises by itself)."""
 
     def __init__(self):
         h = C.c_void_p()

@@ -279,7 +279,14 @@ class StridedView:
         """Host copy of the logical array (applies op).  For tests and small results; the bulk
         device->host path is `Array(view)` in mapreduce.py."""
         if _is_torch(self.parent):
+            import ctypes
+            import importlib
             import torch
+            # inside `with S.Stream():` the launches went to a library-owned stream, which torch's streams are not ordered against:
+            # finish it before torch gathers (found by tools/fuzz_more.py OWN_STREAM=1, whose harness read stale results)
+            own = importlib.import_module(".mapreduce", __package__)._STREAM_OVERRIDE.stack
+            if own:
+                L.check(L.load().smr_stream_sync(ctypes.c_void_p(own[-1])))
             p = self.parent.detach()
             st = p.untyped_storage()
             n_after = st.nbytes() // self.dtype.itemsize - p.storage_offset()

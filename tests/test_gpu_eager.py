@@ -178,9 +178,13 @@ def test_front_ends_inside_a_stream_block_use_direct_dispatch():
         C1 = S.map(lambda x, y: x * y - 2 * x, A, B)                       # allocates (torch), launches on the stream
         S.map_(lambda x: x + 1, out, out)                                  # depends on the permutedims! above
         r = S.sum(C1, dims=(0, 2))
+        big = dev(rng.standard_normal((600, 500, 8)))
+        torch.cuda.synchronize()                                           # (torch's upload is not ordered against the library stream)
+        inside = S.sum(big, dims=(0, 1)).toarray()                         # toarray() inside the block finishes the library stream first
     torch.cuda.synchronize()
     after = stats()
     st.close()
+    assert np.allclose(inside, host(big).sum(axis=(0, 1), keepdims=True), rtol=1e-12)
     assert after["launches"] - before["launches"] >= 4, (before, after)
     assert np.array_equal(host(out), np.transpose(a, (2, 1, 0)) + 1)
     assert np.array_equal(C1.toarray(), a * b - 2 * a)
