@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--extra-timeout", type=int, default=300, help="N > 1: seconds the secondary workloads may take before the headline is printed without them")
     ap.add_argument("--extras", default="all", help="comma-separated subset of the secondary workloads: c1,hbm128,cold,c5,c4 (default: all)")
     ap.add_argument("--step-mode", choices=("seq", "seq1", "inorder", "chains"), default="seq",
                     help="seq: the library's own replay of the recorded step (smr_seq: AQL packets on its HSA queues, one queue per "
@@ -263,14 +264,14 @@ def main():
     # (tests/libfake_rccl.so: N processes sharing ONE GPU) -- the ranks meet over gloo instead and all land on the devices there are:
     # the rehearsal of the whole N-rank bench path (launcher, communicator, sharded config 4, JSON assembly) on a one-GPU box.
     rehearsal = bool(os.environ.get("SMR_RCCL_LIB"))
+    ndev = max(1, torch.cuda.device_count())
+    local = local % ndev if rehearsal else local
+    torch.cuda.set_device(local)          # before the process group: RCCL binds its communicator to the current device
+    dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
-    ndev = max(1, torch.cuda.device_count())
-    local = local % ndev if rehearsal else local
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     red_dev = torch.device("cpu") if rehearsal else dev   # where the ranks' scalars are reduced (gloo: host tensors)
 
     def barrier():
@@ -489,12 +490,32 @@ def main():
     }
 
     extra = {}
+    stuck = False
     if not args.no_extra:
-        try:
-            extra = secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur,
-                              only=None if args.extras == "all" else set(args.extras.split(",")), red_dev=red_dev)
-        except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
-            extra = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        def run_extra():
+            try:
+                torch.cuda.set_device(local)
+                if os.environ.get("BENCH_SIMULATE_STUCK_RANK") == str(rank):   # test hook for the watchdog below
+                    time.sleep(1e6)
+                return secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur,
+                                 only=None if args.extras == "all" else set(args.extras.split(",")), red_dev=red_dev)
+            except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
+                return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if world == 1:
+            extra = run_extra()
+        else:
+            # N ranks: the secondary workloads include the sharded config 4, whose all-reduce the library issues on its own RCCL
+            # communicator -- a collective that does not complete (a rank that failed, a bootstrap that cannot connect) must not take
+            # the headline line with it: the legs run beside a watchdog, and a rank that is still stuck when it fires reports that and
+            # leaves without the final barrier
+            import threading
+            box = {}
+            th = threading.Thread(target=lambda: box.update(extra=run_extra()), daemon=True)
+            th.start()
+            th.join(timeout=args.extra_timeout)
+            stuck = th.is_alive()
+            extra = ({"error": "the secondary workloads did not finish within %d s on rank %d (a collective that did not complete?); the headline "
+                               "above was measured before them" % (args.extra_timeout, rank)} if stuck else box.get("extra", {}))
 
     if rank == 0:
         out = {
@@ -526,10 +547,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(S)
         if extra:
             out["extra"] = extra
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if not stuck:   # (a peer may be stuck: the closing barrier gets a watchdog of its own)
+            import threading
+            th = threading.Thread(target=lambda: (dist.barrier(), dist.destroy_process_group()), daemon=True)
+            th.start()
+            th.join(timeout=60)
+            stuck = th.is_alive()
+        if stuck:
+            sys.stdout.flush()
+            os._exit(0)
 
 
 def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur, only=None, red_dev=None):
