@@ -247,6 +247,7 @@ struct Direct {
     // kernarg layouts by code object (storage base address of the loaded image) and kernel-descriptor symbol
     std::map<uint64_t, std::map<std::string, KernargLayout>> code_objects;
     int n_meta = 0, n_v5 = 0;    // kernels resolved with a layout from metadata / from the v5 rule
+    bool agent_by_pci = false;   // the HSA agent was found by the HIP device's PCI address (false: the only GPU agent there is)
     bool probe_ok = false;       // the self-test launch saw the blockDim / gridDim / LDS it was given
     bool probe_meta = false;     // ... with a layout read from metadata
     // SEQ_MAXQ hardware queues of the library's own (created on first use): launches that belong to different dependency
@@ -425,6 +426,7 @@ Direct& direct_of(int dev) {
         }
     }
     d->agent = pick.found;
+    d->agent_by_pci = pick.have;
     if (int rc = direct_queue(*d, 0)) {
         (void)rc;
         return *d;
@@ -1907,10 +1909,10 @@ int smr_seq_info(smr_seq* q, char* buf, size_t buflen) {
     if (q->aql) {
         size_t np = 0;
         for (const auto& v : q->packets) np += v.size();
-        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d sliced=%d queues=%d ordered=%d unordered=%d acquire=%s(%d of %zu packets) first_acquire=%s release=%d self_released=%d kernarg_layout=%s stream_wait=%s last_replay_us=%.3f",
+        std::snprintf(buf, buflen, "backend=aql items=%zu packets=%zu components=%d sliced=%d queues=%d ordered=%d unordered=%d acquire=%s(%d of %zu packets) first_acquire=%s release=%d self_released=%d kernarg_layout=%s agent=%s stream_wait=%s last_replay_us=%.3f",
                       q->items.size(), np, q->ncomp, q->nsliced, q->nq, q->n_barrier, q->n_any, q->acq_mid < 0 ? "by-need" : (q->acq_mid == 0 ? "none" : (q->acq_mid == 1 ? "agent" : "system")),
                       q->n_acquire, np, (q->acq_first >= 0 ? q->acq_first : q->acq_first_auto) == 2 ? "system" : ((q->acq_first >= 0 ? q->acq_first : q->acq_first_auto) == 1 ? "agent" : "none"),
-                      q->rel_mid, q->n_self_released, layout_source(direct_of(q->device)),
+                      q->rel_mid, q->n_self_released, layout_source(direct_of(q->device)), direct_of(q->device).agent_by_pci ? "pci-address" : "only-gpu",
                       q->async_mode == 0 ? "host(blocking)" : (direct_of(q->device).wait_value_ok ? "hipStreamWaitValue64" : "holding-kernel|owned-stream"),
                       direct_of(q->device).last_us);
     }

@@ -72,6 +72,7 @@ def test_kernarg_layout_comes_from_metadata_and_the_selftest_passed():
     info = q.info()
     assert field(info, "backend") == "aql", info
     assert field(info, "kernarg_layout") == "metadata+verified", info
+    assert field(info, "agent") == "pci-address", info     # the HSA agent is the HIP device's, found by PCI domain / bus / device (matters with 8 GPUs)
     assert np.array_equal(host(B), w2) and np.array_equal(host(Cc), w3)
 
 
