@@ -358,6 +358,49 @@ def test_admitted_calls_compute_what_julia_computes(seed):
     assert nadmit >= 40 and nwrapped >= 5, (nadmit, nwrapped, nrefuse)
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_admitted_reductions_compute_what_julia_computes(seed):
+    """The same property for reductions into an Int64 accumulator (sum / maximum / minimum of f over the elements): the reduction
+    observes f's value at 64 bits, so a narrow result must be re-wrapped before it is accumulated -- abs2(::Int32) summed at 64 bits is
+    the sum of the WRAPPED squares."""
+    rng = np.random.default_rng(5000 + seed)
+    n, nadmit, nwrapped = 24, 0, 0
+    for trial in range(80):
+        nargs = int(rng.integers(1, 3))
+        tree = random_tree(rng, int(rng.integers(1, 4)), nargs)
+        if folds(tree) or tree[0] == "const":
+            continue
+        ins_dt = [dt for dt in INPUTS if dt != np.uint64]          # UInt64 + Int64 promotes to UInt64: the accumulator would not be an Int64
+        dts = [ins_dt[int(rng.integers(0, len(ins_dt)))] for _ in range(nargs)]
+        op = ["+", "max", "min"][int(rng.integers(0, 3))]
+        ins = [adversarial(rng, dt, n) for dt in dts]
+        f, need = to_lambda(tree)
+        views = tuple(fview(a) for a in ins[:need])
+        d0 = int(rng.integers(-1000, 1000))
+        acc = np.array([d0], dtype=np.int64)
+        dest = S.StridedView(acc, (n,), (0,), 0)
+        try:
+            got = int(run_oracle(f, op, None, (n,), (dest,) + views).ravel()[0])
+        except Exception as e:  # noqa: BLE001
+            assert "nsupported" in str(e) or "64-bit" in str(e), (tree, e)
+            continue
+        vals = []
+        for i in range(n):
+            args = [Val(int(a[i]), 1 if a.dtype == np.bool_ else a.dtype.itemsize * 8, np.issubdtype(a.dtype, np.signedinteger)) for a in ins[:need]]
+            vals.append(julia_eval(tree, args).v)
+        fold = {"+": lambda xs: wrap(d0 + sum(xs), 64, True), "max": lambda xs: max([d0] + xs), "min": lambda xs: min([d0] + xs)}[op]
+        assert got == fold(vals), ("oracle vs Julia's typing", tree, dts[:need], op)
+        cp = canon_prog(f, op, (n,), (S.StridedView(np.array([d0], dtype=np.int64), (n,), (0,), 0),) + views)
+        if cp is None or cp[4] != I64:
+            continue
+        prog, consts, nw, orig, _ = cp
+        nadmit += 1
+        nwrapped += nw > 0
+        wide = [wide_eval(prog, consts, orig, [0] + [int(a[i]) for a in ins[:need]]) for i in range(n)]
+        assert fold(wide) == got, ("the planner admitted a reduction whose 64-bit evaluation differs from Julia's", tree, dts[:need], op, prog)
+    assert nadmit >= 25 and nwrapped >= 5, (nadmit, nwrapped)
+
+
 # ---- on the device --------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("jit", [1, 0])
@@ -409,6 +452,26 @@ def test_hip_rewrapped_programs_equal_the_oracle(jit):
             nrun += 1
             nwrapped += cp[2] > 0
         assert nwrapped >= (10 if jit else 25), (nrun, nwrapped)
+        nred = 0
+        for trial in range(0 if jit else 150):                          # reductions into an Int64 accumulator (interpreter only: no hiprtc time)
+            nargs = int(rng.integers(1, 3))
+            tree = random_tree(rng, int(rng.integers(1, 4)), nargs)
+            if folds(tree) or tree[0] == "const":
+                continue
+            ins_dt = [dt for dt in INPUTS if dt != np.uint64]
+            ins = [adversarial(rng, ins_dt[int(rng.integers(0, len(ins_dt)))], 3000) for _ in range(nargs)]
+            op = ["+", "max", "min"][int(rng.integers(0, 3))]
+            f, need = to_lambda(tree)
+            views = tuple(fview(v) for v in ins[:need])
+            mk = lambda: S.StridedView(np.array([17], dtype=np.int64), (3000,), (0,), 0)  # noqa: E731
+            cp = canon_prog(f, op, (3000,), (mk(),) + views)
+            if cp is None or cp[4] != I64 or cp[2] == 0:
+                continue
+            got = run_device(f, op, None, (3000,), (mk(),) + views)
+            want = run_oracle(f, op, None, (3000,), (mk(),) + views)
+            assert int(np.asarray(got).ravel()[0]) == int(np.asarray(want).ravel()[0]), (tree, op, [v.dtype for v in ins[:need]], cp[0])
+            nred += 1
+        assert jit or nred >= 15, nred
     finally:
         S.set_option("jit", old)
 
