@@ -352,7 +352,12 @@ int64_t smr_plan_algorithmic_bytes(const smr_plan* plan);
  * reference walks its blocks in loop order, src/mapreduce.jl:385-401).  Returns the number
  * of workgroups n of the launch, or 0 when tiles run in natural order; writes
  * min(n, cap) entries: out[b] = linear tile id executed by workgroup b, 0xffffffff = idle
- * padding.  Workgroup b runs on XCD b mod 8.                                              */
+ * padding.  Workgroup b runs on XCD b mod 8.
+ * ORBIT family: a workgroup holds one tile per LDS slot (as many slots as the views' permutation group has elements, four for a
+ * group of order three); the list has `slots` entries per workgroup (n = slots * grid, `grid` as smr_plan_describe prints it):
+ * out[b * slots + g] = tile in slot g of workgroup b, the first of an idle workgroup is 0xffffffff.  Every tile of the box
+ * appears exactly once, except that a group of order three repeats slot 0 in slot 3 and an incomplete last workgroup of
+ * shared (diagonal) orbits repeats its slot 0.                                             */
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap);
 /* Introspection of the two-sided FLAT form (no reference counterpart): the two memory runs a tile is the product of, for the
  * planner tests (tests/test_abi.py walks every tile with these numbers on the CPU and checks that each element of the box is

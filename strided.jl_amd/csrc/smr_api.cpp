@@ -721,7 +721,7 @@ int smr_plan_jit_source(const smr_plan* plan, char* buf, size_t buflen) {
 
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
     if (!plan || (plan->plan.family != FAM_TILED && plan->plan.family != FAM_ORBIT)) return 0;
-    const std::vector<uint32_t>& ord = plan->plan.family == FAM_ORBIT ? plan->plan.orbit.list : plan->plan.tile.ord;
+    const std::vector<uint32_t>& ord = plan->plan.family == FAM_ORBIT ? plan->plan.orbit.wtile : plan->plan.tile.ord;
     if (out)
         for (size_t i = 0; i < ord.size() && i < cap; ++i) out[i] = ord[i];
     return (int64_t)ord.size();
@@ -940,6 +940,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "nt_load") o.nt_load = value;
     else if (n == "orbit_min") o.orbit_min = value;
     else if (n == "orbit_few") o.orbit_few = value;
+    else if (n == "orbit_pack") o.orbit_pack = value;
     else if (n == "orbit_pipe") o.orbit_pipe = value;
     else if (n == "orbit_lds_min") o.orbit_lds_min = value;
     else if (n == "orbit_group") o.orbit_group = value;
@@ -1035,6 +1036,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "nt_load") return o.nt_load;
     if (n == "orbit_min") return o.orbit_min;
     if (n == "orbit_few") return o.orbit_few;
+    if (n == "orbit_pack") return o.orbit_pack;
     if (n == "orbit_pipe") return o.orbit_pipe;
     if (n == "orbit_lds_min") return o.orbit_lds_min;
     if (n == "orbit_group") return o.orbit_group;

@@ -158,8 +158,15 @@ struct OrbitPlan {
     i64 ntiles[MAXN];
     i64 ntiles_total = 1;
     int norbits = 0;
-    std::vector<uint32_t> list;  // root tile of the orbit executed by workgroup b (0xffffffff = idle);
-                                 // grouped by super-cells, one contiguous run per XCD
+    std::vector<uint32_t> list;  // root tile of every orbit, in execution order (grouped by super-cells)
+    // The work list the kernel walks (round 6): `nslots` tile ids per workgroup (0xffffffff in the first = idle), dealt in one contiguous
+    // run per XCD, and per workgroup the 2-bit fields (slot * 8 + input) * 2 of `wmap`: the LDS slot an output of that slot reads that
+    // input from.  A full orbit fills the slots with g_a . t (the map is `slot` for every workgroup); orbits with a stabiliser (tiles on
+    // a diagonal: 36 of the 1044 at 32^4) have fewer distinct tiles and SHARE a workgroup (option orbit_pack), so that no tile is loaded
+    // or stored twice and -- at 32^4 -- the launch is 1024 workgroups, four on every CU, instead of 1048.
+    int nslots = 0;
+    std::vector<uint32_t> wtile;
+    std::vector<uint64_t> wmap;
     size_t lds_bytes = 0;
 };
 
@@ -306,6 +313,7 @@ struct Options {
                              // 5.60 -> 4.61 us, 24^4 3.41 -> 3.01 us; larger sizes keep the 8^4 cubes)
     i64 orbit_wgs = 0;       // persistent ORBIT form: cap on the number of workgroups (0 = as many as the machine holds at once)
     i64 orbit_lds_min = 0;   // experiment: request at least this much LDS per ORBIT workgroup (limits residency)
+    i64 orbit_pack = 1;      // orbits with fewer distinct tiles than |G| share a workgroup (0: one workgroup per orbit, tiles repeated)
     i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
     i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes (default 0: all) and
                              // TILED tiles that write whole 128-byte lines (profiles/r02_nt_store_ab.txt: configs[4]

@@ -46,7 +46,10 @@ constexpr int OMAXT = 4;  // tiled dims = dims of the unit class <= |G| <= 4
 struct OrbitArgs {
     const char* src;  // the shared buffer, element offset applied
     char* dst;
-    const uint32_t* list;  // per workgroup: the NG slot origins (element offsets; [0] = 0xffffffff: idle)
+    const uint32_t* list;  // per workgroup a row of 2 * NG words: the NG slot origins (element offsets; [0] = 0xffffffff: idle), then the
+                           // 64-bit slot map -- field (g * 8 + k) * 2: the LDS slot an output of slot g reads input k from.  (The
+                           // natively compiled kernels receive this pointer once more as their FIRST parameter: it is preloaded
+                           // into SGPRs with the wave, and the row's load leaves before the kernel arguments have been fetched.)
     const uint32_t* lanetab;  // [(r * NT + tid) * rowlen]: byte offset, then the LDS read index of every non-own view
     int32_t nin, tilelog, ntlog, conj0, nts, nlist;  // nlist: rows of `list` (PIPE form)
     uint32_t swz_s1, swz_s2, swz_mask, pad1;
@@ -54,9 +57,33 @@ struct OrbitArgs {
     int32_t esh[OMAXT], elen[OMAXT];
     uint32_t estride[OMAXT];       // byte stride of tiled dim j
     int32_t lsh[MAXIN][OMAXT];     // LDS bit position of tiled dim j as seen through view k
-    int32_t slot[MAXG][MAXIN];     // LDS slot view k of slot a's outputs reads from
     uint32_t conjbit[MAXIN];       // 0x80000000 when view k is conjugated (complex types)
 };
+
+// What a wave needs before its first global load can leave: the natively compiled kernels receive these as LEADING SCALAR
+// parameters, which gfx950 preloads into SGPRs with the wave (Makefile: -mllvm -amdgpu-kernarg-preload-count=16) -- the only
+// memory round trip in front of the loads is then the origin row's.  (Left in the argument struct the compiler fetched them in
+// two dependent batches of scalar loads: tools/orbit32_probe.hip, profiles/r06_orbit_phases.txt.)
+struct OrbitHead {
+    const uint32_t* list;  // = OrbitArgs::list
+    const char* src;       // = OrbitArgs::src
+    uint32_t eshp, elenp;  // esh[j] / elen[j] in byte j
+    uint32_t estride[OMAXT];
+    uint32_t ntlog;
+};
+static inline __host__ __device__ OrbitHead orbit_head(const OrbitArgs& a) {
+    OrbitHead h;
+    h.list = a.list;
+    h.src = a.src;
+    h.eshp = h.elenp = 0;
+    for (int j = 0; j < OMAXT; ++j) {
+        h.eshp |= (uint32_t)a.esh[j] << (8 * j);
+        h.elenp |= (uint32_t)a.elen[j] << (8 * j);
+        h.estride[j] = a.estride[j];
+    }
+    h.ntlog = (uint32_t)a.ntlog;
+    return h;
+}
 
 template <class T, int V>
 struct alignas(sizeof(T) * V) OVec {
@@ -79,7 +106,7 @@ SMR_DEV c64 ocj(c64 x, uint32_t bit) {
 // list with stride gridDim.x (a multiple of 8: it stays on its XCD's run) and issues the loads of its next orbit
 // right after the barrier, so that they fly during the exchange and the stores of the current one.
 template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE = false>
-SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
+SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
     typedef OVec<T, V> VT;
     constexpr int NIN_STATIC = F::NIN;
     constexpr int NINMAX = (NIN_STATIC >= 0) ? NIN_STATIC : MAXIN;
@@ -90,20 +117,22 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     const uint32_t tid = threadIdx.x;
     // ---- slot origins: one wide scalar load of this workgroup's table row -----------------------------
     i64 org[NG];
+    uint64_t smap;
     bool live;
-    auto load_row = [&](uint32_t b, i64(&og)[NG], bool& lv) {
-        typedef uint32_t rowv __attribute__((ext_vector_type(NG)));
-        const rowv row = reinterpret_cast<const rowv*>(a.list)[b];
+    auto load_row = [&](uint32_t b, i64(&og)[NG], uint64_t& mp, bool& lv) {
+        typedef uint32_t rowv __attribute__((ext_vector_type(2 * NG)));
+        const rowv row = reinterpret_cast<const rowv*>(h.list)[b];
         uint32_t o32[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) o32[g] = row[g];
+        mp = (uint64_t)row[NG] | ((uint64_t)row[NG + 1] << 32);
         // a padding workgroup (first word 0xffffffff) runs on slot origins 0 and only skips its stores: an early
         // exit here would keep every other kernel-argument load behind this row's round trip
         lv = o32[0] != 0xffffffffu;
 #pragma unroll
         for (int g = 0; g < NG; ++g) og[g] = lv ? (i64)o32[g] * (i64)sizeof(T) : 0;
     };
-    load_row(blockIdx.x, org, live);
+    load_row(blockIdx.x, org, smap, live);
 
     // ---- per-lane byte offsets inside a tile + LDS read indices -----------------------------------------
     constexpr int NLR = NK - (OWN0 ? 1 : 0);      // views read from LDS
@@ -116,7 +145,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
         typedef uint32_t trow __attribute__((ext_vector_type(ROWLEN)));
 #pragma unroll
         for (int r = 0; r < NREP; ++r) {
-            const trow t = reinterpret_cast<const trow*>(a.lanetab)[((uint32_t)r << a.ntlog) | tid];
+            const trow t = reinterpret_cast<const trow*>(a.lanetab)[((uint32_t)r << h.ntlog) | tid];
             goff[r] = t[0];
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
@@ -129,12 +158,12 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     uint32_t cj[NREP][OMAXT];
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
-        const uint32_t e = (((uint32_t)r << a.ntlog) | tid) * V;
+        const uint32_t e = (((uint32_t)r << h.ntlog) | tid) * V;
         uint32_t g = 0;
 #pragma unroll
         for (int j = 0; j < OMAXT; ++j) {
-            cj[r][j] = __builtin_amdgcn_ubfe(e, (uint32_t)a.esh[j], (uint32_t)a.elen[j]);
-            g += cj[r][j] * a.estride[j];
+            cj[r][j] = __builtin_amdgcn_ubfe(e, (h.eshp >> (8 * j)) & 0xffu, (h.elenp >> (8 * j)) & 0xffu);
+            g += cj[r][j] * h.estride[j];
         }
         goff[r] = g;
     }
@@ -145,7 +174,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < NREP; ++r) x[g][r] = *reinterpret_cast<const VT*>(a.src + org[g] + goff[r]);
+        for (int r = 0; r < NREP; ++r) x[g][r] = *reinterpret_cast<const VT*>(h.src + org[g] + goff[r]);
 
     // ---- while the loads fly: everything the exchange needs from the kernel arguments ---------------
     // (left to itself the compiler sinks these scalar loads below the barrier: one more serial scalar-memory
@@ -166,16 +195,25 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
     uint32_t swz_s1 = a.swz_s1, swz_s2 = a.swz_s2, swz_mask = a.swz_mask;
     asm volatile("" : "+s"(swz_s1), "+s"(swz_s2), "+s"(swz_mask));
     uint32_t sbase[NG][NK], hbit[NK], cbit[NK];
+    uint32_t tilelog = (uint32_t)a.tilelog;
+    asm volatile("" : "+s"(tilelog));
+    // the LDS slot every (output slot, view) pair reads from: fields of this workgroup's row (orbits that share a workgroup have
+    // their own little maps: smr_plan.cpp, plan_orbit)
+    auto slot_bases = [&](uint64_t mp) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                sbase[g][k] = ((uint32_t)(mp >> ((g * 8 + k) * 2)) & 3u) << tilelog;
+                asm volatile("" : "+s"(sbase[g][k]));
+            }
+    };
+    slot_bases(smap);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         hbit[k] = (uint32_t)a.lsh[k][0];
         cbit[k] = a.conjbit[k];
         asm volatile("" : "+s"(hbit[k]), "+s"(cbit[k]));
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            sbase[g][k] = (uint32_t)a.slot[g][k] << a.tilelog;
-            asm volatile("" : "+s"(sbase[g][k]));
-        }
 #pragma unroll
         for (int r = 0; r < NREP; ++r) asm volatile("" : "+v"(lr[k][r]));
     }
@@ -199,11 +237,12 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
         // no branch in front of the LDS stores), so that it has arrived when the barrier opens and the next loads
         // leave right behind it
         i64 norg[NG];
+        uint64_t nmap = 0;
         bool nlive = false, more = false;
         if constexpr (PIPE) {
             wg += gridDim.x;
             more = wg < (uint32_t)a.nlist;
-            load_row(more ? wg : (uint32_t)a.nlist - 1u, norg, nlive);
+            load_row(more ? wg : (uint32_t)a.nlist - 1u, norg, nmap, nlive);
         }
         // ---- park the slots in LDS ---------------------------------------------------------------------------
 #pragma unroll
@@ -211,7 +250,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
             T* L = lds + ((size_t)g << a.tilelog);
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
-                const uint32_t e = (((uint32_t)r << a.ntlog) | tidp) * V;
+                const uint32_t e = (((uint32_t)r << h.ntlog) | tidp) * V;
 #pragma unroll
                 for (int h = 0; h < V; ++h) L[swz(e + h)] = x[g][r].v[h];
             }
@@ -223,7 +262,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < NREP; ++r) xn[g][r] = *reinterpret_cast<const VT*>(a.src + norg[g] + goff[r]);
+                    for (int r = 0; r < NREP; ++r) xn[g][r] = *reinterpret_cast<const VT*>(h.src + norg[g] + goff[r]);
             }
         }
 
@@ -314,6 +353,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
             }
             __syncthreads();  // every lane has read its LDS values: the slots may be overwritten
             live = nlive;
+            slot_bases(nmap);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 org[g] = norg[g];
@@ -326,9 +366,22 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, F f) {
 
 #ifndef SMR_JIT
 template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE>
-__global__ void __launch_bounds__(1024) k_orbit_map(const OrbitArgs a, F f SMR_STAMP_PARAM) {
+__global__ void __launch_bounds__(1024) k_orbit_map(const uint32_t* list, const char* src, uint32_t eshp, uint32_t elenp, uint32_t es0, uint32_t es1,
+                                                    uint32_t es2, uint32_t es3, uint32_t ntlog, const OrbitArgs a, F f SMR_STAMP_PARAM) {
+    // the leading scalars = OrbitHead, preloaded into SGPRs: the origin row's load is the first thing the wave does, and the global
+    // loads leave as soon as it is back (tools/orbit32_probe.hip: 4.76 -> 4.45 us at 32^4)
     SMR_STAMP_BEGIN
-    orbit_map_body<T, F, V, NREP, NG, OWN0, PIPE>(a, f);
+    OrbitHead h;
+    h.list = list;
+    h.src = src;
+    h.eshp = eshp;
+    h.elenp = elenp;
+    h.estride[0] = es0;
+    h.estride[1] = es1;
+    h.estride[2] = es2;
+    h.estride[3] = es3;
+    h.ntlog = ntlog;
+    orbit_map_body<T, F, V, NREP, NG, OWN0, PIPE>(a, h, f);
     SMR_STAMP_END
 }
 
@@ -429,30 +482,32 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             for (int d = 0; d < c.N; ++d)
                 if (jof[d] >= 0) a.lsh[k - 1][jof[d]] = a.esh[jof[o.pdim[k][d]]];
             a.conjbit[k - 1] = tab.conj[k] ? 0x80000000u : 0u;
-            for (int g = 0; g < NG; ++g) a.slot[g][k - 1] = o.slot[g < o.ng ? g : 0][k];
         }
+        if (o.nslots != NG) return set_error(SMR_EINVAL, "orbit: slot count mismatch");
         const OSwz sw = choose_orbit_swizzle(a, c.M - 1, OWN0, (int)sizeof(T), V, NREP);
         a.swz_s1 = sw.s1;
         a.swz_s2 = sw.s2;
         a.swz_mask = sw.mask;
         if (!plan.ordtab && !jit_dry_run()) {
-            // origin table: slot g of the orbit rooted at tile t holds tile g.t, whose coordinate along dim
-            // gdim[g][d] is t[d]; a group of order 3 is padded with a copy of slot 0 (its outputs are
-            // written twice, with identical values)
-            std::vector<uint32_t> rows(o.list.size() * NG, 0xffffffffu);
-            for (size_t w = 0; w < o.list.size(); ++w) {
-                if (o.list[w] == 0xffffffffu) continue;
-                i64 id = o.list[w], tc[MAXN];
-                for (int d = 0; d < c.N; ++d) {
-                    tc[d] = id % o.ntiles[d];
-                    id /= o.ntiles[d];
+            // one row per workgroup: the NG slot origins (element offset of the tile in each slot), then the slot map (plan_orbit)
+            const size_t nwg = o.wmap.size();
+            std::vector<uint32_t> rows(nwg * 2 * NG, 0u);
+            for (size_t w = 0; w < nwg; ++w) {
+                uint32_t* row = &rows[w * 2 * NG];
+                if (o.wtile[w * NG] == 0xffffffffu) {
+                    row[0] = 0xffffffffu;
+                    continue;
                 }
                 for (int g = 0; g < NG; ++g) {
-                    const int gg = g < o.ng ? g : 0;
-                    i64 org = 0;
-                    for (int d = 0; d < c.N; ++d) org += tc[d] * (c.strides[o.k0][o.gdim[gg][d]] << o.lg[d]);
-                    rows[w * NG + g] = (uint32_t)org;
+                    i64 id = o.wtile[w * NG + g], org = 0;
+                    for (int d = 0; d < c.N; ++d) {
+                        org += (id % o.ntiles[d]) * (c.strides[o.k0][d] << o.lg[d]);
+                        id /= o.ntiles[d];
+                    }
+                    row[g] = (uint32_t)org;
                 }
+                row[NG] = (uint32_t)o.wmap[w];
+                row[NG + 1] = (uint32_t)(o.wmap[w] >> 32);
             }
             void* dptr = nullptr;
             hipError_t e = hipMalloc(&dptr, rows.size() * sizeof(uint32_t));
@@ -511,8 +566,8 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     const unsigned block = 1u << a.ntlog;
     size_t lds = (size_t)NG * (sizeof(T) << o.tilelog);
     if (opt.orbit_lds_min > 0) lds = std::max(lds, (size_t)opt.orbit_lds_min);  // experiment: fewer resident workgroups per CU
-    a.nlist = (int32_t)o.list.size();
-    unsigned grid = (unsigned)o.list.size();
+    a.nlist = (int32_t)o.wmap.size();
+    unsigned grid = (unsigned)o.wmap.size();
     if (PIPE) {
         // as many workgroups as the machine holds at once, a multiple of 8 so that a workgroup stays on its XCD's run
         static const int ncu = [] {
@@ -531,7 +586,7 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         l.tname = tname<T>();
         l.argtype = "smr::OrbitArgs";
         l.entry = std::string("smr::orbit_map_body<") + tname<T>() + ", smr::FJit, " + std::to_string(V) + ", " + std::to_string(NREP) + ", " +
-                  std::to_string(NG) + ", " + (OWN0 ? "true" : "false") + ", " + (PIPE ? "true" : "false") + ">(a, smr::FJit{kc});";
+                  std::to_string(NG) + ", " + (OWN0 ? "true" : "false") + ", " + (PIPE ? "true" : "false") + ">(a, smr::orbit_head(a), smr::FJit{kc});";
         l.grid = grid;
         l.block = block;
         l.lds = lds;
@@ -546,9 +601,11 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_error(e, "hipFuncSetAttribute(lds)");
         }
-        if (!PIPE) mark_sliceable(2, (unsigned)offsetof(OrbitArgs, list), (unsigned)(NG * sizeof(uint32_t)));  // one table row per workgroup
+        if (!PIPE) mark_sliceable(2, 0u, (unsigned)(2 * NG * sizeof(uint32_t)));  // one table row per workgroup; the pointer is parameter 0
         if (a.nts == 2) mark_self_released();
-        SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, a, f SMR_STAMP_ARG(grid, block));
+        const OrbitHead h = orbit_head(a);
+        SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, h.list, h.src, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3], h.ntlog, a,
+                   f SMR_STAMP_ARG(grid, block));
         return check_launch("k_orbit_map");
     }
 }

@@ -983,25 +983,114 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
         }
     }
     o.norbits = (int)list.size();
+    o.list = list;
+    // ---- workgroups: the tiles of an orbit fill the LDS slots of one workgroup; orbits with fewer distinct tiles share one ------------
+    const int NS = o.ng == 3 ? 4 : o.ng;  // a group of order 3 runs in four slots (the fourth repeats the first)
+    o.nslots = NS;
+    struct Wg {
+        uint32_t tile[MAXG];
+        uint64_t map;
+    };
+    auto field = [](int g, int k) { return (unsigned)((g * 8 + k) * 2); };  // k = input index - 1
+    std::vector<Wg> wgs;
+    std::vector<uint32_t> cell_wg;  // super-cell of every workgroup (orbit_deal = 1)
+    // pending[s]: orbits of s distinct tiles waiting for company -- (tiles, per-tile reads as indices into the orbit's own tiles)
+    struct Part {
+        uint32_t tile[MAXG];
+        int rd[MAXG][MAXM];
+        int n;
+    };
+    std::vector<Part> pending[MAXG + 1];
+    auto emit_packed = [&](int sdist, uint32_t cell) {
+        std::vector<Part>& pp = pending[sdist];
+        if (pp.empty()) return;
+        Wg w;
+        w.map = 0;
+        int base = 0;
+        for (const Part& q : pp) {
+            for (int j = 0; j < q.n; ++j) {
+                w.tile[base + j] = q.tile[j];
+                for (int k = 1; k < c.M; ++k) w.map |= (uint64_t)(base + q.rd[j][k]) << field(base + j, k - 1);
+            }
+            base += q.n;
+        }
+        for (int g = base; g < NS; ++g) {  // an incomplete last workgroup: the free slots repeat slot 0 (identical values are stored twice)
+            w.tile[g] = w.tile[0];
+            for (int k = 1; k < c.M; ++k) w.map |= ((w.map >> field(0, k - 1)) & 3u) << field(g, k - 1);
+        }
+        wgs.push_back(w);
+        cell_wg.push_back(cell);
+        pp.clear();
+    };
+    for (size_t i = 0; i < list.size(); ++i) {
+        i64 tc[MAXN], id = list[i];
+        for (int d = 0; d < c.N; ++d) {
+            tc[d] = id % o.ntiles[d];
+            id /= o.ntiles[d];
+        }
+        uint32_t ids[MAXG];
+        for (int a = 0; a < o.ng; ++a) {
+            i64 v = 0;
+            for (int d = 0; d < c.N; ++d) v += tc[d] * tmul[G[a][d]];
+            ids[a] = (uint32_t)v;
+        }
+        int first[MAXG], ndist = 0, dix[MAXG];  // dix[a]: index of g_a . t among the distinct tiles
+        for (int a = 0; a < o.ng; ++a) {
+            dix[a] = -1;
+            for (int b = 0; b < a && dix[a] < 0; ++b)
+                if (ids[b] == ids[a]) dix[a] = dix[b];
+            if (dix[a] < 0) {
+                dix[a] = ndist;
+                first[ndist++] = a;
+            }
+        }
+        if (ndist == o.ng || !opt.orbit_pack || NS / ndist < 2) {
+            Wg w;
+            w.map = 0;
+            for (int g = 0; g < NS; ++g) {
+                const int a = g < o.ng ? g : 0;
+                w.tile[g] = ids[a];
+                for (int k = 1; k < c.M; ++k) w.map |= (uint64_t)o.slot[a][k] << field(g, k - 1);
+            }
+            wgs.push_back(w);
+            cell_wg.push_back(cell_of[i]);
+            continue;
+        }
+        Part q;
+        q.n = ndist;
+        for (int j = 0; j < ndist; ++j) {
+            q.tile[j] = ids[first[j]];
+            for (int k = 1; k < c.M; ++k) q.rd[j][k] = dix[o.slot[first[j]][k]];
+        }
+        pending[ndist].push_back(q);
+        if ((int)pending[ndist].size() * ndist + ndist > NS) emit_packed(ndist, cell_of[i]);
+    }
+    for (int sd = 1; sd <= MAXG; ++sd) emit_packed(sd, cell_wg.empty() ? 0u : cell_wg.back());
     constexpr int NX = 8;
+    auto place = [&](size_t pos, const Wg& w) {
+        for (int g = 0; g < NS; ++g) o.wtile[pos * NS + g] = w.tile[g];
+        o.wmap[pos] = w.map;
+    };
     if (opt.orbit_deal == 1) {
         // experiment (round 5): super-cell c runs on XCD c mod 8 -- consecutive super-cells step along dim 0, so at any time the eight
         // XCDs work on eight neighbours along the buffer's unit axis (whole DRAM pages chip-wide) while the partner halves of every
         // line still meet inside one XCD's L2
-        std::vector<uint32_t> perx[NX];
-        for (size_t i = 0; i < list.size(); ++i) perx[cell_of[i] % NX].push_back(list[i]);
+        std::vector<size_t> perx[NX];
+        for (size_t i = 0; i < wgs.size(); ++i) perx[cell_wg[i] % NX].push_back(i);
         size_t cs2 = 0;
         for (int x = 0; x < NX; ++x) cs2 = std::max(cs2, perx[x].size());
-        o.list.assign(cs2 * NX, 0xffffffffu);
+        o.wtile.assign(cs2 * NX * NS, 0xffffffffu);
+        o.wmap.assign(cs2 * NX, 0);
         for (int x = 0; x < NX; ++x)
-            for (size_t sl = 0; sl < perx[x].size(); ++sl) o.list[sl * NX + x] = perx[x][sl];
+            for (size_t sl = 0; sl < perx[x].size(); ++sl) place(sl * NX + x, wgs[perx[x][sl]]);
         return true;
     }
-    const size_t cs = (list.size() + NX - 1) / NX;
-    o.list.assign(cs * NX, 0xffffffffu);
+    const size_t cs = (wgs.size() + NX - 1) / NX;
+    o.wtile.assign(cs * NX * NS, 0xffffffffu);
+    o.wmap.assign(cs * NX, 0);
     for (size_t x = 0; x < (size_t)NX; ++x)
         for (size_t sl = 0; sl < cs; ++sl)
-            if (x * cs + sl < list.size()) o.list[sl * NX + x] = list[x * cs + sl];
+            if (x * cs + sl < wgs.size()) place(sl * NX + x, wgs[x * cs + sl]);
     return true;
 }
 
@@ -1902,7 +1991,7 @@ void describe(Plan& plan) {
                 n += std::snprintf(buf + n, sizeof buf - n, "%sd%d:%d", first ? "" : ",", d, 1 << ob.lg[d]);
                 first = false;
             }
-        n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.list.size());
+        n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.wmap.size());
     } else if (plan.family == FAM_FLAT && plan.flatb.on) {
         n += std::snprintf(buf + n, sizeof buf - n, " batched block=%d(d0..d%d) blocks_per_wg=%d", plan.flatb.P, plan.flatb.g - 1, plan.flatb.K);
     } else if (plan.family == FAM_FLAT && plan.flat2.on) {

@@ -131,35 +131,50 @@ def _orbit_cover(roots, nt, perms):
 
 
 def test_orbit_list_covers_every_tile_once_and_groups_line_partners():
-    """FAM_ORBIT: one workgroup per orbit of tiles under the group the permuted views generate; the list
-    holds exactly one root per orbit (every tile is computed exactly once) and the orbits of one
-    super-cell (2 tiles along every tiled dim) run on one XCD."""
+    """FAM_ORBIT: a workgroup holds one tile per LDS slot -- the orbit of a tile under the group the permuted views generate;
+    orbits on a diagonal (fewer distinct tiles than slots) share workgroups (round 6), so every tile of the box is loaded and
+    stored exactly once, the 32^4 launch is 1024 workgroups (4 per CU) and the orbits of one super-cell (2 tiles along every
+    tiled dim) run on one XCD."""
     x = S.StridedView(np.zeros((32, 32, 32, 32), order="F"))
     y = x.similar()
     ps = [x.permutedims(q) for q in [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]]
     plan = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps))
-    assert "family=orbit" in plan.describe() and "orbits=1044" in plan.describe()  # necklaces of length 4 over 8 symbols
-    lst = np.array(plan.tile_order(), dtype=np.int64)
-    assert len(lst) % 8 == 0
-    roots = lst[lst != 0xFFFFFFFF]
-    assert len(roots) == 1044
-    rot = [[(d + k) % 4 for d in range(4)] for k in range(4)]
-    assert sorted(_orbit_cover(roots, (8, 8, 8, 8), rot)) == list(range(8 ** 4))
-    # super-cell (2^4 tiles) of a root; its orbits occupy consecutive slots of ONE XCD (runs may be cut 7 times)
-    where = {int(r): i for i, r in enumerate(lst) if r != 0xFFFFFFFF}
+    # necklaces of length 4 over 8 symbols: 1008 of period 4, 28 of period 2, 8 of period 1 -> 1008 + 14 + 2 workgroups
+    assert "family=orbit" in plan.describe() and "orbits=1044" in plan.describe() and "grid=1024" in plan.describe()
+    lst = np.array(plan.tile_order(), dtype=np.int64).reshape(-1, 4)
+    assert len(lst) == 1024 and len(lst) % 8 == 0
+    assert sorted(lst.ravel().tolist()) == list(range(8 ** 4))  # every tile once, no idle workgroup
+    # a workgroup's tiles are closed under the rotation of the four coordinates (whole orbits only)
+    def rot(t):
+        return (t % 8) * 512 + t // 8   # (t0,t1,t2,t3) -> (t1,t2,t3,t0)
+    for row in lst[::37]:
+        assert {rot(int(t)) for t in row} == {int(t) for t in row}
+    # super-cell (2^4 tiles) of a tile; a cell's tiles occupy workgroups of ONE XCD (the eight runs may cut 7 cells, and a
+    # shared workgroup holds diagonal tiles of a few neighbouring cells)
     cells = {}
-    for r, i in where.items():
-        t = [(r // 8 ** d) % 8 for d in range(4)]
-        cells.setdefault(tuple(c // 2 for c in t), []).append(i)
-    split = sum(1 for v in cells.values() if len({i % 8 for i in v}) > 1)
-    assert split <= 7
-    # symmetrise: pairs of transposed 32x32 tiles, diagonal tiles alone
+    for b, row in enumerate(lst):
+        for t in row:
+            tc = [(int(t) // 8 ** d) % 8 for d in range(4)]
+            cells.setdefault(tuple(c // 2 for c in tc), set()).add(b % 8)
+    split = sum(1 for v in cells.values() if len(v) > 1)
+    assert split <= 7 + 16, split
+    S.set_option("orbit_pack", 0)
+    try:
+        plan = S.make_plan(lambda a, b, c, e: a + b + c + e, None, None, x.size, (y, *ps))
+        lst = np.array(plan.tile_order(), dtype=np.int64).reshape(-1, 4)
+        assert "grid=1048" in plan.describe() and len(lst) == 1048
+        live = lst[lst[:, 0] != 0xFFFFFFFF]
+        assert len(live) == 1044 and sorted(set(live.ravel().tolist())) == list(range(8 ** 4))
+    finally:
+        S.set_option("orbit_pack", 1)
+    # symmetrise: pairs of transposed 32x32 tiles; the 125 diagonal tiles share 63 workgroups
     plan = _sym_plan(4000)
     assert "family=orbit" in plan.describe() and "group=2" in plan.describe() and "tile=d0:32,d1:32" in plan.describe()
-    lst = np.array(plan.tile_order(), dtype=np.int64)
-    roots = lst[lst != 0xFFFFFFFF]
-    assert len(roots) == 125 * 126 // 2
-    assert sorted(_orbit_cover(roots, (125, 125), [[0, 1], [1, 0]])) == list(range(125 * 125))
+    lst = np.array(plan.tile_order(), dtype=np.int64).reshape(-1, 2)
+    live = lst[lst[:, 0] != 0xFFFFFFFF]
+    assert len(live) == 125 * 124 // 2 + 63
+    tiles = live.ravel().tolist()
+    assert sorted(set(tiles)) == list(range(125 * 125)) and len(tiles) == 125 * 125 + 1  # the odd diagonal tile repeats in its workgroup
     # sizes without a power-of-two divisor fall back to the classic kernel with ragged tiles
     assert "family=tiled" in _sym_plan(1000).describe()
 
