@@ -5,8 +5,9 @@ Metric (BASELINE.json): GB/s effective HBM (and % of roofline) for @strided perm
 broadcast on 32^4 Float64.  One STEP = the two README workloads on one pair of 32^4 f64 arrays,
 inputs resident in HBM:
     (C2)  permutedims!(B, A, (4,3,2,1))                         README.md:98
-    (C3)  C .= A_p1 .+ A_p2 .+ A_p3 .+ A_p4  (4 permuted views) README.md:104   (into a third array C: the two
-          operations of a step then share nothing but the read-only input A)
+    (C3)  C .= A_p1 .+ A_p2 .+ A_p3 .+ A_p4  (4 permuted views) README.md:104   (into a THIRD array C, chosen so that the two
+          operations of a step share nothing but the read-only input A and may overlap; the README's session writes both
+          into B -- that write-after-write chain is timed as well and reported on the same line: "step_same_destination")
 Algorithmic bytes per step = 2 launches x (8 MiB read + 8 MiB written) = 33,554,432 B
 (every distinct array counted once).
 
@@ -191,6 +192,29 @@ def cpu_baseline(S, budget_s=24.0, full=True):
     }
 
 
+# The shape of the JSON line, in one place: --dry (the CPU test of the N-rank path) prints it, the real run asserts it.
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_replay", "higher_is_better", "scaling", "degraded",
+             "vs_baseline", "dtype", "data", "rehearsal", "config", "frac_of_hbm_peak", "step_same_destination", "roofline")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "frac_rocprof_avg", "us_rocprof_avg", "rocprof_file",
+                 "per_kernel", "library_replay_alone", "note", "hbm_cold")
+EXTRA_KEYS = {"c1": ("c1_symmetrise_4000_f64",), "hbm128": ("permutedims_128^4_f64", "broadcast4_128^4_f64"),
+              "cold": ("permutedims_32^4_f64_cold", "permutedims_32^4_f64_cold_seq_2_queues", "broadcast4_32^4_f64_cold", "broadcast4_32^4_f64_cold_seq_2_queues"),
+              "c5": ("c5_expr_8192_f32",), "c4": ("c4_mapreduce_abs2_4096x4096x64_f32",),
+              "sharded": ("c1_symmetrise_sharded", "broadcast4_sharded", "broadcast4_128^4_sharded")}
+
+
+def extra_keys(world, extras):
+    """Names the secondary workloads put under "extra" for a job of `world` ranks (the sharded map/permute legs run for N > 1, or on request)."""
+    only = None if extras == "all" else set(extras.split(","))
+    names = []
+    for leg, keys in EXTRA_KEYS.items():
+        if leg == "sharded" and world == 1 and (only is None or "sharded" not in only):
+            continue
+        if only is None or leg in only:
+            names.extend(keys)
+    return names
+
+
 def relaunch_as_ranks(ngpus):
     """`python bench.py --gpus N` started without a launcher: become the launcher (one rank per GPU)."""
     import socket
@@ -222,7 +246,11 @@ def dry_run(args, world, rank):
     assert seen == world and ranksum == world * (world - 1) // 2
     if rank == 0:
         print(json.dumps({"dry": True, "n_gpus": seen, "requested_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-                          "backend": "gloo" if world > 1 else "none"}))
+                          "backend": "gloo" if world > 1 else "none",
+                          # the shape the real line will have for this job (asserted by the real run before it prints)
+                          "line_keys": list(LINE_KEYS) + ([] if args.no_cpu or seen > 1 else ["cpu_baseline"]) + ([] if args.no_extra else ["extra"]),
+                          "roofline_keys": list(ROOFLINE_KEYS), "extra_keys": [] if args.no_extra else extra_keys(seen, args.extras),
+                          "timed_region": "barrier | per-rank clock: K steps + local device sync | barrier, then MAX over ranks"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -237,7 +265,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--extra-timeout", type=int, default=300, help="N > 1: seconds the secondary workloads may take before the headline is printed without them")
-    ap.add_argument("--extras", default="all", help="comma-separated subset of the secondary workloads: c1,hbm128,cold,c5,c4 (default: all)")
+    ap.add_argument("--extras", default="all", help="comma-separated subset of the secondary workloads: c1,hbm128,cold,c5,c4,sharded (default: all; `sharded` = the map/permute configs cut into --gpus slabs, runs by default only for N > 1)")
     ap.add_argument("--step-mode", choices=("seq", "seq1", "inorder", "chains"), default="seq",
                     help="seq: the library's own replay of the recorded step (smr_seq: AQL packets on its HSA queues, one queue per "
                          "dependency component -- the step's two operations are independent, both only read A -- results of in-order "
@@ -351,6 +379,10 @@ def main():
         seq.wait()
     tB.zero_(); tC.zero_()  # the timed region must (re)produce both outputs
     stream_handle = seq_stream.handle if use_seq else cur()
+    # Timed region (N ranks): collective barrier + device sync, THEN every rank's own clock around its K steps and its own device
+    # sync; the MAX over ranks is taken afterwards.  (Until round 5 the closing dist.barrier() sat inside the region: a collective
+    # of ~2 ms around 0.1 ms of work -- profiles/r05_bench_gpus8_rehearsal.json.  The ranks share no data on this path, so the
+    # slowest rank's local time IS the job's time.)
     barrier()
     t0 = time.perf_counter()
     if use_seq:
@@ -362,8 +394,9 @@ def main():
     else:
         for _ in range(K):
             step()
-    barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    barrier()
     check_outputs("after the timed region")  # bit-exact, AFTER timing: the overlapped replay has in-order results
     if use_seq:
         seq_info = seq.info()
@@ -462,7 +495,67 @@ def main():
         return round(best / nl * 1e6, 3)
     replay = {name: {"one_queue_us": replay_alone_us(pl, {"queues": 1, "slices": 1}), "cut_in_two_us": replay_alone_us(pl, {"queues": 2, "slices": 2})}
               for name, pl in (("permutedims", plan2), ("broadcast4", plan3))} if use_seq else {}
+    # The README's own form of the step (/root/reference README.md:92-105): BOTH statements write B.  A write-after-write chain: the
+    # second launch may not overtake the first, nothing overlaps.  Timed the same two ways as the headline's form.
+    plan3b = S.make_plan(lambda a, b, c, d: a + b + c + d, None, None, A.size, (B,) + tuple(A.permutedims(p) for p in perms))
+
+    def step_b():
+        s_ = cur()
+        plan2.execute(s_)
+        plan3b.execute(s_)
+    step_b()
+    torch.cuda.synchronize()
+    assert torch.equal(tB, ref3), "same-destination step: B must hold the 4-way sum"
+    gb = graph_of(torch, step_b, reps)
+    gb.replay()
+    torch.cuda.synchronize()
+    same_graph_us = min(event_time_ms(torch, gb.replay, 2) for _ in range(7)) / reps * 1e3
+    del gb
+    same_seq_us = None
+    if use_seq:
+        qb = S.Sequence().add(plan2).add(plan3b)
+        stb = S.Stream()
+        qb.run(5, stb.handle); qb.wait()
+        same_seq_us = 1e30
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            qb.run(2 * reps, stb.handle); qb.wait()
+            same_seq_us = min(same_seq_us, (time.perf_counter() - t) / (2 * reps) * 1e6)
+        torch.cuda.synchronize()
+        assert torch.equal(tB, ref3), "same-destination replay: B must hold the 4-way sum"
+        del qb
+        stb.close()
+    same_us = min(x for x in (same_graph_us, same_seq_us) if x is not None)
+    step_same_destination = {
+        "us_per_step": round(same_us, 3), "GB/s": round((bytes2 + bytes3) / same_us / 1e3, 1),
+        "frac_of_hbm_peak": round((bytes2 + bytes3) / same_us / 1e3 / HBM_PEAK_GBS, 4),
+        "hipgraph_in_order_us": round(same_graph_us, 3), "library_replay_us": round(same_seq_us, 3) if same_seq_us is not None else None,
+        "note": "permutedims!(B, A, (4,3,2,1)) then B .= sum of 4 permuted views of A: both statements into B as in the reference's README "
+                "session (README.md:92-105) -- a write-after-write chain, no overlap possible; `value` above is the step with the sum "
+                "written to a third array C"}
+    plan2.execute(cur())   # B holds the permutation again (the headline arrays are verified once more below)
+    torch.cuda.synchronize()
+    del plan3b
+
     dom = ("broadcast4", ms3, bytes3, plan3) if ms3 >= ms2 else ("permutedims", ms2, bytes2, plan2)
+    # rocprofv3's average duration of the dominant kernel, from the tracked summary of the same command (profiles/): the profiler
+    # serialises sub-5-us dispatches, so this is the pessimistic witness next to the HIP-event minimum above
+    rocprof = {"file": None, "us_avg": None, "frac": None}
+    try:
+        import glob
+        import re
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_trace_stats.txt")))
+        if cands:
+            want_k = ("k_orbit_map", "FAdd4") if dom[0] == "broadcast4" else ("k_tiled_map", "FIdent")
+            for line in open(cands[-1]):
+                f = line.split()
+                if len(f) >= 5 and f[0].isdigit() and all(w in line for w in want_k):
+                    rocprof = {"file": "profiles/" + os.path.basename(cands[-1]), "us_avg": round(float(f[1]) / 1e3, 3),
+                               "frac": round(dom[2] / float(f[1]) / HBM_PEAK_GBS, 4)}
+                    break
+    except Exception:  # noqa: BLE001 -- a missing / unreadable summary must not cost the line
+        pass
     achieved = dom[2] / (dom[1] * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -475,6 +568,8 @@ def main():
         "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "us_per_launch": round(dom[1] * 1e3, 3),
+        # the same kernel by rocprofv3's AVERAGE over the tracked kernel trace of this command (profiler-serialised dispatches)
+        "frac_rocprof_avg": rocprof["frac"], "us_rocprof_avg": rocprof["us_avg"], "rocprof_file": rocprof["file"],
         "per_kernel": {
             "permutedims": {"us": round(ms2 * 1e3, 3), "us_median": round(med2 * 1e3, 3), "GB/s": round(bytes2 / (ms2 * 1e-3) / 1e9, 1),
                             "frac": round(bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "plan": plan2.describe()},
@@ -517,6 +612,11 @@ def main():
             extra = ({"error": "the secondary workloads did not finish within %d s on rank %d (a collective that did not complete?); the headline "
                                "above was measured before them" % (args.extra_timeout, rank)} if stuck else box.get("extra", {}))
 
+    # HBM-cold fractions of the two headline kernels (rotating through more arrays than the Infinity Cache holds): the bandwidth truth
+    # next to the cache-resident figures, promoted out of `extra`
+    if isinstance(extra, dict):
+        cold = {k: {"us": v.get("us"), "frac": v.get("frac_of_8TBs")} for k, v in extra.items() if k.endswith("_cold") or "_cold_" in k}
+        roofline["hbm_cold"] = cold or None
     if rank == 0:
         out = {
             "metric": "GB/s effective HBM for @strided permutedims!+broadcast, 32^4 fp64",
@@ -525,11 +625,14 @@ def main():
             # the library's own clock around the same K steps: first doorbell -> completion signals observed (no Python, no torch sync)
             "ms_per_step_replay": round(replay_us / K * 1e-3, 6) if (use_seq and replay_us is not None) else None,
             "higher_is_better": True, "scaling": "weak",
+            # a secondary workload failed or a rank's watchdog fired: the headline was measured before them, but this is not a clean run
+            "degraded": bool(stuck or (isinstance(extra, dict) and "error" in extra)),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rehearsal": ("$SMR_RCCL_LIB is set: %d ranks over gloo sharing %d GPU(s), the collective is a stand-in -- a rehearsal of the N-rank "
                           "path, not a measurement" % (world, ndev)) if rehearsal else None,
-            "config": {"workload": "configs[1]+configs[2]: permutedims!(B,A,(4,3,2,1)) then C .= sum of 4 permuted views of A (a third array C), "
-                                   "32x32x32x32 Float64, one set of arrays (A, B, C) per GPU",
+            "config": {"workload": "configs[1]+configs[2]: permutedims!(B,A,(4,3,2,1)) then C .= sum of 4 permuted views of A, 32x32x32x32 Float64, one "
+                                   "set of arrays (A, B, C) per GPU.  C is a THIRD array chosen so that the two statements share only the read-only A "
+                                   "and overlap; the README writes both into B -- that form is `step_same_destination` on this line",
                        "algorithmic_bytes_per_step": bytes2 + bytes3,
                        "launch": ("smr_seq replay (AQL packets on the library's HSA queues), " +
                                   ("one queue per dependency component, the heavier chain (the 4-way sum) cut into two block ranges: the step's two "
@@ -541,12 +644,19 @@ def main():
                        "step_us_long_graph": step_us,
                        "parallelism": "replicas x%d (independent arrays per rank)" % world},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            "step_same_destination": step_same_destination,
             "roofline": roofline,
         }
         if not args.no_cpu and world == 1:  # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(S)
         if extra:
             out["extra"] = extra
+        # the line has the shape --dry announces (tests/test_distributed_cpu.py checks that one on the CPU)
+        assert set(LINE_KEYS) <= set(out), sorted(set(LINE_KEYS) - set(out))
+        assert set(ROOFLINE_KEYS) <= set(roofline), sorted(set(ROOFLINE_KEYS) - set(roofline))
+        if extra and "error" not in extra:
+            missing = [k for k in extra_keys(world, args.extras) if k not in extra]
+            assert not missing, "secondary workloads missing from the line: %s" % missing
         print(json.dumps(out), flush=True)
     if world > 1:
         if not stuck:   # (a peer may be stuck: the closing barrier gets a watchdog of its own)
@@ -556,8 +666,9 @@ def main():
             th.join(timeout=60)
             stuck = th.is_alive()
         if stuck:
+            # a rescued run is not a clean one: the line carries extra.error, and the exit status says so too
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)
 
 
 def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_view, cur, only=None, red_dev=None):
@@ -717,7 +828,52 @@ def secondary(S, torch, np, dev, world, rank, event_time_ms, graph_of, colmajor_
             "collective": "RCCL ncclAllReduce(1 x f32) issued by libstrided_hip (smr_comm.cpp)" if sharded else "none",
             "rccl_ranks": rccl_ranks if sharded else 1, "per_step_rank0": per_step}
 
-    for name, sec in (("c1", sec_c1), ("hbm128", sec_hbm128), ("cold", sec_cold), ("c5", sec_c5), ("c4", sec_c4)):
+    def sec_sharded():
+        # north_star: "large arrays are block-partitioned across the GPUs ...; map/permute stays embarrassingly parallel per shard".
+        # The 4000^2 symmetrisation and the 4-way permuted sum (32^4, 128^4), cut along the destination's slowest dim into `world`
+        # slabs (smr_shard_ex: the reference's own offset arithmetic, /root/reference/src/mapreduce.jl:203-222): every rank holds a
+        # full replica of the source (a permuted source slab is a strided sub-box of the whole array) and writes only its slab of the
+        # destination -- no collective on the data path.  Time = the slowest rank's; bytes = the whole problem's.
+        import torch.distributed as dist
+        from strided_jl_amd import distributed as D
+
+        def run(name, f, dims, mk_arrays, reps):
+            arrays = mk_arrays()
+            sdims, sarrays, need, _ = D.shard(f, None, None, dims, arrays, world, rank)
+            assert not need, "a map needs no all-reduce"
+            p = S.make_plan(f, None, None, sdims, sarrays)
+            ms = timed(p, reps)
+            full = S.make_plan(f, None, None, dims, arrays)
+            b = full.algorithmic_bytes
+            if world > 1:
+                tt = torch.tensor([ms], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ms = float(tt.item())
+            res[name] = {"us": round(ms * 1e3, 2), "shards": world, "GB/s_total": round(b / (ms * 1e-3) / 1e9, 1),
+                         "GB/s_per_gpu": round(b / world / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs_per_gpu": round(b / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "shard_dims": list(sdims), "collective": "none (replicated source, disjoint destination slabs)", "plan_of_this_rank": p.describe()}
+
+        m = 4000
+        g = torch.Generator(device=dev)
+        g.manual_seed(4321)   # the same replica on every rank
+
+        def sym_arrays():
+            tA = torch.randn(m * m, dtype=torch.float64, device=dev, generator=g)
+            tB = torch.empty_like(tA)
+            A, B = colmajor_view(S, tA, (m, m)), colmajor_view(S, tB, (m, m))
+            return (B, A, A.adjoint())
+        run("c1_symmetrise_sharded", lambda x, y: (x + y) / 2, (m, m), sym_arrays, 50)
+        for n, reps in ((32, 200), (128, 5)):
+            def sum_arrays(n=n):
+                tA = torch.randn(n ** 4, dtype=torch.float64, device=dev, generator=g)
+                tB = torch.empty_like(tA)
+                A, B = colmajor_view(S, tA, (n,) * 4), colmajor_view(S, tB, (n,) * 4)
+                return (B,) + tuple(A.permutedims(q) for q in perms)
+            run("broadcast4_sharded" if n == 32 else "broadcast4_128^4_sharded", lambda a, b, c, d: a + b + c + d, (n,) * 4, sum_arrays, reps)
+
+    for name, sec in (("c1", sec_c1), ("hbm128", sec_hbm128), ("cold", sec_cold), ("c5", sec_c5), ("c4", sec_c4), ("sharded", sec_sharded)):
+        if name == "sharded" and world == 1 and (only is None or "sharded" not in only):
+            continue   # one GPU: the sharded legs are the unsharded ones (ask for them with --extras sharded)
         if want(name):
             sec()
     return res

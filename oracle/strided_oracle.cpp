@@ -22,6 +22,7 @@
 #include "../include/strided_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -39,7 +40,8 @@ constexpr int MAXN = SMR_MAXN;
 constexpr int MAXM = SMR_MAXM;
 
 thread_local std::string g_err;
-bool g_literal_409 = false;  // see Kernel::blockloop
+std::atomic<long> g_guard_hits{0};  // how often _computeblocks' termination guard fired (tests/golden: the case the reference is suspected to spin on)
+std::atomic<bool> g_literal_409{false};  // see Kernel::blockloop (process-wide: the oracle's worker threads read it; atomic, so toggling it is no data race)
 int fail(int code, const std::string& m) {
     g_err = m;
     return code;
@@ -467,12 +469,18 @@ void computeblocks(const i64* dims, const i64* costs, const i64 (*bytestrides)[M
     // forever (:491-498).  Blocking only affects the traversal order, so the oracle stops there.
     while (totalmemoryregion(b, N, bytestrides, M, first) >= 2 * BLOCKMEMORYSIZE) {  // :491-494
         int i = pick();
-        if (b[i] <= 1) break;
+        if (b[i] <= 1) {
+            g_guard_hits.fetch_add(1);
+            break;
+        }
         b[i] = (b[i] + 1) >> 1;
     }
     while (totalmemoryregion(b, N, bytestrides, M, first) > BLOCKMEMORYSIZE) {  // :495-498
         int i = pick();
-        if (b[i] <= 1) break;
+        if (b[i] <= 1) {
+            g_guard_hits.fetch_add(1);
+            break;
+        }
         b[i] = b[i] - 1;
     }
     for (int i = first; i < N; ++i) blocks[i] = b[i];
@@ -806,7 +814,7 @@ struct Kernel {
             // with init = true again).  No reference test has a reversed destination with an initop; `!= 0` is what the line is for
             // (a reduced dim, stride 0, must not be initialised twice).  The oracle follows the intent; the literal reading is kept
             // selectable (oracle_set_literal_409) so that tests/test_oracle_numpy.py can show the difference against NumPy.
-            init = init && (g_literal_409 ? L.strides[0][level] > 0 : L.strides[0][level] != 0);
+            init = init && (g_literal_409.load(std::memory_order_relaxed) ? L.strides[0][level] > 0 : L.strides[0][level] != 0);
             for (int k = 0; k < M; ++k) I[k] += d[level] * L.strides[k][level];
         }
         for (int k = 0; k < M; ++k) I[k] -= dims[level] * L.strides[k][level];
@@ -1133,7 +1141,13 @@ extern "C" {
 const char* oracle_last_error(void) { return g_err.c_str(); }
 
 // 1: read src/mapreduce.jl:409 literally (see Kernel::blockloop); default 0
-void oracle_set_literal_409(int on) { g_literal_409 = on != 0; }
+void oracle_set_literal_409(int on) { g_literal_409.store(on != 0); }
+// number of times the termination guard of _computeblocks fired since the last reset (reset != 0 clears it after reading)
+long oracle_guard_hits(int reset) {
+    const long n = g_guard_hits.load();
+    if (reset) g_guard_hits.store(0);
+    return n;
+}
 
 // Full reference path on host memory: _mapreduce_fuse! -> ... -> _mapreduce_kernel!
 int oracle_mapreduce(const smr_problem* p, int nthreads) {

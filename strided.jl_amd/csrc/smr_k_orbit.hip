@@ -67,6 +67,7 @@ struct OrbitArgs {
 struct OrbitHead {
     const uint32_t* list;  // = OrbitArgs::list
     const char* src;       // = OrbitArgs::src
+    char* dst;             // = OrbitArgs::dst (left in the struct, its scalar load was sunk between the LDS reads and the adds)
     uint32_t eshp, elenp;  // esh[j] / elen[j] in byte j
     uint32_t estride[OMAXT];
     uint32_t ntlog;
@@ -75,6 +76,7 @@ static inline __host__ __device__ OrbitHead orbit_head(const OrbitArgs& a) {
     OrbitHead h;
     h.list = a.list;
     h.src = a.src;
+    h.dst = a.dst;
     h.eshp = h.elenp = 0;
     for (int j = 0; j < OMAXT; ++j) {
         h.eshp |= (uint32_t)a.esh[j] << (8 * j);
@@ -220,6 +222,28 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
     uint32_t conj0 = a.conj0 ? 0x80000000u : 0u, nts_flag = (uint32_t)a.nts;
     asm volatile("" : "+s"(conj0), "+s"(nts_flag));
     auto swz = [&](uint32_t i) { return i ^ (((i >> swz_s1) ^ (i >> swz_s2)) & swz_mask); };
+    // one-shot form: the swizzled LDS indices of the lane's writes and of its transposing reads are formed HERE, while the global
+    // loads fly (left alone the compiler computes them behind the barrier: ~45 vector instructions on the critical path of a
+    // launch whose waves live 2 us).  The persistent form recomputes them per orbit (its registers hold two orbits).
+    constexpr int NPRE = PIPE ? 1 : NREP;
+    uint32_t wi[NPRE][V], ri[NK][NPRE][V];
+    if constexpr (!PIPE) {
+#pragma unroll
+        for (int r = 0; r < NREP; ++r)
+#pragma unroll
+            for (int hh = 0; hh < V; ++hh) {
+                wi[r][hh] = swz(((((uint32_t)r << h.ntlog) | tid) * V) + hh);
+                asm volatile("" : "+v"(wi[r][hh]));
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    ri[k][r][hh] = 0;
+                    if (!(OWN0 && k == 0)) {
+                        ri[k][r][hh] = swz(lr[k][r] | ((uint32_t)hh << hbit[k]));
+                        asm volatile("" : "+v"(ri[k][r][hh]));
+                    }
+                }
+            }
+    }
 
     uint32_t wg = blockIdx.x, tidp = tid;
     for (;;) {
@@ -252,7 +276,10 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
             for (int r = 0; r < NREP; ++r) {
                 const uint32_t e = (((uint32_t)r << h.ntlog) | tidp) * V;
 #pragma unroll
-                for (int h = 0; h < V; ++h) L[swz(e + h)] = x[g][r].v[h];
+                for (int hh = 0; hh < V; ++hh) {
+                    if constexpr (PIPE) L[swz(e + hh)] = x[g][r].v[hh];
+                    else L[wi[r][hh]] = x[g][r].v[hh];
+                }
             }
         }
         __syncthreads();
@@ -286,8 +313,12 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
                                 val[gi][h][k] = x[g][r].v[h];
                             } else {
                                 // sub-element h moves along tiled dim 0 of the natural order
-                                const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
-                                val[gi][h][k] = lds[sbase[g][k] + swz(idx)];
+                                if constexpr (PIPE) {
+                                    const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
+                                    val[gi][h][k] = lds[sbase[g][k] + swz(idx)];
+                                } else {
+                                    val[gi][h][k] = lds[sbase[g][k] + ri[k][r][h]];
+                                }
                             }
                         }
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads together: one LDS latency per batch, not one per output
@@ -327,20 +358,20 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int r = 0; r < NREP; ++r) store_vec_wt<VT>(a.dst + org[g] + goff[r], x[g][r]);
+                        for (int r = 0; r < NREP; ++r) store_vec_wt<VT>(h.dst + org[g] + goff[r], x[g][r]);
                 }
             } else if (nts) {
                 nt_block_guard();
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < NREP; ++r) store_vec_ct<true, VT>(a.dst + org[g] + goff[r], x[g][r]);
+                    for (int r = 0; r < NREP; ++r) store_vec_ct<true, VT>(h.dst + org[g] + goff[r], x[g][r]);
                 nt_block_guard();
             } else {
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < NREP; ++r) store_vec_ct<false, VT>(a.dst + org[g] + goff[r], x[g][r]);
+                    for (int r = 0; r < NREP; ++r) store_vec_ct<false, VT>(h.dst + org[g] + goff[r], x[g][r]);
             }
         }
         if constexpr (!PIPE) {
@@ -366,7 +397,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
 
 #ifndef SMR_JIT
 template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE>
-__global__ void __launch_bounds__(1024) k_orbit_map(const uint32_t* list, const char* src, uint32_t eshp, uint32_t elenp, uint32_t es0, uint32_t es1,
+__global__ void __launch_bounds__(1024) k_orbit_map(const uint32_t* list, const char* src, char* dst, uint32_t eshp, uint32_t elenp, uint32_t es0, uint32_t es1,
                                                     uint32_t es2, uint32_t es3, uint32_t ntlog, const OrbitArgs a, F f SMR_STAMP_PARAM) {
     // the leading scalars = OrbitHead, preloaded into SGPRs: the origin row's load is the first thing the wave does, and the global
     // loads leave as soon as it is back (tools/orbit32_probe.hip: 4.76 -> 4.45 us at 32^4)
@@ -374,6 +405,7 @@ __global__ void __launch_bounds__(1024) k_orbit_map(const uint32_t* list, const 
     OrbitHead h;
     h.list = list;
     h.src = src;
+    h.dst = dst;
     h.eshp = eshp;
     h.elenp = elenp;
     h.estride[0] = es0;
@@ -604,7 +636,7 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         if (!PIPE) mark_sliceable(2, 0u, (unsigned)(2 * NG * sizeof(uint32_t)));  // one table row per workgroup; the pointer is parameter 0
         if (a.nts == 2) mark_self_released();
         const OrbitHead h = orbit_head(a);
-        SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, h.list, h.src, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3], h.ntlog, a,
+        SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, h.list, h.src, h.dst, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3], h.ntlog, a,
                    f SMR_STAMP_ARG(grid, block));
         return check_launch("k_orbit_map");
     }

@@ -1699,13 +1699,17 @@ int seq_submit(smr_seq* q, Direct& d, int reps) {
         }
     }
     d.t_submit = now_s();
+    // the limit is on the ABSENCE OF PROGRESS, as in wait_signal: a replay longer than the rings (16384 packets per queue) that runs
+    // for minutes keeps draining and keeps being fed -- the clock restarts with every packet written (it used to run
+    // from t_submit, so a legitimate replay of more than SMR_DIRECT_TIMEOUT_MS was declared dead while its rings were full)
+    double t_progress = d.t_submit;
     unsigned idle_rounds = 0;
     while (open_queues > 0) {
         // every ring full (the replay is longer than the rings: the packet processor has to catch up): spin briefly, then yield; bounded
         if (++idle_rounds > 64) {
             if (idle_rounds < 1024) __builtin_ia32_pause();
             else sched_yield();
-            if ((idle_rounds & 1023) == 0 && (d.failed.load() || now_s() - d.t_submit > direct_timeout_s())) {
+            if ((idle_rounds & 1023) == 0 && (d.failed.load() || now_s() - t_progress > direct_timeout_s())) {
                 direct_fail(d, "the hardware queues stopped consuming packets during a replay");
                 return SMR_EHIP;
             }
@@ -1739,6 +1743,7 @@ int seq_submit(smr_seq* q, Direct& d, int reps) {
             }
             h.signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)(base + nthis - 1));
             idle_rounds = 0;
+            t_progress = now_s();
             written[k] += nthis;
             if (written[k] >= totalp[k]) --open_queues;
         }

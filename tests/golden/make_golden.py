@@ -79,6 +79,48 @@ G["mm_alpha_beta"] = np.array([al, be])
 G["mm_out"] = F(be * M3 + al * (M1.conj().T @ M2.T))          # C = beta*C + alpha*A'*transpose(B)
 G["mm_out_conjdest"] = F(np.conj(be) * M3 + np.conj(al * (M1 @ M2)))  # mul!(conj(C), A, B, alpha, beta)
 
+# ---- round 6: every documented deviation of DESIGN.md section 4 and every BASELINE config at reduced size, so that
+# ONE run of make_golden.jl settles them all.  A second generator: the arrays above keep their values.
+rng6 = np.random.default_rng(20261001)
+# (a) src/mapreduce.jl:409 -- reversed destination + initop, more than 32 KiB so that the kept dim is cut into blocks (the oracle
+#     reads the line as `!= 0`).  out[k] = initop(out[k]) + sum_i sin(X[i, k]), both seen through reversed ranges.
+I9, K9 = 32, 159
+X9 = F(rng6.random((I9, K9)) + 1j * rng6.random((I9, K9)) + 0.25)
+O9 = rng6.random(K9) + 1j * rng6.random(K9) + 0.25
+beta9 = 0.5 + 0.25j
+G["rev409_in"], G["rev409_dest"], G["rev409_beta"] = X9, O9, np.array([beta9])
+red9 = np.sin(X9).sum(axis=0)
+for key, init in (("none", O9), ("zero", 0 * O9), ("scale", beta9 * O9), ("const", beta9 + 0 * O9), ("conj", np.conj(O9))):
+    G[f"rev409_{key}"] = init + red9        # element k of the PARENT vector (the reversed views only change the traversal)
+# (b) the `_computeblocks` termination case: negative strides make every block weight <= 0 and the reference's halving loops
+#     (src/mapreduce.jl:491-498) are suspected never to end; the oracle breaks out.  dims (66, 2, 19), a 3-input map.
+gd = (66, 2, 19)
+gviews = [((38, 19, -1), 18), ((38, 2, 4), 0), ((-1, 66, 0), 65), ((0, 1, 0), 0)]   # (strides, offset): destination first
+gsizes = [2508, 2545, 132, 2]
+gpar = [np.zeros(gsizes[0])] + [rng6.standard_normal(n) for n in gsizes[1:]]
+
+
+def gview(par, st, off):
+    return np.lib.stride_tricks.as_strided(par[off:], shape=gd, strides=tuple(8 * x for x in st), writeable=False)
+
+
+gsum = (gview(gpar[1], *gviews[1]) + gview(gpar[2], *gviews[2])) + gview(gpar[3], *gviews[3])
+gout = gpar[0].copy()
+i0, i1, i2 = np.meshgrid(*(np.arange(d) for d in gd), indexing="ij")
+gout[gviews[0][1] + 38 * i0 + 19 * i1 - i2] = gsum
+G["guard_in1"], G["guard_in2"], G["guard_in3"], G["guard_out"] = gpar[1], gpar[2], gpar[3], gout
+# (c) stride-0 broadcast operands (src/broadcast.jl:41-65): a column, a row and a scalar
+G["bc0_col"], G["bc0_row"] = F(rng6.standard_normal((5, 1))), F(rng6.standard_normal((1, 6)))
+G["bc0_out"] = F(G["bc0_col"] + G["bc0_row"] * 2.5)
+# (d) an offset, stepped sub-view seen through a permutation (test/othertests.jl:134-189)
+SV = F(rng6.standard_normal((12, 10)))
+G["sv_in"] = SV
+G["sv_out"] = F(2 * SV[2:9, 1:10:2].T)       # Julia: 2 .* permutedims(sview(A, 3:9, 2:2:10), (2, 1))
+# (e) BASELINE configs at reduced size: configs[0] = sym_*, [1] = perm_4321, [2] = sum4_*, [4] = expr_* above; configs[3] here
+C4 = F((rng6.random((16, 16, 8)) * 2 - 1).astype(np.float32))
+G["c4_in"] = C4
+G["c4_abs2"] = np.array([(C4.astype(np.float64) ** 2).sum()])   # float64 truth; the engine accumulates in Float32 (rtol 1e-5)
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "strided_golden.npz")
 np.savez_compressed(out, **G)
 print("wrote", out, os.path.getsize(out), "bytes,", len(G), "arrays")

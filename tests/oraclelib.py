@@ -61,6 +61,14 @@ def set_literal_409(on):
     load().oracle_set_literal_409(1 if on else 0)
 
 
+def guard_hits(reset=True):
+    """How often the termination guard of the restated _computeblocks fired (oracle/strided_oracle.cpp: with negative strides the
+    reference's halving loops are suspected never to end; the oracle breaks out)."""
+    lib = load()
+    lib.oracle_guard_hits.restype = C.c_long
+    return int(lib.oracle_guard_hits(1 if reset else 0))
+
+
 def plan(problem):
     info = oracle_plan_info()
     rc = load().oracle_plan(C.byref(problem), C.byref(info))

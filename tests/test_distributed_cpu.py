@@ -159,6 +159,20 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert len(lines) == 1, r.stdout            # rank 0 prints ONE line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["requested_gpus"] == 2 and out["steps"] == 7 and out["warmup"] == 1
+    # the shape of the line a 2-rank job prints (round 6: the real run asserts the same constants before it prints): the map / permute
+    # configs cut into N slabs are there with the reduce path, the README's same-destination step and both roofline witnesses are
+    # top-level, and the collective barrier is outside the timed region
+    assert {"c1_symmetrise_sharded", "broadcast4_sharded", "c4_mapreduce_abs2_4096x4096x64_f32"} <= set(out["extra_keys"])
+    assert {"step_same_destination", "roofline", "ms_per_step_replay", "degraded"} <= set(out["line_keys"]) and "cpu_baseline" not in out["line_keys"]
+    assert {"frac", "frac_rocprof_avg", "hbm_cold", "per_kernel"} <= set(out["roofline_keys"])
+    assert out["timed_region"].startswith("barrier | per-rank clock")
+    sys.path.insert(0, root)
+    import bench
+    assert "c1_symmetrise_sharded" not in bench.extra_keys(1, "all") and "broadcast4_sharded" in bench.extra_keys(1, "c4,sharded")
+    assert bench.extra_keys(8, "c4") == ["c4_mapreduce_abs2_4096x4096x64_f32"]
+    src = open(os.path.join(root, "bench.py")).read()
+    timed = src[src.index("    t0 = time.perf_counter()\n    if use_seq:"):src.index("    dt = time.perf_counter() - t0")]
+    assert "barrier()" not in timed and "torch.cuda.synchronize()" in timed   # no collective between the two clock readings
     # a launcher that started a different number of ranks than --gpus says is an error, not a silent 1-GPU run
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,

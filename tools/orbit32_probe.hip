@@ -182,8 +182,11 @@ __device__ __forceinline__ void sum_body(const SumRef a) {
     constexpr int NT = ONEWAVE ? 64 : 128;
     constexpr int NREP = ONEWAVE ? 2 : 1;
     __shared__ __attribute__((aligned(16))) double lds[4 * 256];
-    u64 t[8];
-    if (PH) t[0] = __builtin_readcyclecounter();
+    u64 t[8], rt0 = 0;
+    if (PH) {
+        rt0 = wall_clock64();
+        t[0] = __builtin_readcyclecounter();
+    }
     uint32_t org[4];
     bool live = true;
     if (VAR == 0 || VAR == 3) {
@@ -306,10 +309,13 @@ __device__ __forceinline__ void sum_body(const SumRef a) {
         t[6] = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         t[7] = __builtin_readcyclecounter();
+        const u64 rt1 = wall_clock64();
         if ((tid & 63) == 0 && a.stamps) {
-            u64* o = a.stamps + ((size_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 8;
+            u64* o = a.stamps + ((size_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 10;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = t[i];
+            o[8] = rt0;
+            o[9] = rt1;
         }
     } else if (ST == 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -765,43 +771,48 @@ int main(int argc, char** argv) {
 
     // ---- part 3: phase stamps -----------------------------------------------------------------------------------------------
     std::printf("\n== part 3: per-wave phases (s_memtime cycles; mean / p50 / p95 over the waves of one launch, 20 launches back to back) ==\n");
-    auto phases = [&](auto kern, const char* name, int lanes, const Swz& sw) {
+    auto phases = [&](auto kern, const char* name, int lanes, const Swz& sw, bool scalar_params = false, unsigned grid_override = 0, const uint32_t* rows_override = nullptr) {
         const int waves = lanes / 64;
         const size_t nw = nwg * waves;
         const int L = 20;
         u64* dst;
-        CK(hipMalloc(&dst, nw * 8 * sizeof(u64) * L));
-        CK(hipMemset(dst, 0, nw * 8 * sizeof(u64) * L));
+        CK(hipMalloc(&dst, nw * 10 * sizeof(u64) * L));
+        CK(hipMemset(dst, 0, nw * 10 * sizeof(u64) * L));
         SumArgs a = sa;
         a.swz_s1 = sw.s1;
         a.swz_s2 = sw.s2;
         a.swz_mask = sw.mask;
+        (void)scalar_params;
+        (void)grid_override;
+        (void)rows_override;
         for (int rep = 0; rep < 2; ++rep)
             for (int l = 0; l < L; ++l) {
-                a.stamps = dst + (size_t)l * nw * 8;
+                a.stamps = dst + (size_t)l * nw * 10;
                 hipLaunchKernelGGL(kern, dim3(nwg), dim3(lanes), 0, c.st, a);
             }
         CK(hipStreamSynchronize(c.st));
-        std::vector<u64> h(nw * 8 * L);
+        std::vector<u64> h(nw * 10 * L);
         CK(hipMemcpy(h.data(), dst, h.size() * 8, hipMemcpyDeviceToHost));
         static const char* ph[7] = {"origins known", "loads issued", "data arrived", "parked+barrier", "LDS reads+adds", "stores issued", "stores acked"};
         std::printf("%s\n", name);
         std::vector<double> acc[8];
-        double span_sum = 0;
+        double span_sum = 0, life_cyc = 0, life_tick = 0;
         for (int l = 5; l < L; ++l) {
-            u64 first = ~0ull, last = 0;
+            u64 first = ~0ull, last = 0;  // device wall clock (100 MHz, one clock for the chip; s_memtime is per XCD)
             for (size_t w = 0; w < nw; ++w) {
-                const u64* o = &h[((size_t)l * nw + w) * 8];
+                const u64* o = &h[((size_t)l * nw + w) * 10];
                 if (o[0] == 0) continue;
-                first = std::min(first, o[0]);
-                last = std::max(last, o[7]);
+                first = std::min(first, o[8]);
+                last = std::max(last, o[9]);
             }
             span_sum += (double)(last - first);
             for (size_t w = 0; w < nw; ++w) {
-                const u64* o = &h[((size_t)l * nw + w) * 8];
+                const u64* o = &h[((size_t)l * nw + w) * 10];
                 if (o[0] == 0) continue;
                 for (int i = 1; i < 8; ++i) acc[i - 1].push_back((double)(o[i] - o[i - 1]));
                 acc[7].push_back((double)(o[7] - o[0]));
+                life_cyc += (double)(o[7] - o[0]);
+                life_tick += (double)(o[9] - o[8]);
             }
         }
         auto stat = [&](std::vector<double>& v, const char* nm) {
@@ -813,13 +824,72 @@ int main(int argc, char** argv) {
         };
         for (int i = 0; i < 7; ++i) stat(acc[i], ph[i]);
         stat(acc[7], "wave lifetime");
-        std::printf("   launch span (first wave start -> last wave's stores acked): mean %.0f cycles\n", span_sum / (L - 5));
+        std::printf("   s_memtime runs at %.0f MHz (lifetimes against the 100-MHz wall clock); launch span, first wave start -> last wave's stores acked: mean %.2f us\n",
+                    life_cyc / (life_tick * 0.01), span_sum / (L - 5) * 0.01);
+        CK(hipFree(dst));
+    };
+    auto phasesx = [&](auto kern, const char* name, int lanes, const Swz& sw, bool scalar_params = false, unsigned grid_override = 0, const uint32_t* rows_override = nullptr) {
+        const int waves = lanes / 64;
+        const size_t nw = nwg * waves;
+        const int L = 20;
+        u64* dst;
+        CK(hipMalloc(&dst, nw * 10 * sizeof(u64) * L));
+        CK(hipMemset(dst, 0, nw * 10 * sizeof(u64) * L));
+        SumArgs a = sa;
+        a.swz_s1 = sw.s1;
+        a.swz_s2 = sw.s2;
+        a.swz_mask = sw.mask;
+        (void)scalar_params;
+        (void)grid_override;
+        (void)rows_override;
+        for (int rep = 0; rep < 2; ++rep)
+            for (int l = 0; l < L; ++l) {
+                a.stamps = dst + (size_t)l * nw * 10;
+                hipLaunchKernelGGL(kern, dim3(nwg), dim3(lanes), 0, c.st, (const double*)dA, dC, (const uint32_t*)d_rows, a.stamps, sw.s1, sw.s2, sw.mask, 0u, reps_h);
+            }
+        CK(hipStreamSynchronize(c.st));
+        std::vector<u64> h(nw * 10 * L);
+        CK(hipMemcpy(h.data(), dst, h.size() * 8, hipMemcpyDeviceToHost));
+        static const char* ph[7] = {"origins known", "loads issued", "data arrived", "parked+barrier", "LDS reads+adds", "stores issued", "stores acked"};
+        std::printf("%s\n", name);
+        std::vector<double> acc[8];
+        double span_sum = 0, life_cyc = 0, life_tick = 0;
+        for (int l = 5; l < L; ++l) {
+            u64 first = ~0ull, last = 0;  // device wall clock (100 MHz, one clock for the chip; s_memtime is per XCD)
+            for (size_t w = 0; w < nw; ++w) {
+                const u64* o = &h[((size_t)l * nw + w) * 10];
+                if (o[0] == 0) continue;
+                first = std::min(first, o[8]);
+                last = std::max(last, o[9]);
+            }
+            span_sum += (double)(last - first);
+            for (size_t w = 0; w < nw; ++w) {
+                const u64* o = &h[((size_t)l * nw + w) * 10];
+                if (o[0] == 0) continue;
+                for (int i = 1; i < 8; ++i) acc[i - 1].push_back((double)(o[i] - o[i - 1]));
+                acc[7].push_back((double)(o[7] - o[0]));
+                life_cyc += (double)(o[7] - o[0]);
+                life_tick += (double)(o[9] - o[8]);
+            }
+        }
+        auto stat = [&](std::vector<double>& v, const char* nm) {
+            std::sort(v.begin(), v.end());
+            double m = 0;
+            for (double x : v) m += x;
+            m /= v.size();
+            std::printf("   %-16s mean %7.0f  p50 %7.0f  p95 %7.0f  max %7.0f cycles\n", nm, m, v[v.size() / 2], v[v.size() * 95 / 100], v.back());
+        };
+        for (int i = 0; i < 7; ++i) stat(acc[i], ph[i]);
+        stat(acc[7], "wave lifetime");
+        std::printf("   s_memtime runs at %.0f MHz (lifetimes against the 100-MHz wall clock); launch span, first wave start -> last wave's stores acked: mean %.2f us\n",
+                    life_cyc / (life_tick * 0.01), span_sum / (L - 5) * 0.01);
         CK(hipFree(dst));
     };
     phases(k_sum<0, 0, 0, true>, "table in memory, 128 lanes (product form)", 128, sw128);
     phases(k_sum<1, 0, 0, true>, "table in kernel arguments, 128 lanes", 128, sw128);
     phases(k_sum<4, 0, 0, true>, "table in kernel arguments, one wave per orbit", 64, sw64);
     phases(k_sum<1, 0, 2, true>, "table in kernel arguments, 128 lanes, sc1 stores", 128, sw128);
+    phasesx(k_sumx<0, 0, 0, true>, "scalar parameters (preloaded into SGPRs when built with -amdgpu-kernarg-preload-count), table in memory, 128 lanes", 128, sw128);
     {
         // clock rate of s_memtime against the 100-MHz wall clock
         int dev = 0, khz = 0;
