@@ -82,16 +82,40 @@ G["mm_out_conjdest"] = F(np.conj(be) * M3 + np.conj(al * (M1 @ M2)))  # mul!(con
 # ---- round 6: every documented deviation of DESIGN.md section 4 and every BASELINE config at reduced size, so that
 # ONE run of make_golden.jl settles them all.  A second generator: the arrays above keep their values.
 rng6 = np.random.default_rng(20261001)
-# (a) src/mapreduce.jl:409 -- reversed destination + initop, more than 32 KiB so that the kept dim is cut into blocks (the oracle
-#     reads the line as `!= 0`).  out[k] = initop(out[k]) + sum_i sin(X[i, k]), both seen through reversed ranges.
-I9, K9 = 32, 159
-X9 = F(rng6.random((I9, K9)) + 1j * rng6.random((I9, K9)) + 0.25)
-O9 = rng6.random(K9) + 1j * rng6.random(K9) + 0.25
-beta9 = 0.5 + 0.25j
-G["rev409_in"], G["rev409_dest"], G["rev409_beta"] = X9, O9, np.array([beta9])
-red9 = np.sin(X9).sum(axis=0)
+# (a) src/mapreduce.jl:409 -- reversed destination + initop on a working set above 32 KiB, laid out so that the planner CUTS the kept
+#     (reversed) dim into blocks (the layout family tools/fuzz_more.py found in round 5; tests/test_golden.py asserts the cut).  The
+#     oracle and the device read the line as `!= 0`; read literally (`> 0`) every block after the first keeps its stale
+#     destination values.  out[k] = initop(out[k]) + sum_{i,j} (x + y + z)[i, j, k], destination seen through a reversed range.
+#     Inputs are NOT stored: element i of a parent is mod(i * a, m) / m + 0.25 (exact in any IEEE language) -- REV409 below.
+REV409 = dict(dims=(100, 8, 159), dest=((0, 0, -1), 158, 159, (104729, 1013)),
+              ins=[((160, 0, 1), 0, 15999, (7919, 1009)), ((-1280, -160, 1), 127840, 127999, (7920, 1013)), ((3, 2400, 300), 0, 64498, (7921, 1019))])
+
+
+def formula(n, a, m):
+    i = np.arange(n, dtype=np.int64)
+    return ((i * a) % m).astype(np.float64) / m + 0.25
+
+
+def strided(par, dims, st, off):
+    idx = off + sum(s_ * ix for s_, ix in zip(st, np.meshgrid(*(np.arange(d) for d in dims), indexing="ij")))
+    return par[idx]
+
+
+_d = REV409["dims"]
+for _st, _off, _n, _am in REV409["ins"]:
+    _lo = _off + sum(min(0, (d - 1) * s_) for d, s_ in zip(_d, _st))
+    _hi = _off + sum(max(0, (d - 1) * s_) for d, s_ in zip(_d, _st))
+    assert _lo >= 0 and _hi < _n, (_st, _lo, _hi, _n)
+tot9 = None
+for _st, _off, _n, _am in REV409["ins"]:
+    _v = strided(formula(_n, *_am), _d, _st, _off)
+    tot9 = _v if tot9 is None else tot9 + _v
+red9 = tot9.sum(axis=(0, 1))[::-1]            # element p of the PARENT vector holds out[k] for k = 158 - p
+O9 = formula(159, *REV409["dest"][3])
+beta9 = 0.375
+G["rev409_beta"] = np.array([beta9])
 for key, init in (("none", O9), ("zero", 0 * O9), ("scale", beta9 * O9), ("const", beta9 + 0 * O9), ("conj", np.conj(O9))):
-    G[f"rev409_{key}"] = init + red9        # element k of the PARENT vector (the reversed views only change the traversal)
+    G[f"rev409_{key}"] = init + red9
 # (b) the `_computeblocks` termination case: negative strides make every block weight <= 0 and the reference's halving loops
 #     (src/mapreduce.jl:491-498) are suspected never to end; the oracle breaks out.  dims (66, 2, 19), a 3-input map.
 gd = (66, 2, 19)
