@@ -193,7 +193,7 @@ def cpu_baseline(S, budget_s=24.0, full=True):
 
 
 # The shape of the JSON line, in one place: --dry (the CPU test of the N-rank path) prints it, the real run asserts it.
-LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_replay", "higher_is_better", "scaling", "degraded",
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_replay", "closing_device_sync_us", "higher_is_better", "scaling", "degraded",
              "vs_baseline", "dtype", "data", "rehearsal", "config", "frac_of_hbm_peak", "step_same_destination", "roofline")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "frac_rocprof_avg", "us_rocprof_avg", "rocprof_file",
                  "per_kernel", "library_replay_alone", "note", "hbm_cold")
@@ -387,14 +387,19 @@ def main():
     t0 = time.perf_counter()
     if use_seq:
         seq.run(K, stream_handle)
-        seq.wait()
+        seq.wait()       # host-side wait on the replay's completion signals: the K steps are done when it returns (the replay does not
+        #                  run on a HIP stream, a device sync cannot see it) ...
+        t_done = time.perf_counter()
+        torch.cuda.synchronize()   # ... and the device sync the contract brackets the region with finds nothing left to wait for
+        t_sync = time.perf_counter() - t_done
     elif use_graph:
         for _ in range(nrep):
             gstep.replay()
+        torch.cuda.synchronize()
     else:
         for _ in range(K):
             step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
     check_outputs("after the timed region")  # bit-exact, AFTER timing: the overlapped replay has in-order results
@@ -624,6 +629,8 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 6),
             # the library's own clock around the same K steps: first doorbell -> completion signals observed (no Python, no torch sync)
             "ms_per_step_replay": round(replay_us / K * 1e-3, 6) if (use_seq and replay_us is not None) else None,
+            # of ms_per_step * steps: the closing torch.cuda.synchronize() alone, after smr_seq_wait had already seen the completion signals
+            "closing_device_sync_us": round(t_sync * 1e6, 1) if use_seq else None,
             "higher_is_better": True, "scaling": "weak",
             # a secondary workload failed or a rank's watchdog fired: the headline was measured before them, but this is not a clean run
             "degraded": bool(stuck or (isinstance(extra, dict) and "error" in extra)),
