@@ -216,7 +216,7 @@ static int execute(const Plan& plan, void* const* bases, hipStream_t s) {
             std::vector<RecLaunch> rec;
             // self-released launches (write-through stores, no release fence on the packet: smr_seq.cpp) while what this stream has
             // been writing lately fits the caches
-            set_recorder(&rec, options().eager_self_release != 0 && !wr.empty() && eager_recent_writes_fit(wr[0].lo, wr[0].hi));
+            set_recorder(&rec, options().eager_self_release != 0 && !wr.empty() && eager_recent_writes_fit(wr[0].lo, wr[0].hi), true);
             int rc = execute_family(plan, bases, s);
             set_recorder(nullptr);
             if (rc) return rc;
@@ -920,12 +920,14 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_part_wgs") o.reduce_part_wgs = value;
     else if (n == "reduce_single") o.reduce_single = value;
     else if (n == "reduce_col_narrow") o.reduce_col_narrow = value;
+    else if (n == "reduce_col_exact") o.reduce_col_exact = value;
     else if (n == "reduce_row_floor") o.reduce_row_floor = value;
     else if (n == "reduce_row_dense") o.reduce_row_dense = value;
     else if (n == "flat2") o.flat2 = value;
     else if (n == "flat2_bytes") o.flat2_bytes = value;
     else if (n == "flat2_lead_bytes") o.flat2_lead_bytes = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
+    else if (n == "tiled_uavec") o.tiled_uavec = value;
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "seq_self_release") o.seq_self_release = value;
@@ -1004,6 +1006,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "reduce_part_wgs") return o.reduce_part_wgs;
     if (n == "reduce_single") return o.reduce_single;
     if (n == "reduce_col_narrow") return o.reduce_col_narrow;
+    if (n == "reduce_col_exact") return o.reduce_col_exact;
     if (n == "reduce_row_floor") return o.reduce_row_floor;
     if (n == "reduce_row_dense") return o.reduce_row_dense;
     if (n == "flat2") return o.flat2;
@@ -1019,6 +1022,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "jit_failures") return jit_stats().failures;
     if (n == "jit_compile_ms") return (int64_t)jit_stats().compile_ms;
     if (n == "tiled_vec") return o.tiled_vec;
+    if (n == "tiled_uavec") return o.tiled_uavec;
     if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
     if (n == "seq_self_release") return o.seq_self_release;

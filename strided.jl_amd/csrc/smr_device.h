@@ -132,6 +132,10 @@ SMR_DEV void nt_block_guard() { asm volatile("; nt stores" ::: "memory"); }
 
 // vector load, plain or non-temporal by a compile-time switch (a run-time switch belongs around the whole loop:
 // a diamond per load is folded like the stores, and guarding each one keeps the loads of a batch apart)
+template <int I>
+struct IntC {
+    static constexpr int value = I;
+};
 template <bool B>
 struct BoolC {
     static constexpr bool value = B;

@@ -229,6 +229,8 @@ struct Plan {
     int part_g0log = 0, part_g1log = 0;  // ROW: lanes of a group along the inner reduced dim / the outer index
                                          // COL: rows of a workgroup along the inner reduced dim / the outer index
     int part_txlog = 0;                  // COL: lanes along kept dim 0
+    int part_col_tx = 0, part_col_v = 1; // COL, exact lane map (round 6): lanes along kept dim 0 (0 = the power of two above), valid for this vector width
+    int part_col_y0 = 1, part_col_y1 = 1; //   rows of a workgroup along the inner reduced dim x along the outer index (TY = 256 / tx = y0 * y1)
     int part_xsplit = 1, part_qsplit = 1;  // split of the inner / outer reduced range over workgroups
     // TILED: per-lane index tables in device memory, one per kernel variant (built on first use)
     mutable void* lanetab[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -271,6 +273,7 @@ struct Options {
     i64 flat2_bytes = 384;      // ... target bytes of a run
     i64 flat2_lead_bytes = 512; // ... both sides' unit-stride dims must be shorter than this
     i64 reduce_row_dense = 1;   // ROW form: lanes along the outputs when the inner reduced dim is at most 64 bytes and kept dim 0 is dense behind it
+    i64 reduce_col_exact = 1;   // COL form: lanes along kept dim 0 sized to the row (25 lanes x 10 rows for 100 Float32) when that fills more of the workgroup than a power of two
     i64 reduce_col_narrow = 1;  // COL form: narrow the row segments when that yields reduce_part_wgs workgroups without a split
     i64 reduce_part_kind = -1;  // -1 = planner's choice; 0/1/2 force general / ROW / COL when applicable
     i64 reduce_single = 4;     // split reductions of at most this many chunks fold their partials inside the SAME launch (the workgroup
@@ -290,6 +293,7 @@ struct Options {
     i64 flatb = 1;              // FLAT family: batched form for contiguous small blocks (batched transposes of small matrices)
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
+    i64 tiled_uavec = 1;     // ... and at element alignment (odd extents / row strides), partial vectors of ragged tiles element by element
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)
     i64 stream_ua = 1;          // STREAM: element-aligned 16-byte vectors + a partial vector per row for rows that are not whole aligned vectors
     i64 tiled_xpose = 1;        // HBM-sized transposing copies (one staged input, 128 x 32 tiles, whole tiles, 8- / 16-byte elements) run the lean kernel k_xpose_big
@@ -410,7 +414,7 @@ bool eager_recent_writes_fit(uintptr_t dest_lo, uintptr_t dest_hi);  // smr_seq.
 void mark_sliceable(int kind, unsigned off, unsigned row);  // applies to the NEXT recorded launch of the calling thread (no-op when nothing records)
 void mark_self_released();                                  // likewise: RecLaunch::self_released
 void take_slice_mark(RecLaunch& r);
-void set_recorder(std::vector<RecLaunch>* r, bool for_sequence = false);
+void set_recorder(std::vector<RecLaunch>* r, bool allow_self_release = false, bool eager = false);
 // Is the launch being recorded for a SEQUENCE (smr_seq) whose packets may drop their release fence, and is this execution in the
 // regime where the fence matters (what it writes fits the caches: option "self_release_max_bytes", default 64 MiB)?  Launchers that
 // can issue write-through stores then do (store policy 2) and call mark_self_released().

@@ -16,6 +16,9 @@
 //   REDUCE_PART: some dims kept; TR lanes cooperate per destination element
 #include "smr_dispatch.h"
 
+#ifndef SMR_RED_U
+#define SMR_RED_U 4  // loads in flight per lane in the ROW / COL forms
+#endif
 #ifndef SMR_CT
 #error "compile with -DSMR_CT=0..3 or 7"
 #endif
@@ -35,6 +38,8 @@ struct RedArgs {
     int32_t ngroups;  // REDUCE_PART: workgroups along the output index
     i64 chunk;        // reduced elements per chunk (multiple of tr)
     // vectorised forms (ROW / COL): reduced space = inner dim NK (extent L0) x outer index q in [0, Q)
+    int32_t ctx, cty, cy0, cy1;  // COL: lanes along kept dim 0 x rows (cty = cy0 rows along the inner reduced dim x cy1 along the outer index); ctx * cty <= 256
+    uint32_t ctx_m, cy0_m;       //      ceil(2^16 / ctx), ceil(2^16 / cy0): n / d = (n * m) >> 16 for n < 256, d <= 256
     int32_t g0log, g1log, txlog, xsplit, qsplit, ntl;  // ntl: non-temporal loads in REDUCE_ALL (Options::nt_load)
     i64 L0, Q, xchunk, qchunk;
     i64 nkb0;         // COL: workgroups along kept dim 0
@@ -482,7 +487,7 @@ SMR_DEV void reduce_row_impl(const RedArgs& a, F f) {
     const int redop = (OPC >= 0) ? OPC : a.redop;  // compile-time for the sum: no op switch inside the loops
     __shared__ T xbuf[256];
     typedef RVec<T, V> VT;
-    constexpr int U = 4;  // vectors in flight per lane
+    constexpr int U = SMR_RED_U;  // vectors in flight per lane
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
     const int glog = a.g0log + a.g1log;
     const int G0 = 1 << a.g0log, G1 = 1 << a.g1log;
@@ -587,7 +592,12 @@ SMR_DEV void reduce_row_impl(const RedArgs& a, F f) {
             }
         }
     }
-    T v = red_apply<T>(redop, red_apply<T>(redop, acc[0], acc[1]), red_apply<T>(redop, acc[2], acc[3]));
+    // pairwise over the U accumulators (U = 4: (a0 + a1) + (a2 + a3))
+#pragma unroll
+    for (int w = 1; w < U; w <<= 1)
+#pragma unroll
+        for (int u = 0; u + w < U; u += 2 * w) acc[u] = red_apply<T>(redop, acc[u], acc[u + w]);
+    T v = acc[0];
     const int G = 1 << glog;
     v = wave_reduce(v, redop, G < 64 ? G : 64);
     if (G > 64) {  // lanes of one output span several waves
@@ -624,18 +634,19 @@ SMR_DEV void reduce_col_impl(const RedArgs& a, F f) {
     const int redop = (OPC >= 0) ? OPC : a.redop;  // compile-time for the sum: no op switch inside the loops
     __shared__ T xbuf[256 * V];
     typedef RVec<T, V> VT;
-    constexpr int U = 4;
+    constexpr int U = SMR_RED_U;
     const int nin = (F::NIN >= 0) ? F::NIN : a.M - 1;
-    const int TX = 1 << a.txlog;
-    const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> a.txlog;
-    const int Y0 = 1 << a.g0log, Y1 = 1 << a.g1log;
-    const int t0 = ty & (Y0 - 1), t1 = ty >> a.g0log;
+    // lanes along kept dim 0 x rows: powers of two, or sized to the row (25 x 10 for rows of 100 Float32; lanes past TX * TY idle)
+    const int TX = a.ctx, TY = a.cty;
+    const int ty = (int)((threadIdx.x * a.ctx_m) >> 16), tx = (int)threadIdx.x - ty * TX;
+    const int Y0 = a.cy0, Y1 = a.cy1;
+    const int t1 = (int)(((uint32_t)ty * a.cy0_m) >> 16), t0 = ty - t1 * Y0;
     const i64 sp = (i64)blockIdx.x / a.ngroups;
     const i64 kb = (i64)blockIdx.x - sp * a.ngroups;
     const i64 krest = kb / a.nkb0;
     const i64 c0 = kb - krest * a.nkb0;
     const i64 i0 = (c0 * TX + tx) * V;
-    const bool live = i0 < a.dims[0];
+    const bool live = ty < TY && i0 < a.dims[0];
     const i64 sx = sp % a.xsplit, sq = sp / a.xsplit;
     const i64 jbeg = sx * a.xchunk, jend = (jbeg + a.xchunk < a.L0) ? jbeg + a.xchunk : a.L0;
     const i64 qbeg = sq * a.qchunk, qend = (qbeg + a.qchunk < a.Q) ? qbeg + a.qchunk : a.Q;
@@ -729,18 +740,22 @@ SMR_DEV void reduce_col_impl(const RedArgs& a, F f) {
         }
     }
     // fold the TY rows: LDS tree, halving the number of active rows
-    const int TY = 256 >> a.txlog;
+    // (any row count: a step folds rows [h, cur) onto [0, cur - h); fixed order, whatever the count)
 #pragma unroll
     for (int e = 0; e < V; ++e) xbuf[threadIdx.x * V + e] = acc[e];
     __syncthreads();
-    for (int h = TY >> 1; h > 0; h >>= 1) {
-        if (ty < h) {
+    int hh = 1;
+    while (hh < TY) hh <<= 1;
+    int cur = TY;
+    for (int h = hh >> 1; h > 0; h >>= 1) {
+        if (ty < h && ty + h < cur) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 acc[e] = red_apply<T>(redop, acc[e], xbuf[(threadIdx.x + h * TX) * V + e]);
                 xbuf[threadIdx.x * V + e] = acc[e];
             }
         }
+        cur = cur < h ? cur : h;
         __syncthreads();
     }
     if (live && ty == 0) {
@@ -780,12 +795,30 @@ __global__ void __launch_bounds__(256) k_reduce_part_final(RedArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = neutral<T>(a.redop);
     if (live) {
+        // eight partials per lane and round, loaded before the first is used (guarded loads one by one were eight serial round trips to
+        // the memory side -- the partials were written by the launch before -- and made this pass as long as the main one: sum over
+        // dims (2,3,4) of (100,90,80,7) Float32, 512 chunks: 5.4 us of the 10.8); partial i still goes to accumulator (i / lpo) % 4
         const T* p = (const T*)a.partials + o * a.nsplit;
-        for (int i = l; i < a.nsplit; i += 4 * lpo) {
+        const int last = a.nsplit - 1;
+        auto walk = [&](auto nb) {
+            constexpr int NB = decltype(nb)::value;
+            for (int i = l; i < a.nsplit; i += NB * lpo) {
+                T x[NB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (i + j * lpo < a.nsplit) acc[j] = red_apply<T>(a.redop, acc[j], p[i + j * lpo]);
-        }
+                for (int j = 0; j < NB; ++j) {
+                    const int ii = i + j * lpo;
+                    x[j] = p[ii < last ? ii : last];
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int ii = i + j * lpo;
+                    const T t = red_apply<T>(a.redop, acc[j & 3], x[j]);
+                    if (ii < a.nsplit) acc[j & 3] = t;
+                }
+            }
+        };
+        if (a.nsplit > 4 * lpo) walk(IntC<8>{});
+        else walk(IntC<4>{});  // a handful of partials: one batch of four
     }
     T v = red_apply<T>(a.redop, red_apply<T>(a.redop, acc[0], acc[1]), red_apply<T>(a.redop, acc[2], acc[3]));
     v = wave_reduce(v, a.redop, lpo);
@@ -1011,7 +1044,19 @@ static int go_part(const Plan& plan, void* const* bases, hipStream_t s, F f) {
             if (!done) rc = launch_part<T, F, MIXED, 1, 1>(c, a, blocks, s, f);
         } else {
             a.xchunk = (a.L0 + a.xsplit - 1) / a.xsplit;
-            const i64 per = ((i64)V) << a.txlog;
+            a.ctx = 1 << a.txlog;
+            a.cty = 256 >> a.txlog;
+            a.cy0 = 1 << a.g0log;
+            a.cy1 = 1 << a.g1log;
+            if (plan.part_col_tx > 0 && plan.part_col_v == V) {  // exact lane map (smr_plan.cpp), planned for this vector width
+                a.ctx = plan.part_col_tx;
+                a.cty = 256 / a.ctx;
+                a.cy0 = plan.part_col_y0;
+                a.cy1 = plan.part_col_y1;
+            }
+            a.ctx_m = (65536u + (uint32_t)a.ctx - 1u) / (uint32_t)a.ctx;
+            a.cy0_m = (65536u + (uint32_t)a.cy0 - 1u) / (uint32_t)a.cy0;
+            const i64 per = (i64)V * a.ctx;
             a.nkb0 = (c.dims[0] + per - 1) / per;
             const i64 groups = a.nkb0 * (c.nout / c.dims[0]);
             a.ngroups = (int32_t)groups;

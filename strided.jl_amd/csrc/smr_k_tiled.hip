@@ -105,7 +105,7 @@ struct TiledArgs {
     i64 gdims[MAXN];
     int32_t glog[MAXN];
     uint32_t ord16[NORD16 / 2];  // ordmode 1: the same as 16-bit entries inside the kernel arguments
-    // BITS form (narrow offsets, no ragged tile): the per-lane table rows are COMPUTED -- bit slices of the lane
+    // BITS form (narrow offsets, variants 0 / 1 / 2): the per-lane table rows are COMPUTED -- bit slices of the lane
     // id -- instead of loaded, which takes one dependent memory round trip out of the prologue
     int32_t bpos[MAXM][MAXT], blen[MAXM][MAXT], blsh[MAXM][MAXT];  // slice p of operand k's enumeration (blen 0 = unused)
     uint32_t bstr[MAXM][MAXT];                                     // its byte stride
@@ -116,6 +116,13 @@ SMR_DEV uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s) { return (__umulhi(
 
 template <class T, int V>
 struct alignas(sizeof(T) * V) TVec {
+    T v[V];
+};
+
+// global-memory view of a lane's vector: element alignment only (round 6: odd extents and odd row strides keep 16-byte accesses;
+// the hardware takes dwordx2 / dwordx4 at any dword address, as in smr_k_stream.hip)
+template <class T, int V>
+struct alignas(sizeof(T)) TUVec {
     T v[V];
 };
 
@@ -147,14 +154,17 @@ SMR_DEV void store_at(char* p, int dtype, int conj, T v) {
 // (more than 4 grid dims, or origins beyond 4 GiB / negative steps).  The plain variant (0) carries
 // none of it: code size and every extra scalar wait are part of the latency of a ~3.5 us launch
 // (measured: permutedims! 3.48 -> 3.43 us, 4-way sum 6.84 -> 6.59 us for dropping bit 2 alone).
-// Instantiated: 0 (plain), 2 (orbit order), 7 (everything).
+// Bit 3: partial vectors (the extent of a vector axis is not a multiple of V: the last vector of a row is moved element by element).
+// Instantiated: 0 (plain), 1 (plain + bounds checks on edge tiles), 9 (1 + partial vectors), 2 (orbit order), 7 (everything).
 template <class T, class F, bool MIXED, bool WIDE, int V, int MODE, int THRLOG>
 SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     constexpr bool EDGE = (MODE & 1) != 0;
     constexpr bool ORD = (MODE & 2) != 0;
     constexpr bool GENORG = (MODE & 4) != 0;
+    constexpr bool PV = (MODE & 8) != 0 || MODE == 7;  // partial vectors at the end of a row (extent of a vector axis not a multiple of V)
     typedef typename off_t_of<WIDE>::type O;
     typedef TVec<T, V> VT;
+    typedef TUVec<T, V> GT;  // the same vector in global memory
     constexpr int VLOG = (V == 1) ? 0 : (V == 2 ? 1 : 2);
     constexpr int NREP = EPL / V;
     constexpr int NT = 1 << THRLOG;
@@ -167,7 +177,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
 
     // ---- per-lane rows (byte offset + swizzled LDS index of the lane's first element, per operand) ----
     // tables in device memory (first memory instructions of the kernel) or, BITS, bit slices of the lane id
-    constexpr bool BITS = SMR_TILED_BITS && !WIDE && !EDGE;
+    constexpr bool BITS = SMR_TILED_BITS && !WIDE && (MODE & 4) == 0;
     LaneRow<WIDE> row[NINMAX + 1];
 #pragma unroll
     for (int k = 0; k <= NINMAX; ++k) {
@@ -247,12 +257,18 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
                 }
         }
     }
-    auto in_bounds = [&](int k, uint32_t e) {
-        bool ok = true;
+    // how many of the V elements e .. e + V - 1 of operand k's enumeration lie inside the array (they differ in the coordinate at
+    // bit 0): V or 0, or -- extent of the vector axis not a multiple of V -- something between in the last vector of a row
+    auto in_count = [&](int k, uint32_t e) -> uint32_t {
+        uint32_t cnt = V;
 #pragma unroll
         for (int j = 0; j < MAXT; ++j)
-            if (j < a.nt) ok = ok && (((e >> a.esh[k][j]) & ((1u << a.tlog[j]) - 1u)) < lim[j]);
-        return ok;
+            if (j < a.nt) {
+                const uint32_t cj = (e >> a.esh[k][j]) & ((1u << a.tlog[j]) - 1u);
+                if (cj >= lim[j]) cnt = 0;
+                else if (PV && V > 1 && a.esh[k][j] == 0) cnt = min(cnt, lim[j] - cj);
+            }
+        return cnt;
     };
     auto tile_base = [&](int k) -> char* {
         if (!GENORG || a.base32) {  // every tile origin of every operand is below 4 GiB, steps non-negative
@@ -270,11 +286,11 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
 
     // ---- phase A: issue EVERY global load of the tile before anything waits ------------------------
     VT x[NINMAX > 0 ? NINMAX : 1][NREP];
-    bool okd[NREP];  // destination-order validity of repeat r (edge tiles)
+    uint32_t cntd[NREP];  // valid elements of repeat r in destination order (edge tiles: 0 .. V)
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
-        okd[r] = true;
-        if (edge) okd[r] = in_bounds(0, (((uint32_t)r << THRLOG) | tid) << VLOG);
+        cntd[r] = V;
+        if (edge) cntd[r] = in_count(0, (((uint32_t)r << THRLOG) | tid) << VLOG);
     }
 #pragma unroll
     for (int i = 0; i < NINMAX; ++i) {
@@ -288,9 +304,14 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
             const bool stg = a.staged[i + 1] >= 0;
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
-                bool ok = okd[r];
-                if (edge && stg) ok = in_bounds(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG);
-                if (ok) {
+                uint32_t cn = cntd[r];
+                if (edge && stg) cn = in_count(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG);
+                if (PV && V > 1 && cn > 0 && cn < (uint32_t)V) {  // the partial vector at the end of a row: element by element
+                    const char* p = bp + (O)(row[i + 1].g + d.Gr[r]);
+#pragma unroll
+                    for (int h = 0; h < V; ++h)
+                        if ((uint32_t)h < cn) x[i][r].v[h] = load_at<T, MIXED>(p + h * sizeof(T), d.dtype, d.conj);
+                } else if (cn) {
                     const char* p = bp + (O)(row[i + 1].g + d.Gr[r]);
                     if constexpr (V == 1) {
                         x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
@@ -307,7 +328,11 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
 #elif SMR_TILED_NTL  // experiment (A/B build): non-temporal loads
                         x[i][r] = load_vec_ct<true, VT>(p);
 #else
-                        x[i][r] = *reinterpret_cast<const VT*>(p);
+                        {
+                            const GT gv = *reinterpret_cast<const GT*>(p);
+#pragma unroll
+                            for (int h = 0; h < V; ++h) x[i][r].v[h] = gv.v[h];
+                        }
 #endif
                         if constexpr (tr<T>::cx) {
                             if (d.conj) {
@@ -331,7 +356,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
                 bool ok = true;
-                if (edge) ok = in_bounds(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG);
+                if (edge) ok = in_count(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG) > 0;
                 if (ok) {
 #pragma unroll
                     for (int h = 0; h < V; ++h) L[row[i + 1].l ^ d.Lr[r] ^ d.Lh[h]] = x[i][r].v[h];
@@ -348,7 +373,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
             const T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
-                if (okd[r]) {
+                if (cntd[r]) {
 #pragma unroll
                     for (int h = 0; h < V; ++h) x[i][r].v[h] = L[row[0].l ^ a.Lrd[r] ^ a.Lhd[h]];
                 }
@@ -358,7 +383,7 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     VT out[NREP];
 #pragma unroll
     for (int r = 0; r < NREP; ++r) {
-        if (okd[r]) {
+        if (cntd[r]) {
 #pragma unroll
             for (int h = 0; h < V; ++h) {
                 T arg[MAXIN];
@@ -386,21 +411,50 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
         auto put = [&](auto NT) {
 #pragma unroll
             for (int r = 0; r < NREP; ++r)
-                if (okd[r]) store_vec_ct<decltype(NT)::value, VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
+                if (cntd[r] == (uint32_t)V) {
+                    GT gv;
+#pragma unroll
+                    for (int h = 0; h < V; ++h) gv.v[h] = out[r].v[h];
+                    store_vec_ct<decltype(NT)::value, GT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), gv);
+                }
+        };
+        // the partial vector at the end of a row (edge tiles, extent of the vector axis not a multiple of V): element by element
+        auto put_partial_vecs = [&](auto WT) {
+            if constexpr (EDGE && PV) {
+#pragma unroll
+                for (int r = 0; r < NREP; ++r)
+                    if (cntd[r] > 0 && cntd[r] < (uint32_t)V) {
+#pragma unroll
+                        for (int h = 0; h < V; ++h)
+                            if ((uint32_t)h < cntd[r]) {
+                                char* p = bp0 + (O)(row[0].g + a.op[0].Gr[r]) + h * sizeof(T);
+                                if constexpr (decltype(WT)::value) {
+                                    TVec<T, 1> one;
+                                    one.v[0] = out[r].v[h];
+                                    store_vec_wt<TVec<T, 1>>(p, one);
+                                } else {
+                                    *reinterpret_cast<T*>(p) = out[r].v[h];
+                                }
+                            }
+                    }
+            }
         };
         if (a.nts == 2) {  // agent-scope write-through ("self-released" launch: smr_device.h)
             if constexpr (has_wt_store<VT>::value) {
 #pragma unroll
                 for (int r = 0; r < NREP; ++r)
-                    if (okd[r]) store_vec_wt<VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
+                    if (cntd[r] == (uint32_t)V) store_vec_wt<VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
+                if constexpr (has_wt_store<TVec<T, 1>>::value) put_partial_vecs(BoolC<true>{});
                 self_release_wait();
             }
         } else if (a.nts) {
             nt_block_guard();
             put(BoolC<true>{});
             nt_block_guard();
+            put_partial_vecs(BoolC<false>{});
         } else {
             put(BoolC<false>{});
+            put_partial_vecs(BoolC<false>{});
         }
     }
 }
@@ -702,7 +756,7 @@ static Swizzle choose_swizzle(int tilelog, int w, const std::vector<LanePattern>
 }
 
 template <class T, class F, bool MIXED, bool WIDE, int V, int MODE, int THRLOG>
-static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool ua = false) {
     constexpr bool EDGE = (MODE & 1) != 0;
     typedef typename off_t_of<WIDE>::type O;
     constexpr int NREP = EPL / V;
@@ -718,7 +772,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     unsigned pgrid = 0;
     if constexpr (!EDGE) {
         const Options& o = options();
-        if (o.tiled_persist && !t.no_persist) {
+        if (o.tiled_persist && !t.no_persist && !ua) {  // (the persistent form keeps aligned vector accesses)
             static const int ncu = [] {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -795,7 +849,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     if (cached.size() == sizeof a) {
         std::memcpy(&a, cached.data(), sizeof a);
         if constexpr ((MODE & 4) == 0) {
-            if (!a.base32 || a.ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
+            if (!a.base32 || a.ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab, ua);
         }
         for (int k = 0; k < c.M; ++k) a.op[k].base = tab.base[k];
         a.nts = nts_now;
@@ -863,7 +917,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         pats.push_back(r);
     }
     int cost0 = 0, cost1 = 0;
-    constexpr bool BITS = SMR_TILED_BITS && !WIDE && !EDGE;
+    constexpr bool BITS = SMR_TILED_BITS && !WIDE && (MODE & 4) == 0;
     Swizzle swz = choose_swizzle(t.tilelog, w, pats, &cost0, &cost1);
     uint32_t fs1 = 31, fs2 = 31, fmask = 0;
     if (BITS && swz.w != 32) {
@@ -971,7 +1025,7 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     a.base32 = base32 ? 1 : 0;
     if constexpr ((MODE & 4) == 0) {
         // the lean variants assume 32-bit tile origins over at most 4 grid dims
-        if (!base32 || ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
+        if (!base32 || ng > NG) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab, ua);
     }
 
     // per-lane table: built once per (plan, kernel variant), kept in device memory (not needed by the BITS form)
@@ -1071,15 +1125,48 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
 }
 
 template <class T, class F, bool MIXED, bool WIDE, int V, int THRLOG>
-static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool ua = false) {
     const Canon& c = plan.c;
     const TilePlan& t = plan.tile;
     bool ragged = false;
     for (int j = 0; j < t.nt; ++j)
         if (c.dims[t.tdim[j]] & (((i64)1 << t.tlog[j]) - 1)) ragged = true;
-    if (ragged) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab);
-    if (!t.ord.empty()) return go3e<T, F, MIXED, WIDE, V, 2, THRLOG>(plan, s, f, tab);
-    return go3e<T, F, MIXED, WIDE, V, 0, THRLOG>(plan, s, f, tab);
+    // ragged extents: the lean kernel plus bounds checks in the workgroups that sit on a last, partly filled tile (round 6; every
+    // ragged problem used to take variant 7 -- lane tables from memory, 64-bit origins, order lookups -- and paid ~2 us for it:
+    // transposes of 7200 x 100 Float64 5.4 us against 3.0 us for 7200 x 128, profiles/r06_ragged_tiles.txt)
+    bool pv = false;  // does some operand's vector axis end in a partial vector?
+    if constexpr (V > 1) {
+        for (int k = 0; k < c.M; ++k) {
+            const int j0 = (k > 0 && t.staged[k] >= 0) ? t.order[k][0] : 0;
+            if (c.dims[t.tdim[j0]] % V) pv = true;
+        }
+        if (ragged && t.ord.empty() && pv) return go3e<T, F, MIXED, WIDE, V, 9, THRLOG>(plan, s, f, tab, ua);
+    }
+    if (ragged && t.ord.empty()) return go3e<T, F, MIXED, WIDE, V, 1, THRLOG>(plan, s, f, tab, ua);
+    if (ragged) return go3e<T, F, MIXED, WIDE, V, 7, THRLOG>(plan, s, f, tab, ua);
+    if (!t.ord.empty()) return go3e<T, F, MIXED, WIDE, V, 2, THRLOG>(plan, s, f, tab, ua);
+    return go3e<T, F, MIXED, WIDE, V, 0, THRLOG>(plan, s, f, tab, ua);
+}
+
+// The same at element alignment (round 6): odd extents, odd row strides, views that begin inside a vector.  Every operand still runs
+// along its unit axis; the one partial vector at the end of a row (extent not a multiple of V) is moved element by element by the
+// workgroups of the ragged last tile.  Elements of 4 or 8 bytes.
+template <class T>
+static bool vector_ok_ua(const Plan& plan, const OpTab& tab, int V) {
+    const Canon& c = plan.c;
+    const TilePlan& t = plan.tile;
+    int vlog = 0;
+    while ((1 << vlog) < V) ++vlog;
+    if (sizeof(T) < 4) return false;
+    for (int k = 0; k < c.M; ++k) {
+        const bool staged = k > 0 && t.staged[k] >= 0;
+        const int j0 = staged ? t.order[k][0] : 0;
+        const int d0 = t.tdim[j0];
+        if (t.tlog[j0] < vlog) return false;
+        if (c.strides[k][d0] != 1) return false;
+        if (((uintptr_t)tab.base[k]) % sizeof(T)) return false;
+    }
+    return true;
 }
 
 // Can every operand be accessed V elements at a time (V * sizeof(T) <= 16 bytes)?
@@ -1112,6 +1199,7 @@ static int go_tl(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool na
         // a lane's 4 elements as 16-byte vectors (8-byte for 1/2-byte element types)
         constexpr int VMAX = (16 / sizeof(T)) > 4 ? 4 : (int)(16 / sizeof(T));
         if (options().tiled_vec && vector_ok<T>(plan, tab, VMAX)) return go3<T, F, false, false, VMAX, THRLOG>(plan, s, f, tab);
+        if (options().tiled_vec && options().tiled_uavec && vector_ok_ua<T>(plan, tab, VMAX)) return go3<T, F, false, false, VMAX, THRLOG>(plan, s, f, tab, true);
     }
     return go3<T, F, MIXED, false, 1, THRLOG>(plan, s, f, tab);
 }

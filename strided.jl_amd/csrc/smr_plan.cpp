@@ -1582,7 +1582,9 @@ static bool plan_flat2(const Canon& c, Flat2Plan& f) {
             if (!o.flat2_long) return false;
             cutlead[s] = true;
             fill *= (long double)e / (long double)((e + 31) / 32 * 32);
-            if (e % vlen) novec = true;  // TILED then moves 4- / 8-byte elements one by one as well, in padded tiles: (999,1001) 7.2 -> 6.4 us
+            // (round 6: TILED keeps 16-byte accesses at element alignment -- (999,1001) Float64 5.7 us there against 6.45 here, Float32 4.6
+            // against 6.1 -- but at 64 MiB this form is ahead again: (2049,2051) Float64 14.6 against 18.4 us)
+            if (e % vlen && (!o.tiled_uavec || c.total * es >= ((i64)32 << 20))) novec = true;  // TILED then moves 4- / 8-byte elements one by one as well, in padded tiles: (999,1001) 7.2 -> 6.4 us
             continue;
         }
         if ((e & (e - 1)) != 0) awkward = odd_short = true;
@@ -1889,19 +1891,58 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 const int tylog = 8 - txlog;
                 plan.part_g0log = std::min(tylog, p2ceil(L0));
                 plan.part_g1log = tylog - plan.part_g0log;
-                const i64 kb = ((K0 + (((i64)vmax) << txlog) - 1) / (((i64)vmax) << txlog)) * (c.nout / K0);
+                i64 kb = ((K0 + (((i64)vmax) << txlog) - 1) / (((i64)vmax) << txlog)) * (c.nout / K0);
+                i64 rows_per_wg = (i64)1 << tylog, y0 = (i64)1 << plan.part_g0log, y1 = (i64)1 << plan.part_g1log;
+                // exact lane map (round 6): a row of 100 Float32 is 25 vectors -- 32 lanes leave 22 % of the workgroup idle, 25 lanes x 10
+                // rows leave 2 % (and 10 rows = 4000 contiguous bytes per step).  Taken when it fills at least 3 % more lanes; the
+                // row may be cut into up to four even segments.  Valid for the vector width assumed here (the launch checks alignment).
+                plan.part_col_tx = 0;
+                if (o.reduce_col_exact) {
+                    bool vdiv = vmax > 1 && K0 % vmax == 0;
+                    for (int k = 1; k < c.M && vdiv; ++k)
+                        if (c.strides[k][0] == 1)
+                            for (int d = 1; d < c.N; ++d)
+                                if (c.strides[k][d] % vmax) vdiv = false;
+                    const i64 vv = vdiv ? vmax : 1;
+                    const i64 n0v = (K0 + vv - 1) / vv, per2 = vv << txlog, nk2 = (K0 + per2 - 1) / per2;
+                    double best = (double)K0 / (double)(nk2 * per2);
+                    i64 btx = 0;
+                    for (i64 sg = 1; sg <= 4; ++sg) {
+                        const i64 tx = (n0v + sg - 1) / sg;
+                        if (tx > 256 || tx * vv * es < 64 || (tx & (tx - 1)) == 0) continue;
+                        const i64 ty = 256 / tx;
+                        if (red < 8 * ty) continue;  // short reductions keep the few-rows rule above
+                        const double util = (double)n0v / (double)(sg * tx) * (double)(tx * ty) / 256.0;
+                        if (util > best + 0.03) {
+                            best = util;
+                            btx = tx;
+                        }
+                    }
+                    if (btx) {
+                        plan.part_col_tx = (int)btx;
+                        plan.part_col_v = (int)vv;
+                        rows_per_wg = 256 / btx;
+                        // rows along the inner reduced dim: the largest divisor of the row count that it can fill
+                        y0 = 1;
+                        for (i64 dv = 1; dv <= rows_per_wg; ++dv)
+                            if (rows_per_wg % dv == 0 && dv <= std::max<i64>(1, L0)) y0 = dv;
+                        y1 = rows_per_wg / y0;
+                        plan.part_col_y0 = (int)y0;
+                        plan.part_col_y1 = (int)y1;
+                        kb = ((n0v + btx - 1) / btx) * (c.nout / K0);
+                    }
+                }
                 i64 split = 1;
-                const i64 rows_per_wg = (i64)1 << tylog;
                 // half the ROW form's target: every workgroup leaves TX*V partials per chunk, and the sweep has 512 ahead of 1024-4096
                 const i64 target = std::max<i64>(1, o.reduce_part_wgs / 2);
                 if (kb < target && red >= rows_per_wg * 16) split = std::max<i64>(1, std::min<i64>(target / kb, red / (rows_per_wg * 8)));
                 split = std::min<i64>(split, 4096);
                 // cut the outer reduced index first, the inner reduced dim with what is left (a short Q -- a trailing
                 // dim of 7 -- used to forbid any cut but 2 along L0: 160 workgroups for 19 MiB)
-                plan.part_qsplit = (int)even_cut(split, Q >> plan.part_g1log);
-                plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split / plan.part_qsplit, L0 / ((i64)4 << plan.part_g0log)));
+                plan.part_qsplit = (int)even_cut(split, Q / y1);
+                plan.part_xsplit = (int)std::max<i64>(1, std::min<i64>(split / plan.part_qsplit, L0 / (4 * y0)));
                 plan.part_split = plan.part_xsplit * plan.part_qsplit;
-                plan.part_tr = 1 << tylog;
+                plan.part_tr = (int)rows_per_wg;
             } else if (row) {
                 // ROW: G consecutive lanes per output, vector loads along the inner reduced dim
                 plan.part_kind = 1;
@@ -2010,6 +2051,7 @@ void describe(Plan& plan) {
         static const char* kinds[] = {"general", "row", "col"};
         n += std::snprintf(buf + n, sizeof buf - n, " nout=%lld form=%s lanes_per_out=%d split=%d", (long long)c.nout, kinds[plan.part_kind],
                            plan.part_tr, plan.part_split);
+        if (plan.part_kind == 2 && plan.part_col_tx) n += std::snprintf(buf + n, sizeof buf - n, " lanes=%dx%d", plan.part_col_tx, 256 / plan.part_col_tx);
     }
     if (c.int_wraps) n += std::snprintf(buf + n, sizeof buf - n, " int_wraps=%d", c.int_wraps);
     std::snprintf(buf + n, sizeof buf - n, " algbytes=%lld", (long long)c.algbytes);

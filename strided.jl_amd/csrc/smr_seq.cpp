@@ -49,9 +49,11 @@ namespace smr {
 static thread_local std::vector<RecLaunch>* tl_recorder = nullptr;
 std::vector<RecLaunch>* recorder() { return tl_recorder; }
 static thread_local bool tl_rec_seq = false, tl_self_released = false;
-void set_recorder(std::vector<RecLaunch>* r, bool for_sequence) {
+static thread_local bool tl_rec_eager = false;  // the recorder belongs to an eager call: `allow` was decided by the eager option, not the sequence's
+void set_recorder(std::vector<RecLaunch>* r, bool allow_self_release, bool eager) {
     tl_recorder = r;
-    tl_rec_seq = r != nullptr && for_sequence;
+    tl_rec_seq = r != nullptr && allow_self_release;
+    tl_rec_eager = r != nullptr && eager;
 }
 void mark_self_released() {
     if (tl_recorder) tl_self_released = true;
@@ -59,7 +61,8 @@ void mark_self_released() {
 bool want_self_release(const Plan& plan) {
     if (!tl_recorder || !tl_rec_seq) return false;
     const Options& o = options();
-    if (!o.seq_self_release) return false;
+    // the two knobs are independent: a sequence asks seq_self_release, an eager call was admitted by eager_self_release
+    if (!(tl_rec_eager ? o.eager_self_release : o.seq_self_release)) return false;
     const Canon& c = plan.c;
     i64 lo = 0, hi = 0;  // extent of the destination in elements
     for (int d = 0; d < c.N; ++d) {

@@ -494,7 +494,8 @@ def test_planner_rules_for_short_dims_big_transposes_and_short_reductions():
     assert "form=col lanes_per_out=32 split=1" in red((512, 384, 64), (1,))      # 16.0 -> 12.4 us
     assert "form=col lanes_per_out=16 split=1" in red((256, 256, 256), (1,))     # 18.4 -> 14.2 us
     # ... and splits aim at 1024 (ROW) / 512 (COL) workgroups instead of 4096
-    assert "form=col lanes_per_out=8 split=512" in red((100, 90, 80, 7), (1, 2, 3))
+    # (round 6: rows of 100 Float32 = 25 vectors get 25 lanes x 10 rows instead of 32 x 8)
+    assert "form=col lanes_per_out=10 split=512 lanes=25x10" in red((100, 90, 80, 7), (1, 2, 3))
     assert "form=row lanes_per_out=256 split=2 " in red((512, 384, 64), (0, 2)) + " "
     # at most `reduce_single` chunks: folded inside the launch; the option round-trips and 0 restores the two-launch form
     assert S.get_option("reduce_single") == 4
@@ -744,7 +745,9 @@ def test_round4_planner_rules_for_ragged_and_batched_shapes():
     # long unit-stride dims: evenly cut leads when 32 x 32 tiles would be poorly filled (and the array has >= 8 MiB) ...
     assert "two-sided" in desc((257, 129, 65), (2, 1, 0)) and "dest_run=1x" in desc((257, 129, 65), (2, 1, 0))
     # ... or when an extent is not a multiple of the 16-byte vector length (TILED would move single elements as well) ...
-    assert "two-sided" in desc((2049, 2051), (1, 0)) and "two-sided" in desc((2049, 2051), (1, 0), np.float32)
+    # (round 6: only from 32 MiB on -- below, TILED keeps 16-byte accesses at element alignment and is ahead)
+    assert "two-sided" in desc((2049, 2051), (1, 0)) and "two-sided" in desc((2899, 2901), (1, 0), np.float32)
+    assert "family=tiled" in desc((999, 1001), (1, 0)) and "family=tiled" in desc((999, 1001), (1, 0), np.float32)
     # ... or next to a short lead that is not a power of two
     assert "two-sided" in desc((17, 33, 65, 31), (3, 2, 0, 1))
     # well-filled, even and power-of-two shapes stay with TILED; so do small arrays

@@ -53,6 +53,12 @@ for dims in ((100, 90, 80), (257, 129, 65), (48, 36, 24, 30), (17, 33, 65, 31), 
     for p in (perms[:3] + perms[-2:]) if N > 3 else perms:
         B = mk(tuple(dims[i] for i in p))
         rec(f"permutedims {dims} {p}", S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims(p))))
+# ragged matrices: transposes and adjoints of (999, 1001)
+for dt in (torch.float64, torch.float32):
+    A = mk((999, 1001), dt)
+    rec(f"transpose (999, 1001) {str(dt)[6:]}", S.make_plan(lambda x: x, None, None, (1001, 999), (mk((1001, 999), dt), A.permutedims((1, 0)))))
+    Bs = mk((999, 999), dt)
+    rec(f"B .= A[:, :999] .+ A[:, :999]' {str(dt)[6:]}", S.make_plan(lambda x, y: x + y, None, None, (999, 999), (Bs, A.sview(slice(None), slice(0, 999)), A.sview(slice(None), slice(0, 999)).permutedims((1, 0)))))
 # tensor-network-like shapes: bond dims mixed with physical dims of 2..4
 import random
 random.seed(1)
