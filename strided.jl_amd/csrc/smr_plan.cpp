@@ -1879,13 +1879,20 @@ int make_plan(const smr_problem* p, Plan& plan) {
                 // (sum(A; dims=2) of 512x384x64 f32: 16.0 -> 12.4 us, 256^3: 18.4 -> 14.7 us, tools/reduce_sweep.py)
                 auto kb_at = [&](int t) { return ((K0 + (((i64)vmax) << t) - 1) / (((i64)vmax) << t)) * (c.nout / K0); };
                 if (o.reduce_col_narrow && kb_at(txlog) < o.reduce_part_wgs) {
+                    int fill = -1;  // the widest segment that still puts a workgroup on every CU (round 6)
+                    const int t0 = txlog;
                     for (int t = txlog - 1; t >= 3 && (((i64)vmax << t) * es >= 128); --t) {
                         if ((red >> (8 - t)) < 8) break;  // fewer than 8 rows of the reduced space per lane row
+                        if (fill < 0 && kb_at(t) >= 256) fill = t;
                         if (kb_at(t) >= o.reduce_part_wgs) {
                             txlog = t;
                             break;
                         }
                     }
+                    // no width reaches the target, but one fills the device without a split: the second launch of a split costs more
+                    // than a thinner first one (sum(A; dims=(3,4)) of (100,90,80,7) Float32: 9000 outputs, 560 rows each: 71 workgroups cut
+                    // 7 ways + a second pass 8.9 us, 282 workgroups of 8 lanes x 32 rows in one launch: see profiles/r06_sum_cases.txt)
+                    if (txlog == t0 && fill >= 0 && o.reduce_col_narrow >= 1 && kb_at(t0) < 256) txlog = fill;
                 }
                 plan.part_txlog = txlog;
                 const int tylog = 8 - txlog;
@@ -1907,6 +1914,8 @@ int make_plan(const smr_problem* p, Plan& plan) {
                     const i64 n0v = (K0 + vv - 1) / vv, per2 = vv << txlog, nk2 = (K0 + per2 - 1) / per2;
                     double best = (double)K0 / (double)(nk2 * per2);
                     i64 btx = 0;
+                    // (cutting the row into more segments just to put a workgroup on every CU and avoid the split loses: rows of 100 as
+                    // 4 x 7 lanes x 36 rows, sum over dims (2,4) of (100,90,80,7) Float32 11.4 us against 9.2 with the split)
                     for (i64 sg = 1; sg <= 4; ++sg) {
                         const i64 tx = (n0v + sg - 1) / sg;
                         if (tx > 256 || tx * vv * es < 64 || (tx & (tx - 1)) == 0) continue;

@@ -177,11 +177,22 @@ def test_nary_maps_with_long_odd_unit_dims(dt):
         c0 = rng.integers(-50, 50, size=tuple(shape[i] for i in q)).astype(dt)
         d0 = rng.integers(-50, 50, size=tuple(shape[i] for i in q)).astype(dt)
         A, C, D = dview(a), dview(c0), dview(d0)
-        plan = S.make_plan(lambda c, x, d: c / 2 + 2 * x - d, None, None, C.size, (C, C, A.permutedims(q), D))
+        # (round 6: with element-aligned vectors TILED takes the odd extents below 32 MiB; this test is about the FLAT form)
+        S.set_option("tiled_uavec", 0)
+        try:
+            plan = S.make_plan(lambda c, x, d: c / 2 + 2 * x - d, None, None, C.size, (C, C, A.permutedims(q), D))
+        finally:
+            S.set_option("tiled_uavec", 1)
         assert "two-sided" in plan.describe(), plan.describe()
         plan.execute()
         torch.cuda.synchronize()
         assert np.array_equal(C.toarray(), c0 / dt(2) + dt(2) * np.transpose(a, q) - d0), (shape, q)
+        # ... and the default plan (TILED with element-aligned 16-byte accesses where it applies) computes the same
+        C2 = dview(c0)
+        plan2 = S.make_plan(lambda c, x, d: c / 2 + 2 * x - d, None, None, C2.size, (C2, C2, A.permutedims(q), D))
+        plan2.execute()
+        torch.cuda.synchronize()
+        assert np.array_equal(C2.toarray(), c0 / dt(2) + dt(2) * np.transpose(a, q) - d0), (shape, q, plan2.describe())
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
