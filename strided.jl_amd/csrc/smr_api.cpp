@@ -943,6 +943,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "orbit_min") o.orbit_min = value;
     else if (n == "orbit_few") o.orbit_few = value;
     else if (n == "orbit_pack") o.orbit_pack = value;
+    else if (n == "orbit_pair") o.orbit_pair = value;
     else if (n == "orbit_pipe") o.orbit_pipe = value;
     else if (n == "orbit_lds_min") o.orbit_lds_min = value;
     else if (n == "orbit_group") o.orbit_group = value;
@@ -1041,6 +1042,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "orbit_min") return o.orbit_min;
     if (n == "orbit_few") return o.orbit_few;
     if (n == "orbit_pack") return o.orbit_pack;
+    if (n == "orbit_pair") return o.orbit_pair;
     if (n == "orbit_pipe") return o.orbit_pipe;
     if (n == "orbit_lds_min") return o.orbit_lds_min;
     if (n == "orbit_group") return o.orbit_group;

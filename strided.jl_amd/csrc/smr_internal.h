@@ -167,6 +167,12 @@ struct OrbitPlan {
     int nslots = 0;
     std::vector<uint32_t> wtile;
     std::vector<uint64_t> wmap;
+    // PAIR form (round 6, 4^4 cubes of 8-byte elements): a workgroup of 256 lanes owns TWO such slot sets (8 tiles: [w * 8 + b * 4 + g]);
+    // where it can, set b = 1 is the orbit whose slot-0 tile is the unit-axis neighbour of set 0's, so that lane pairs {b = 0, b = 1}
+    // move one 64-byte run (smr_k_orbit.hip: orbit_pair_body; tools/orbit16_probe.hip).  pmap[w * 2 + b]: the set's slot map.
+    bool pair_ok = false;
+    std::vector<uint32_t> ptile;
+    std::vector<uint64_t> pmap;
     size_t lds_bytes = 0;
 };
 
@@ -317,6 +323,7 @@ struct Options {
                              // 5.60 -> 4.61 us, 24^4 3.41 -> 3.01 us; larger sizes keep the 8^4 cubes)
     i64 orbit_wgs = 0;       // persistent ORBIT form: cap on the number of workgroups (0 = as many as the machine holds at once)
     i64 orbit_lds_min = 0;   // experiment: request at least this much LDS per ORBIT workgroup (limits residency)
+    i64 orbit_pair = 1;      // 4^4 cubes of 8-byte elements: two orbits per workgroup, unit-axis neighbours in the lane pairs (64-byte runs in slot 0); 1: write-through launches only, 2: always
     i64 orbit_pack = 1;      // orbits with fewer distinct tiles than |G| share a workgroup (0: one workgroup per orbit, tiles repeated)
     i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
     i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes (default 0: all) and

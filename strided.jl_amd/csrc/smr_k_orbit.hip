@@ -395,7 +395,185 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
     }
 }
 
+// ---- PAIR form (round 6): 4^4 cubes of 8-byte elements, |G| = 4, identity view first ---------------------------------------------
+// tools/orbit16_probe.hip: the memory system serves this pattern by REQUESTS -- one per 32-byte run of a cube (TCP_TCC_READ_REQ =
+// 262144 for the 8 MiB of the 4-way sum at 32^4, a quarter of what a line-wide kernel needs per request) -- and a lane quad that
+// covers two neighbouring cubes' halves of one 64-byte run makes one request of two.  A workgroup of 256 lanes owns TWO slot sets
+// (plan_orbit: where it can, set 1 is the orbit of set 0's unit-axis neighbour); lane bit 1 selects the set, so slot 0 of both moves
+// as 64-byte runs -- 4.29 -> 4.13 us warm, 6.5 -> 5.9 us from HBM (the 16-cube form with two paired slots loses: one workgroup
+// per CU waits for ALL its loads before the first exchange).  Every cube has its own 2-KiB LDS region; the in-region index folds its
+// three high bits into bank bits 1..3 and set 1's regions are XORed with 17: the 32 lanes of a half-wave then hit 32 distinct
+// 8-byte banks in the parking writes and in every transposing read (16 lanes of a set stay inside {bit 0 ^ bit 4 = const}).
+// Table: per workgroup 4 entries (one per slot j) of 8 words -- origin of set 0 / set 1 (element offsets; first word 0xffffffff:
+// idle), the own region words (16 bits per set: region << 8 | parity * 17), then for views 1..3 the region words of the cubes an
+// output of slot j reads that view from.
+template <class T, class F>
+SMR_DEV void orbit_pair_body(const OrbitArgs a, const OrbitHead h, F f) {
+    constexpr int V = 2;
+    typedef OVec<T, V> VT;
+    constexpr int NK = F::NIN;
+    static_assert(NK >= 2 && NK <= 4 && sizeof(T) == 8, "PAIR form: 2..4 views of 8-byte elements");
+    typedef uint32_t entv __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = (tid >> 1) & 1u;
+    const uint32_t u = (tid & 1u) | ((tid >> 2) << 1);  // the lane's place in its cube (7 bits)
+    const uint32_t e = u * V;
+    entv ent[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ent[j] = reinterpret_cast<const entv*>(h.list)[blockIdx.x * 4u + (uint32_t)j];
+    const bool live = ent[0][0] != 0xffffffffu;
+    uint32_t cj[OMAXT], goff = 0;
+#pragma unroll
+    for (int j = 0; j < OMAXT; ++j) {
+        cj[j] = __builtin_amdgcn_ubfe(e, (h.eshp >> (8 * j)) & 0xffu, (h.elenp >> (8 * j)) & 0xffu);
+        goff += cj[j] * h.estride[j];
+    }
+    i64 org[4];
+    VT x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t o32 = live ? (b ? ent[j][1] : ent[j][0]) : 0u;
+        org[j] = (i64)o32 * (i64)sizeof(T);
+        x[j] = *reinterpret_cast<const VT*>(h.src + org[j] + goff);
+    }
+    // ---- while the loads fly: LDS indices ----------------------------------------------------------------------------------------
+    auto swz = [](uint32_t i) { return i ^ (((i >> 5) & 7u) << 1); };
+    const uint32_t sh = b * 16u;
+    uint32_t wi[V], ri[NK][V], own[4], src[4][NK];
+#pragma unroll
+    for (int hh = 0; hh < V; ++hh) wi[hh] = swz(e + (uint32_t)hh);
+#pragma unroll
+    for (int k = 1; k < NK; ++k) {
+        uint32_t l = 0;
+#pragma unroll
+        for (int j = 0; j < OMAXT; ++j) l |= cj[j] << a.lsh[k][j];
+#pragma unroll
+        for (int hh = 0; hh < V; ++hh) ri[k][hh] = swz(l | ((uint32_t)hh << a.lsh[k][0]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        own[j] = (ent[j][2] >> sh) & 0xffffu;
+#pragma unroll
+        for (int k = 1; k < NK; ++k) src[j][k] = (ent[j][2 + k] >> sh) & 0xffffu;
+    }
+    uint32_t cbit[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) cbit[k] = a.conjbit[k];
+    uint32_t conj0 = a.conj0 ? 0x80000000u : 0u, nts_flag = (uint32_t)a.nts;
+    // everything above is pinned in registers HERE, while the global loads fly (left alone the compiler fetches the kernel arguments
+    // it needs behind the barrier: two serial scalar-memory round trips in a launch whose waves live 2 us)
+    asm volatile("" : "+s"(conj0), "+s"(nts_flag));
+#pragma unroll
+    for (int k = 0; k < NK; ++k) asm volatile("" : "+s"(cbit[k]));
+    // the LDS addresses themselves (24 of reads, 8 of writes): formed here, not behind the barrier -- whole 32-bit LDS addresses (the
+    // base of the dynamic segment included: added behind the barrier it cost 24 more vector instructions in front of the reads)
+    typedef __attribute__((address_space(3))) unsigned long long LU;  // (8-byte elements travel as one 64-bit word: ds_write_b64 / ds_read_b64)
+    auto lput = [](uint32_t addr, const T& v) {
+        unsigned long long w;
+        __builtin_memcpy(&w, &v, 8);
+        *(LU*)(uintptr_t)addr = w;
+    };
+    auto lget = [](uint32_t addr) {
+        const unsigned long long w = *(const LU*)(uintptr_t)addr;
+        T v;
+        __builtin_memcpy(&v, &w, 8);
+        return v;
+    };
+    const uint32_t lbase = (uint32_t)(uintptr_t)smem_raw;
+    uint32_t wa[4][V], ra[4][V][NK];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int hh = 0; hh < V; ++hh) {
+            wa[j][hh] = lbase + (own[j] ^ wi[hh]) * (uint32_t)sizeof(T);
+            asm volatile("" : "+v"(wa[j][hh]));
+#pragma unroll
+            for (int k = 1; k < NK; ++k) {
+                ra[j][hh][k] = lbase + (src[j][k] ^ ri[k][hh]) * (uint32_t)sizeof(T);
+                asm volatile("" : "+v"(ra[j][hh][k]));
+            }
+        }
+    // ---- park, exchange ----------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int hh = 0; hh < V; ++hh) lput(wa[j][hh], x[j].v[hh]);
+    __syncthreads();
+    T val[4][V][NK];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int hh = 0; hh < V; ++hh) {
+            val[j][hh][0] = x[j].v[hh];
+#pragma unroll
+            for (int k = 1; k < NK; ++k) val[j][hh][k] = lget(ra[j][hh][k]);
+        }
+    __builtin_amdgcn_sched_barrier(0);  // all LDS reads issued before the first use: one LDS latency, then per slot adds and its store
+    if (!live) return;
+    auto outputs = [&](auto mode) {
+        constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            VT out;
+#pragma unroll
+            for (int hh = 0; hh < V; ++hh) {
+                T arg[MAXIN];
+#pragma unroll
+                for (int k = 0; k < MAXIN; ++k) {
+                    arg[k] = T{};
+                    if (k < NK) {
+                        T v = val[j][hh][k < NK ? k : 0];
+                        if constexpr (tr<T>::cx) v = ocj(v, cbit[k < NK ? k : 0]);
+                        arg[k] = v;
+                    }
+                }
+                T o = f(arg);
+                if constexpr (tr<T>::cx) o = ocj(o, conj0);
+                out.v[hh] = o;
+            }
+            char* p = h.dst + org[j] + goff;
+            if constexpr (MODE == 2) {
+                store_vec_wt<VT>(p, out);
+            } else if constexpr (MODE == 1) {
+                nt_block_guard();
+                store_vec_ct<true, VT>(p, out);
+                nt_block_guard();
+            } else {
+                store_vec_ct<false, VT>(p, out);
+            }
+        }
+    };
+    if (nts_flag == 2) {
+        if constexpr (has_wt_store<VT>::value) outputs(IntC<2>{});
+        self_release_wait();
+    } else if (nts_flag) {
+        outputs(IntC<1>{});
+    } else {
+        outputs(IntC<0>{});
+    }
+}
+
 #ifndef SMR_JIT
+template <class T, class F>
+__global__ void __launch_bounds__(256) k_orbit_pair(const uint32_t* list, const char* src, char* dst, uint32_t eshp, uint32_t elenp, uint32_t es0, uint32_t es1,
+                                                    uint32_t es2, uint32_t es3, uint32_t ntlog, const OrbitArgs a, F f SMR_STAMP_PARAM) {
+    SMR_STAMP_BEGIN
+    OrbitHead h;
+    h.list = list;
+    h.src = src;
+    h.dst = dst;
+    h.eshp = eshp;
+    h.elenp = elenp;
+    h.estride[0] = es0;
+    h.estride[1] = es1;
+    h.estride[2] = es2;
+    h.estride[3] = es3;
+    h.ntlog = ntlog;
+    orbit_pair_body<T, F>(a, h, f);
+    SMR_STAMP_END
+}
+
 template <class T, class F, int V, int NREP, int NG, bool OWN0, bool PIPE>
 __global__ void __launch_bounds__(1024) k_orbit_map(const uint32_t* list, const char* src, char* dst, uint32_t eshp, uint32_t elenp, uint32_t es0, uint32_t es1,
                                                     uint32_t es2, uint32_t es3, uint32_t ntlog, const OrbitArgs a, F f SMR_STAMP_PARAM) {
@@ -642,6 +820,100 @@ static int go4(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     }
 }
 
+// PAIR form (orbit_pair_body): builds the 8-word entries once per plan, launches 256 lanes per two slot sets
+template <class T, class F>
+static int go_pair(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
+    const Canon& c = plan.c;
+    const OrbitPlan& o = plan.orbit;
+    constexpr int NS = 4, V = 2;
+    OrbitArgs a;
+    std::vector<unsigned char>& cached = plan.tiled_args[2];
+    if (cached.size() == sizeof a) {
+        std::memcpy(&a, cached.data(), sizeof a);
+    } else {
+        std::memset(&a, 0, sizeof a);
+        const i64 es = (i64)sizeof(T);
+        a.nin = c.M - 1;
+        a.tilelog = o.tilelog;
+        a.ntlog = 8;
+        a.conj0 = tab.conj[0];
+        int nt = 0, sh = 0, jof[MAXN];
+        for (int d = 0; d < c.N; ++d) {
+            jof[d] = -1;
+            if (o.lg[d] == 0) continue;
+            if (nt >= OMAXT) return set_error(SMR_EUNSUPPORTED, "orbit: too many tiled dims");
+            jof[d] = nt;
+            a.esh[nt] = sh;
+            a.elen[nt] = o.lg[d];
+            a.estride[nt] = (uint32_t)(c.strides[o.k0][d] * es);
+            sh += o.lg[d];
+            ++nt;
+        }
+        for (int k = 1; k < c.M; ++k) {
+            for (int d = 0; d < c.N; ++d)
+                if (jof[d] >= 0) a.lsh[k - 1][jof[d]] = a.esh[jof[o.pdim[k][d]]];
+            a.conjbit[k - 1] = tab.conj[k] ? 0x80000000u : 0u;
+        }
+        if (!plan.lanetab[3] && !jit_dry_run()) {
+            const size_t nwg = o.pmap.size() / 2;
+            std::vector<uint32_t> rows(nwg * 4 * 8, 0u);
+            auto region = [](int slot, int b) { return (uint32_t)(((2 * slot + b) << 8) | (b ? 17 : 0)); };
+            for (size_t w = 0; w < nwg; ++w) {
+                if (o.ptile[w * 8] == 0xffffffffu) {
+                    rows[w * 32] = 0xffffffffu;
+                    continue;
+                }
+                for (int j = 0; j < NS; ++j) {
+                    uint32_t* en = &rows[(w * 4 + (size_t)j) * 8];
+                    for (int b = 0; b < 2; ++b) {
+                        i64 id = o.ptile[w * 8 + (size_t)b * 4 + (size_t)j], org = 0;
+                        for (int d = 0; d < c.N; ++d) {
+                            org += (id % o.ntiles[d]) * (c.strides[o.k0][d] << o.lg[d]);
+                            id /= o.ntiles[d];
+                        }
+                        en[b] = (uint32_t)org;
+                        en[2] |= region(j, b) << (16 * b);
+                        const uint64_t mp = o.pmap[w * 2 + (size_t)b];
+                        // view k of the kernel = input k + 1; input 1 is the identity view (the lane's own registers)
+                        for (int k = 1; k < c.M - 1 && k < 4; ++k) en[2 + k] |= region((int)((mp >> ((j * 8 + k) * 2)) & 3u), b) << (16 * b);
+                    }
+                }
+            }
+            void* dptr = nullptr;
+            hipError_t e = hipMalloc(&dptr, rows.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return hip_error(e, "hipMalloc(orbit pair table)");
+            e = hipMemcpy(dptr, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(dptr);
+                return hip_error(e, "hipMemcpy(orbit pair table)");
+            }
+            plan.lanetab[3] = dptr;
+        }
+        a.list = reinterpret_cast<const uint32_t*>(plan.lanetab[3]);
+        if (!jit_dry_run()) {
+            cached.resize(sizeof a);
+            std::memcpy(cached.data(), &a, sizeof a);
+        }
+    }
+    a.src = (const char*)tab.base[o.k0];
+    a.dst = (char*)tab.base[0];
+    const Options& opt = options();
+    a.nts = opt.nt_store > 0 ? 1 : 0;  // (32- / 64-byte runs: partial lines meet in L2, plain stores -- as in the one-orbit form)
+    if (has_wt_store<OVec<T, V>>::value && (opt.nt_store == 2 || want_self_release(plan))) a.nts = 2;
+    a.nlist = (int32_t)(o.pmap.size() / 2);
+    const unsigned grid = (unsigned)(o.pmap.size() / 2), block = 256;
+    const size_t lds = 8 * (sizeof(T) << 8);
+    if (jit_no_launch()) return SMR_OK;
+    clear_sticky_error();
+    auto kern = k_orbit_pair<T, F>;
+    mark_sliceable(2, 0u, (unsigned)(4 * 8 * sizeof(uint32_t)));  // one table row (four entries) per workgroup; the pointer is parameter 0
+    if (a.nts == 2) mark_self_released();
+    const OrbitHead h = orbit_head(a);
+    SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, h.list, h.src, h.dst, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3], h.ntlog, a,
+               f SMR_STAMP_ARG(grid, block));
+    return check_launch("k_orbit_pair");
+}
+
 // persistent pipelined form: when the LDS footprint leaves one workgroup per CU and every CU gets several orbits
 template <class T, class F, int V, int NREP, int NG, bool OWN0>
 static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
@@ -664,6 +936,18 @@ static int go2(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     bool own0 = true;  // is input 1 the identity view?
     for (int d = 0; d < plan.c.N; ++d)
         if (o.pdim[1][d] != d) own0 = false;
+    if constexpr (!is_jit<F>::value && V == 2 && NREP == 1 && sizeof(T) == 8) {
+        if constexpr (F::NIN >= 2 && F::NIN <= 4) {
+            // Taken for WRITE-THROUGH launches (store policy 2: recorded sequences, eager calls on library-owned streams): there every
+            // store travels to the memory side on its own and 64-byte pieces pay -- replay of the 4-way sum at 32^4 4.72 -> 4.42 us
+            // on one queue, 3.66 -> 3.21 cut in two, bench step 5.65 -> 5.36 us.  With plain stores (HIP launches) the two forms have
+            // the same span (3.0 us) and the one-orbit form the shorter launch-to-launch time (4.43 against 4.74 us in a hipGraph):
+            // it stays.  orbit_pair = 2 forces this form everywhere (tests, tools/orbit_pack_ab.py).
+            const bool wt = has_wt_store<OVec<T, V>>::value && (options().nt_store == 2 || want_self_release(plan));
+            if (o.pair_ok && own0 && o.ng == 4 && plan.c.M - 1 == F::NIN && (options().orbit_pair >= 2 || (options().orbit_pair == 1 && wt)))
+                return go_pair<T, F>(plan, s, f, tab);
+        }
+    }
     if (o.ng == 2) return own0 ? go3<T, F, V, NREP, 2, true>(plan, s, f, tab) : go3<T, F, V, NREP, 2, false>(plan, s, f, tab);
     return own0 ? go3<T, F, V, NREP, 4, true>(plan, s, f, tab) : go3<T, F, V, NREP, 4, false>(plan, s, f, tab);
 }

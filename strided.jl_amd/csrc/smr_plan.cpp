@@ -993,6 +993,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
     };
     auto field = [](int g, int k) { return (unsigned)((g * 8 + k) * 2); };  // k = input index - 1
     std::vector<Wg> wgs;
+    std::vector<char> wg_full;      // the workgroup holds ONE orbit of |G| distinct tiles, slot g = g_g . t (PAIR form)
     std::vector<uint32_t> cell_wg;  // super-cell of every workgroup (orbit_deal = 1)
     // pending[s]: orbits of s distinct tiles waiting for company -- (tiles, per-tile reads as indices into the orbit's own tiles)
     struct Part {
@@ -1019,6 +1020,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
             for (int k = 1; k < c.M; ++k) w.map |= ((w.map >> field(0, k - 1)) & 3u) << field(g, k - 1);
         }
         wgs.push_back(w);
+        wg_full.push_back(0);
         cell_wg.push_back(cell);
         pp.clear();
     };
@@ -1053,6 +1055,7 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
                 for (int k = 1; k < c.M; ++k) w.map |= (uint64_t)o.slot[a][k] << field(g, k - 1);
             }
             wgs.push_back(w);
+            wg_full.push_back(ndist == o.ng && NS == o.ng ? 1 : 0);
             cell_wg.push_back(cell_of[i]);
             continue;
         }
@@ -1067,6 +1070,91 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
     }
     for (int sd = 1; sd <= MAXG; ++sd) emit_packed(sd, cell_wg.empty() ? 0u : cell_wg.back());
     constexpr int NX = 8;
+    // ---- PAIR form: two slot sets per workgroup, unit-axis neighbours first ----------------------------------------------------------
+    o.pair_ok = false;
+    {
+        int ntd = 0;
+        bool cubes = true;
+        for (int d = 0; d < c.N; ++d)
+            if (o.lg[d] > 0) {
+                ++ntd;
+                if (o.lg[d] != 2) cubes = false;
+            }
+        if (opt.orbit_pair && o.ng == 4 && NS == 4 && ntd == 4 && cubes && o.tilelog == 8 && es == 8 && o.vec == 2 && o.lg[0] == 2 && opt.orbit_deal != 1 && wgs.size() >= 16) {
+            std::vector<int> owner((size_t)o.ntiles_total, -1);
+            for (size_t i = 0; i < wgs.size(); ++i)
+                if (wg_full[i])
+                    for (int g = 0; g < NS; ++g) owner[wgs[i].tile[g]] = (int)i;
+            std::vector<char> used(wgs.size(), 0);
+            std::vector<uint32_t> pt;
+            std::vector<uint64_t> pm;
+            auto push_set = [&](const uint32_t* tile, uint64_t map) {
+                for (int g = 0; g < NS; ++g) pt.push_back(tile[g]);
+                pm.push_back(map);
+            };
+            uint64_t stdmap = 0;
+            for (int g = 0; g < NS; ++g)
+                for (int k = 1; k < c.M; ++k) stdmap |= (uint64_t)o.slot[g][k] << field(g, k - 1);
+            std::vector<size_t> loose;
+            for (size_t i = 0; i < wgs.size(); ++i) {
+                if (used[i]) continue;
+                int j = -1;
+                uint32_t nb = 0;
+                if (wg_full[i]) {
+                    const uint32_t a0 = wgs[i].tile[0], c0 = (uint32_t)(a0 % o.ntiles[0]);
+                    if ((i64)(c0 ^ 1u) < o.ntiles[0]) {
+                        nb = a0 - c0 + (c0 ^ 1u);
+                        j = owner[nb];
+                    }
+                }
+                if (j < 0 || (size_t)j == i || used[(size_t)j]) {
+                    loose.push_back(i);
+                    used[i] = 1;
+                    continue;
+                }
+                // set 1 = the neighbour's orbit, re-based so that ITS slot 0 is the neighbour tile
+                i64 nc[MAXN], id = nb;
+                for (int d = 0; d < c.N; ++d) {
+                    nc[d] = id % o.ntiles[d];
+                    id /= o.ntiles[d];
+                }
+                uint32_t bt[MAXG];
+                for (int g = 0; g < NS; ++g) {
+                    i64 v = 0;
+                    for (int d = 0; d < c.N; ++d) v += nc[d] * tmul[G[g][d]];
+                    bt[g] = (uint32_t)v;
+                }
+                // set 0 = the lower half of the 64-byte run (lane pairs then run through ascending addresses)
+                if ((wgs[i].tile[0] % o.ntiles[0]) & 1) {
+                    push_set(bt, stdmap);
+                    push_set(wgs[i].tile, wgs[i].map);
+                } else {
+                    push_set(wgs[i].tile, wgs[i].map);
+                    push_set(bt, stdmap);
+                }
+                used[i] = used[(size_t)j] = 1;
+            }
+            for (size_t q = 0; q < loose.size(); q += 2) {  // what found no neighbour (diagonals, packed orbits): any two
+                const Wg& a = wgs[loose[q]];
+                const Wg& b = wgs[q + 1 < loose.size() ? loose[q + 1] : loose[q]];  // an odd one out runs twice (same values stored twice)
+                push_set(a.tile, a.map);
+                push_set(b.tile, b.map);
+            }
+            // one contiguous run of the list per XCD, as below
+            const size_t np = pm.size() / 2, pcs = (np + NX - 1) / NX;
+            o.ptile.assign(pcs * NX * 8, 0xffffffffu);
+            o.pmap.assign(pcs * NX * 2, 0);
+            for (size_t x = 0; x < (size_t)NX; ++x)
+                for (size_t sl = 0; sl < pcs; ++sl)
+                    if (x * pcs + sl < np) {
+                        const size_t src = x * pcs + sl, dst = sl * NX + x;
+                        for (int q = 0; q < 8; ++q) o.ptile[dst * 8 + q] = pt[src * 8 + q];
+                        o.pmap[dst * 2] = pm[src * 2];
+                        o.pmap[dst * 2 + 1] = pm[src * 2 + 1];
+                    }
+            o.pair_ok = true;
+        }
+    }
     auto place = [&](size_t pos, const Wg& w) {
         for (int g = 0; g < NS; ++g) o.wtile[pos * NS + g] = w.tile[g];
         o.wmap[pos] = w.map;
@@ -2042,6 +2130,7 @@ void describe(Plan& plan) {
                 first = false;
             }
         n += std::snprintf(buf + n, sizeof buf - n, " group=%d orbits=%d lds=%zu grid=%zu", ob.ng, ob.norbits, ob.lds_bytes, ob.wmap.size());
+        if (ob.pair_ok) n += std::snprintf(buf + n, sizeof buf - n, " pair_grid=%zu", ob.pmap.size() / 2);
     } else if (plan.family == FAM_FLAT && plan.flatb.on) {
         n += std::snprintf(buf + n, sizeof buf - n, " batched block=%d(d0..d%d) blocks_per_wg=%d", plan.flatb.P, plan.flatb.g - 1, plan.flatb.K);
     } else if (plan.family == FAM_FLAT && plan.flat2.on) {

@@ -160,3 +160,68 @@ def test_split_reductions_other_ops(op, npop, option):
         want = npop(a, axis=rd, keepdims=True)
         got = S.Array(res)
         assert np.allclose(got.reshape(want.shape), want, rtol=1e-10), f"{op} dims={rd}"
+
+
+PERMS4 = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.complex64])
+@pytest.mark.parametrize("n", [32, 24, 40])
+def test_orbit_pair_form_bit_exact(n, dt, option):
+    """ORBIT, PAIR form (two slot sets per workgroup, unit-axis neighbours in the lane pairs; 4^4 cubes of 8-byte elements), forced
+    for plain-store launches too (orbit_pair = 2): the 4-way permuted sum (README.md:104 of the reference), three and two views of
+    the same rotation group, a conjugated view, and the in-place update -- each bit-identical to NumPy and to the one-orbit form."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(-999, 999, size=(n,) * 4).astype(dt)
+    if dt == np.complex64:
+        a = (a + 1j * rng.integers(-999, 999, size=(n,) * 4)).astype(dt)
+    views = lambda A, idx: tuple(A.permutedims(PERMS4[i]) for i in idx)
+    cases = [((0, 1, 2, 3), lambda w, x, y, z: w + x + y + z, lambda v: ((v[0] + v[1]) + v[2]) + v[3]),
+             ((0, 1, 3), lambda w, x, y: w + x + y, lambda v: (v[0] + v[1]) + v[2]),
+             ((0, 2), lambda w, x: w + x, lambda v: v[0] + v[1])]
+    for idx, f, ref in cases:
+        want = ref([np.transpose(a, PERMS4[i]) for i in idx])
+        got = {}
+        for pair in (2, 0):
+            option("orbit_pair", pair)
+            A, Cc = dview(a), dview(np.zeros_like(a))
+            plan = S.make_plan(f, None, None, A.size, (Cc,) + views(A, idx))
+            d = plan.describe()
+            plan.execute(cur())
+            sync()
+            got[pair] = host(Cc)
+            assert np.array_equal(got[pair], want), f"n={n} {dt.__name__} views={idx} orbit_pair={pair}: {d}"
+            if n % 8 == 0 and pair == 2 and "family=orbit" in d and "tile=d0:4" in d:
+                assert "pair_grid=" in d, d
+            # in place: the destination is the buffer
+            A2 = dview(a)
+            plan2 = S.make_plan(f, None, None, A2.size, (A2,) + views(A2, idx))
+            if "family=orbit" in plan2.describe():  # (only the orbit family reads a whole orbit before it writes it: aliasing is safe there)
+                plan2.execute(cur())
+                sync()
+                assert np.array_equal(host(A2), want), f"in place, n={n} {dt.__name__} views={idx} orbit_pair={pair}: {plan2.describe()}"
+    if dt == np.complex64:  # a conjugated view
+        option("orbit_pair", 2)
+        A, Cc = dview(a), dview(np.zeros_like(a))
+        plan = S.make_plan(lambda w, x, y, z: w + x + y + z, None, None, A.size, (Cc, A, A.permutedims(PERMS4[1]).conj(), A.permutedims(PERMS4[2]), A.permutedims(PERMS4[3]).conj()))
+        plan.execute(cur())
+        sync()
+        want = ((a + np.conj(np.transpose(a, PERMS4[1]))) + np.transpose(a, PERMS4[2])) + np.conj(np.transpose(a, PERMS4[3]))
+        assert np.array_equal(host(Cc), want), plan.describe()
+
+
+def test_orbit_pair_form_runs_in_recorded_sequences():
+    """The replayed bench step (smr_seq: write-through launches) takes the PAIR form by itself and stays exact."""
+    n = 32
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((n,) * 4)
+    A, B, Cc = dview(a), dview(np.zeros_like(a)), dview(np.zeros_like(a))
+    p2 = S.make_plan(lambda x: x, None, None, A.size, (B, A.permutedims((3, 2, 1, 0))))
+    p3 = S.make_plan(lambda w, x, y, z: w + x + y + z, None, None, A.size, (Cc,) + tuple(A.permutedims(p) for p in PERMS4))
+    seq = S.Sequence().add(p2).add(p3)
+    seq.run(5, cur())
+    seq.wait()
+    sync()
+    assert np.array_equal(host(B), np.transpose(a, (3, 2, 1, 0)))
+    at = lambda p: np.transpose(a, p)
+    assert np.array_equal(host(Cc), ((at(PERMS4[0]) + at(PERMS4[1])) + at(PERMS4[2])) + at(PERMS4[3]))

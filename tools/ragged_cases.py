@@ -1,3 +1,5 @@
+"""Transposes of ragged / line-misaligned shapes against their aligned neighbours: us per launch in a hipGraph.
+Usage: python tools/ragged_cases.py [option=value ...]"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch

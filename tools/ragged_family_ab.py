@@ -1,3 +1,5 @@
+"""Ragged permutedims: the planner's choice against tiled_uavec = 0 (element-aligned vectors off) and flat = 0 (TILED forced).
+Usage: python tools/ragged_family_ab.py"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
