@@ -100,6 +100,28 @@ SMR_DEV c64 ocj(c64 x, uint32_t bit) {
     return c64{x.re, __longlong_as_double(__double_as_longlong(x.im) ^ ((long long)bit << 32))};
 }
 
+// LDS access by absolute 32-bit address (base of the dynamic segment included), element as one 4- / 8- / 16-byte word: lets a kernel
+// form every address of the exchange BEFORE its barrier (left to the compiler, base and scaling are added behind it, in front of the reads)
+template <int BYTES> struct lds_word;
+template <> struct lds_word<4> { typedef uint32_t type; };
+template <> struct lds_word<8> { typedef unsigned long long type; };
+template <> struct lds_word<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <class T>
+SMR_DEV void lds_put(uint32_t addr, const T& v) {
+    typedef typename lds_word<sizeof(T)>::type W;
+    W w;
+    __builtin_memcpy(&w, &v, sizeof(T));
+    *(__attribute__((address_space(3))) W*)(uintptr_t)addr = w;
+}
+template <class T>
+SMR_DEV T lds_get(uint32_t addr) {
+    typedef typename lds_word<sizeof(T)>::type W;
+    const W w = *(const __attribute__((address_space(3))) W*)(uintptr_t)addr;
+    T v;
+    __builtin_memcpy(&v, &w, sizeof(T));
+    return v;
+}
+
 // NG = |G| (2 or 4; a group of order 3 is padded with a copy of slot 0), OWN0: view 0 is the identity view
 // (its value is the lane's own register).  Apart from the rare > 4 grid dims there is no branch on a
 // kernel argument before the stores: every scalar branch on a just-loaded argument is a serial
@@ -245,6 +267,31 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
             }
     }
 
+    // one-shot form with few addresses (the 4-way sum: 24 of reads, 8 of writes): whole LDS addresses, formed here (round 6: the
+    // base and the scaling used to be added behind the barrier -- ~50 vector instructions in front of the transposing reads)
+    constexpr bool ABS = !PIPE && (NG * NLR * NREP * V <= 32) && (sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16);
+    uint32_t pa[ABS ? NG : 1][NREP][V], la[ABS ? NG : 1][NK][NREP][V];
+    if constexpr (ABS) {
+        const uint32_t lbase = (uint32_t)(uintptr_t)smem_raw;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < NREP; ++r)
+#pragma unroll
+                for (int hh = 0; hh < V; ++hh) {
+                    pa[g][r][hh] = lbase + ((((uint32_t)g) << tilelog) + wi[r][hh]) * (uint32_t)sizeof(T);
+                    asm volatile("" : "+v"(pa[g][r][hh]));
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        la[g][k][r][hh] = 0;
+                        if (!(OWN0 && k == 0)) {
+                            la[g][k][r][hh] = lbase + (sbase[g][k] + ri[k][r][hh]) * (uint32_t)sizeof(T);
+                            asm volatile("" : "+v"(la[g][k][r][hh]));
+                        }
+                    }
+                }
+    }
+
     uint32_t wg = blockIdx.x, tidp = tid;
     for (;;) {
         if constexpr (PIPE) {
@@ -278,6 +325,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
 #pragma unroll
                 for (int hh = 0; hh < V; ++hh) {
                     if constexpr (PIPE) L[swz(e + hh)] = x[g][r].v[hh];
+                    else if constexpr (ABS) lds_put<T>(pa[g][r][hh], x[g][r].v[hh]);
                     else L[wi[r][hh]] = x[g][r].v[hh];
                 }
             }
@@ -316,6 +364,8 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
                                 if constexpr (PIPE) {
                                     const uint32_t idx = lr[k][r] | ((uint32_t)h << hbit[k]);
                                     val[gi][h][k] = lds[sbase[g][k] + swz(idx)];
+                                } else if constexpr (ABS) {
+                                    val[gi][h][k] = lds_get<T>(la[g][k][r][h]);
                                 } else {
                                     val[gi][h][k] = lds[sbase[g][k] + ri[k][r][h]];
                                 }
@@ -468,18 +518,6 @@ SMR_DEV void orbit_pair_body(const OrbitArgs a, const OrbitHead h, F f) {
     for (int k = 0; k < NK; ++k) asm volatile("" : "+s"(cbit[k]));
     // the LDS addresses themselves (24 of reads, 8 of writes): formed here, not behind the barrier -- whole 32-bit LDS addresses (the
     // base of the dynamic segment included: added behind the barrier it cost 24 more vector instructions in front of the reads)
-    typedef __attribute__((address_space(3))) unsigned long long LU;  // (8-byte elements travel as one 64-bit word: ds_write_b64 / ds_read_b64)
-    auto lput = [](uint32_t addr, const T& v) {
-        unsigned long long w;
-        __builtin_memcpy(&w, &v, 8);
-        *(LU*)(uintptr_t)addr = w;
-    };
-    auto lget = [](uint32_t addr) {
-        const unsigned long long w = *(const LU*)(uintptr_t)addr;
-        T v;
-        __builtin_memcpy(&v, &w, 8);
-        return v;
-    };
     const uint32_t lbase = (uint32_t)(uintptr_t)smem_raw;
     uint32_t wa[4][V], ra[4][V][NK];
 #pragma unroll
@@ -498,7 +536,7 @@ SMR_DEV void orbit_pair_body(const OrbitArgs a, const OrbitHead h, F f) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int hh = 0; hh < V; ++hh) lput(wa[j][hh], x[j].v[hh]);
+        for (int hh = 0; hh < V; ++hh) lds_put<T>(wa[j][hh], x[j].v[hh]);
     __syncthreads();
     T val[4][V][NK];
 #pragma unroll
@@ -507,7 +545,7 @@ SMR_DEV void orbit_pair_body(const OrbitArgs a, const OrbitHead h, F f) {
         for (int hh = 0; hh < V; ++hh) {
             val[j][hh][0] = x[j].v[hh];
 #pragma unroll
-            for (int k = 1; k < NK; ++k) val[j][hh][k] = lget(ra[j][hh][k]);
+            for (int k = 1; k < NK; ++k) val[j][hh][k] = lds_get<T>(ra[j][hh][k]);
         }
     __builtin_amdgcn_sched_barrier(0);  // all LDS reads issued before the first use: one LDS latency, then per slot adds and its store
     if (!live) return;
