@@ -14,7 +14,7 @@ import strided_jl_amd as S  # noqa: E402
 from bench import colmajor_view, event_time_ms, graph_of  # noqa: E402
 
 perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
-DEFAULTS = {"orbit": 1, "orbit_lg": -1, "orbit_group": 2, "orbit_deal": 0, "orbit_pack": 1, "nt_store": -1}
+DEFAULTS = {"orbit": 1, "orbit_lg": -1, "orbit_group": 2, "orbit_deal": 0, "orbit_pack": 1, "nt_store": -1, "orbit_pair": 1}
 
 
 def cur():
@@ -32,7 +32,7 @@ for n in sizes:
     by = 2 * esz
     variants = [("default", {}), ("group 1", {"orbit_group": 1}), ("group 4", {"orbit_group": 4}), ("deal 1", {"orbit_deal": 1}),
                 ("group 4 deal 1", {"orbit_group": 4, "orbit_deal": 1}), ("nt stores", {"nt_store": 1}), ("pack 0", {"orbit_pack": 0}),
-                ("classic tiled", {"orbit": 0})]
+                ("pair form", {"orbit_pair": 2}), ("pair form, nt stores", {"orbit_pair": 2, "nt_store": 1}), ("classic tiled", {"orbit": 0})]
     if n % 8 == 0 and n <= 40:
         variants.insert(1, ("8^4 cubes", {"orbit_lg": 3}))
     if n % 4 == 0 and n > 40:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round-6 evidence files on the GPU box (profiles/README.md says what each one is).
 # Usage: bash tools/round_evidence_r06.sh [part ...]   parts: bench prof probe times sanity rehearsal tests (default: all but tests)
-# Writes gpurun_out/r06e/...; copied to profiles/r06_* afterwards.  Needs tools/bin/orbit32_probe{,_preload} (built on the CPU box:
+# Writes gpurun_out/r06e/...; copied to profiles/r06_* afterwards.  Needs tools/bin/orbit32_probe{,_preload} and tools/bin/orbit16_probe (built on the CPU box:
 #   hipcc -O3 -ffp-contract=off --offload-arch=gfx950 [-mllvm -amdgpu-kernarg-preload-count=16] tools/orbit32_probe.hip -o tools/bin/...)
 # and strided.jl_amd/libstrided_hip_stamp.so (make -C strided.jl_amd/csrc stamp) for the device-stamp parts.
 set -u
@@ -24,6 +24,7 @@ fi
 if has probe; then
   timeout 300 tools/bin/orbit32_probe > $O/orbit32_probe.txt 2>&1; echo "probe rc=$?"
   timeout 300 tools/bin/orbit32_probe_preload > $O/orbit32_probe_preload.txt 2>&1; echo "probe (preload build) rc=$?"
+  timeout 300 tools/bin/orbit16_probe > $O/orbit16_probe.txt 2>&1; echo "orbit16_probe rc=$?"
   timeout 600 python tools/orbit_pack_ab.py > $O/orbit_pack_ab.txt 2>&1
   timeout 600 python tools/cold_orbit_sweep.py 32 48 64 > $O/cold_orbit_sweep.txt 2>&1
 fi
@@ -34,6 +35,10 @@ if has times; then
 fi
 if has sanity; then
   timeout 600 python tools/perf_sanity.py > $O/perf_sanity.txt 2>/dev/null; head -3 $O/perf_sanity.txt | cut -c1-160
+  timeout 300 python tools/sum_cases.py > $O/sum_cases.txt 2>/dev/null
+  timeout 300 python tools/sum_cases.py reduce_col_exact=0 > $O/sum_cases_exact0.txt 2>/dev/null
+  timeout 300 python tools/ragged_cases.py > $O/ragged_tiles.txt 2>/dev/null
+  timeout 300 python tools/ragged_family_ab.py > $O/ragged_family_ab.txt 2>/dev/null
 fi
 if has rehearsal; then
   for n in 2 8; do
