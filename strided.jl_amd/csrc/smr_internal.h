@@ -323,7 +323,7 @@ struct Options {
                              // 5.60 -> 4.61 us, 24^4 3.41 -> 3.01 us; larger sizes keep the 8^4 cubes)
     i64 orbit_wgs = 0;       // persistent ORBIT form: cap on the number of workgroups (0 = as many as the machine holds at once)
     i64 orbit_lds_min = 0;   // experiment: request at least this much LDS per ORBIT workgroup (limits residency)
-    i64 orbit_pair = 1;      // 4^4 cubes of 8-byte elements: two orbits per workgroup, unit-axis neighbours in the lane pairs (64-byte runs in slot 0); 1: write-through launches only, 2: always
+    i64 orbit_pair = 1;      // 4^4 cubes of 8-byte elements: two orbits per workgroup, unit-axis neighbours in the lane pairs (64-byte runs in slot 0)
     i64 orbit_pack = 1;      // orbits with fewer distinct tiles than |G| share a workgroup (0: one workgroup per orbit, tiles repeated)
     i64 orbit_few = 40;      // fewer orbits than this even with the smallest admissible edge: classic tiled kernel
     i64 nt_store = -1;       // non-temporal stores: 0 never, 1 always, -1 = STREAM outputs of >= nt_stream_min bytes (default 0: all) and

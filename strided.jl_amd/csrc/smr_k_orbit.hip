@@ -457,7 +457,7 @@ SMR_DEV void orbit_map_body(const OrbitArgs a, const OrbitHead h, F f) {
 // Table: per workgroup 4 entries (one per slot j) of 8 words -- origin of set 0 / set 1 (element offsets; first word 0xffffffff:
 // idle), the own region words (16 bits per set: region << 8 | parity * 17), then for views 1..3 the region words of the cubes an
 // output of slot j reads that view from.
-template <class T, class F>
+template <class T, class F, int SMODE = -1>  // SMODE: store policy fixed at compile time (0 plain, 1 non-temporal, 2 write-through), -1: from the arguments
 SMR_DEV void orbit_pair_body(const OrbitArgs a, const OrbitHead h, F f) {
     constexpr int V = 2;
     typedef OVec<T, V> VT;
@@ -582,7 +582,14 @@ SMR_DEV void orbit_pair_body(const OrbitArgs a, const OrbitHead h, F f) {
             }
         }
     };
-    if (nts_flag == 2) {
+    if constexpr (SMODE == 0) {
+        outputs(IntC<0>{});
+    } else if constexpr (SMODE == 1) {
+        outputs(IntC<1>{});
+    } else if constexpr (SMODE == 2) {
+        if constexpr (has_wt_store<VT>::value) outputs(IntC<2>{});
+        self_release_wait();
+    } else if (nts_flag == 2) {
         if constexpr (has_wt_store<VT>::value) outputs(IntC<2>{});
         self_release_wait();
     } else if (nts_flag) {
@@ -593,7 +600,7 @@ SMR_DEV void orbit_pair_body(const OrbitArgs a, const OrbitHead h, F f) {
 }
 
 #ifndef SMR_JIT
-template <class T, class F>
+template <class T, class F, int SMODE>
 __global__ void __launch_bounds__(256) k_orbit_pair(const uint32_t* list, const char* src, char* dst, uint32_t eshp, uint32_t elenp, uint32_t es0, uint32_t es1,
                                                     uint32_t es2, uint32_t es3, uint32_t ntlog, const OrbitArgs a, F f SMR_STAMP_PARAM) {
     SMR_STAMP_BEGIN
@@ -608,7 +615,7 @@ __global__ void __launch_bounds__(256) k_orbit_pair(const uint32_t* list, const 
     h.estride[2] = es2;
     h.estride[3] = es3;
     h.ntlog = ntlog;
-    orbit_pair_body<T, F>(a, h, f);
+    orbit_pair_body<T, F, SMODE>(a, h, f);
     SMR_STAMP_END
 }
 
@@ -943,12 +950,19 @@ static int go_pair(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
     const size_t lds = 8 * (sizeof(T) << 8);
     if (jit_no_launch()) return SMR_OK;
     clear_sticky_error();
-    auto kern = k_orbit_pair<T, F>;
     mark_sliceable(2, 0u, (unsigned)(4 * 8 * sizeof(uint32_t)));  // one table row (four entries) per workgroup; the pointer is parameter 0
     if (a.nts == 2) mark_self_released();
     const OrbitHead h = orbit_head(a);
-    SMR_LAUNCH(kern, dim3(grid), dim3(block), lds, s, h.list, h.src, h.dst, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3], h.ntlog, a,
-               f SMR_STAMP_ARG(grid, block));
+    // one kernel per store policy: no branch on a kernel argument between the exchange and the stores
+    if (a.nts == 2)
+        SMR_LAUNCH((k_orbit_pair<T, F, 2>), dim3(grid), dim3(block), lds, s, h.list, h.src, h.dst, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3],
+                   h.ntlog, a, f SMR_STAMP_ARG(grid, block));
+    else if (a.nts)
+        SMR_LAUNCH((k_orbit_pair<T, F, 1>), dim3(grid), dim3(block), lds, s, h.list, h.src, h.dst, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3],
+                   h.ntlog, a, f SMR_STAMP_ARG(grid, block));
+    else
+        SMR_LAUNCH((k_orbit_pair<T, F, 0>), dim3(grid), dim3(block), lds, s, h.list, h.src, h.dst, h.eshp, h.elenp, h.estride[0], h.estride[1], h.estride[2], h.estride[3],
+                   h.ntlog, a, f SMR_STAMP_ARG(grid, block));
     return check_launch("k_orbit_pair");
 }
 
@@ -976,13 +990,12 @@ static int go2(const Plan& plan, hipStream_t s, F f, const OpTab& tab) {
         if (o.pdim[1][d] != d) own0 = false;
     if constexpr (!is_jit<F>::value && V == 2 && NREP == 1 && sizeof(T) == 8) {
         if constexpr (F::NIN >= 2 && F::NIN <= 4) {
-            // Taken for WRITE-THROUGH launches (store policy 2: recorded sequences, eager calls on library-owned streams): there every
-            // store travels to the memory side on its own and 64-byte pieces pay -- replay of the 4-way sum at 32^4 4.72 -> 4.42 us
-            // on one queue, 3.66 -> 3.21 cut in two, bench step 5.65 -> 5.36 us.  With plain stores (HIP launches) the two forms have
-            // the same span (3.0 us) and the one-orbit form the shorter launch-to-launch time (4.43 against 4.74 us in a hipGraph):
-            // it stays.  orbit_pair = 2 forces this form everywhere (tests, tools/orbit_pack_ab.py).
-            const bool wt = has_wt_store<OVec<T, V>>::value && (options().nt_store == 2 || want_self_release(plan));
-            if (o.pair_ok && own0 && o.ng == 4 && plan.c.M - 1 == F::NIN && (options().orbit_pair >= 2 || (options().orbit_pair == 1 && wt)))
+            // Write-through launches (store policy 2: recorded sequences, eager calls on library-owned streams) gain most -- every store
+            // travels to the memory side on its own and 64-byte pieces pay: replay of the 4-way sum at 32^4 4.72 -> 4.31 us on one queue,
+            // 3.66 -> 3.04 cut in two, bench step 5.65 -> 5.2 us -- plain-store launches through HIP 4.40 -> 4.27 us.  (With the first
+            // work list -- an orbit's smallest tile paired with whatever sat next to it -- the form LOST through HIP, 4.72 us: the list
+            // matters as much as the kernel, smr_plan.cpp.)  orbit_pair = 0 switches the form off (tests, tools/cold_orbit_sweep.py).
+            if (o.pair_ok && own0 && o.ng == 4 && plan.c.M - 1 == F::NIN && options().orbit_pair >= 1)
                 return go_pair<T, F>(plan, s, f, tab);
         }
     }

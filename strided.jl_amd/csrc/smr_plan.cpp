@@ -1095,45 +1095,54 @@ static bool plan_orbit(const Canon& c, OrbitPlan& o) {
             uint64_t stdmap = 0;
             for (int g = 0; g < NS; ++g)
                 for (int k = 1; k < c.M; ++k) stdmap |= (uint64_t)o.slot[g][k] << field(g, k - 1);
-            std::vector<size_t> loose;
-            for (size_t i = 0; i < wgs.size(); ++i) {
-                if (used[i]) continue;
-                int j = -1;
-                uint32_t nb = 0;
-                if (wg_full[i]) {
-                    const uint32_t a0 = wgs[i].tile[0], c0 = (uint32_t)(a0 % o.ntiles[0]);
-                    if ((i64)(c0 ^ 1u) < o.ntiles[0]) {
-                        nb = a0 - c0 + (c0 ^ 1u);
-                        j = owner[nb];
-                    }
-                }
-                if (j < 0 || (size_t)j == i || used[(size_t)j]) {
-                    loose.push_back(i);
-                    used[i] = 1;
-                    continue;
-                }
-                // set 1 = the neighbour's orbit, re-based so that ITS slot 0 is the neighbour tile
-                i64 nc[MAXN], id = nb;
+            // the slot sets of an orbit re-based at tile `id`: slot g = g_g . id (any tile of a full orbit can be its slot 0)
+            auto rebased = [&](uint32_t id0, uint32_t* bt) {
+                i64 nc[MAXN], id = id0;
                 for (int d = 0; d < c.N; ++d) {
                     nc[d] = id % o.ntiles[d];
                     id /= o.ntiles[d];
                 }
-                uint32_t bt[MAXG];
                 for (int g = 0; g < NS; ++g) {
                     i64 v = 0;
                     for (int d = 0; d < c.N; ++d) v += nc[d] * tmul[G[g][d]];
                     bt[g] = (uint32_t)v;
                 }
-                // set 0 = the lower half of the 64-byte run (lane pairs then run through ascending addresses)
-                if ((wgs[i].tile[0] % o.ntiles[0]) & 1) {
-                    push_set(bt, stdmap);
-                    push_set(wgs[i].tile, wgs[i].map);
-                } else {
-                    push_set(wgs[i].tile, wgs[i].map);
-                    push_set(bt, stdmap);
+            };
+            // super-cell by super-cell, in the cell's own tile order: the tile with an even unit-axis coordinate and its neighbour, both
+            // taken as slot 0 of their orbits -- the eight pairs of a super-cell then run back to back on one XCD and cover its four
+            // rotated images completely (pairing an orbit's smallest tile with whatever sits next to it scattered the pairs: 4.72 us
+            // per launch against 4.27 with this list, tools/orbit16_probe.hip)
+            for (i64 cell = 0; cell < cells; ++cell) {
+                i64 cc[MAXN], r = cell;
+                for (int d = 0; d < c.N; ++d) {
+                    cc[d] = r % ncell[d];
+                    r /= ncell[d];
                 }
-                used[i] = used[(size_t)j] = 1;
+                for (int q = 0; q < nsub; ++q) {
+                    i64 t[MAXN];
+                    int qq = q;
+                    bool inside = true;
+                    for (int d = 0; d < c.N; ++d) {
+                        t[d] = cc[d] * sub[d] + qq % sub[d];
+                        qq /= sub[d];
+                        if (t[d] >= o.ntiles[d]) inside = false;
+                    }
+                    if (!inside || (t[0] & 1) || t[0] + 1 >= o.ntiles[0]) continue;
+                    i64 id = 0;
+                    for (int d = 0; d < c.N; ++d) id += t[d] * tmul[d];
+                    const int i = owner[(size_t)id], j = owner[(size_t)id + 1];  // (tmul[0] == 1: the unit-axis neighbour is id + 1)
+                    if (i < 0 || j < 0 || i == j || used[(size_t)i] || used[(size_t)j]) continue;
+                    uint32_t ta[MAXG], tb[MAXG];
+                    rebased((uint32_t)id, ta);
+                    rebased((uint32_t)id + 1, tb);
+                    push_set(ta, stdmap);
+                    push_set(tb, stdmap);
+                    used[(size_t)i] = used[(size_t)j] = 1;
+                }
             }
+            std::vector<size_t> loose;
+            for (size_t i = 0; i < wgs.size(); ++i)
+                if (!used[i]) loose.push_back(i);
             for (size_t q = 0; q < loose.size(); q += 2) {  // what found no neighbour (diagonals, packed orbits): any two
                 const Wg& a = wgs[loose[q]];
                 const Wg& b = wgs[q + 1 < loose.size() ? loose[q + 1] : loose[q]];  // an odd one out runs twice (same values stored twice)

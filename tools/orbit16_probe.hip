@@ -27,6 +27,12 @@
         }                                                                             \
     } while (0)
 
+// the PRODUCT's device body of the PAIR form, compiled into this probe (device parts only): same kernel code, the probe's work list
+#define SMR_JIT 1
+#define SMR_CT 1
+#include "../strided.jl_amd/csrc/smr_k_orbit.hip"
+#undef SMR_JIT
+
 typedef unsigned long long u64;
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u8v __attribute__((ext_vector_type(8)));
@@ -137,6 +143,22 @@ __global__ void __launch_bounds__(32 * NCW) k_sum16(const u8v* __restrict__ rows
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_product_pair(const uint32_t* list, const char* src, char* dst, uint32_t eshp, uint32_t elenp, uint32_t es0, uint32_t es1,
+                                                      uint32_t es2, uint32_t es3, uint32_t ntlog, const smr::OrbitArgs a) {
+    smr::OrbitHead h;
+    h.list = list;
+    h.src = src;
+    h.dst = dst;
+    h.eshp = eshp;
+    h.elenp = elenp;
+    h.estride[0] = es0;
+    h.estride[1] = es1;
+    h.estride[2] = es2;
+    h.estride[3] = es3;
+    h.ntlog = ntlog;
+    smr::orbit_pair_body<double, smr::FAdd4<double>>(a, h, smr::FAdd4<double>{});
 }
 
 struct Ctx {
@@ -365,7 +387,7 @@ int main(int argc, char** argv) {
         uint32_t* d_rows;
         CK(hipMalloc(&d_rows, rows.size() * 4));
         CK(hipMemcpy(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
-        auto launch = [&](hipStream_t s) {
+        std::function<void(hipStream_t)> launch = [&](hipStream_t s) {
             const u8v* r = reinterpret_cast<const u8v*>(d_rows);
 #define L(NCW, STO) hipLaunchKernelGGL((k_sum16<NCW, STO>), dim3(nwg), dim3(32 * NCW), 0, s, r, (const double*)dA, dC)
             if (ncw == 4) { if (sto == 2) L(4, 2); else if (sto) L(4, 1); else L(4, 0); }
@@ -373,6 +395,37 @@ int main(int argc, char** argv) {
             else { if (sto == 2) L(16, 2); else if (sto) L(16, 1); else L(16, 0); }
 #undef L
         };
+        // sto == 3 (8 cubes only): the product's orbit_pair_body on THIS work list (entries: orgA, orgB, own words, views 1..3)
+        uint32_t* d_prows = nullptr;
+        smr::OrbitArgs pa;
+        std::memset(&pa, 0, sizeof pa);
+        if (sto == 3) {
+            std::vector<uint32_t> pr(nwg * 4 * 8, 0u);
+            for (size_t w = 0; w < nwg; ++w)
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t* en = &rows[(w * 4 + j) * 8];
+                    uint32_t* o = &pr[(w * 4 + j) * 8];
+                    for (int q = 0; q < 6; ++q) o[q] = en[q];
+                }
+            CK(hipMalloc(&d_prows, pr.size() * 4));
+            CK(hipMemcpy(d_prows, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
+            pa.nin = 4;
+            pa.tilelog = 8;
+            pa.ntlog = 8;
+            for (int j = 0; j < 4; ++j) {
+                pa.esh[j] = 2 * j;
+                pa.elen[j] = 2;
+            }
+            pa.estride[0] = 8; pa.estride[1] = 8 * 32; pa.estride[2] = 8 * 1024; pa.estride[3] = 8 * 32768;
+            for (int k = 1; k < 4; ++k)
+                for (int j = 0; j < 4; ++j) pa.lsh[k][j] = 2 * ((j - k + 4) & 3);
+        }
+        auto launch0 = launch;
+        auto launchp = [&](hipStream_t s) {
+            hipLaunchKernelGGL(k_product_pair, dim3(nwg), dim3(256), 16384, s, (const uint32_t*)d_prows, (const char*)dA, (char*)dC, 0x06040200u, 0x02020202u, 8u, 256u, 8192u,
+                               262144u, 8u, pa);
+        };
+        if (sto == 3) launch = launchp;
         CK(hipMemset(dC, 0, NE * 8));
         launch(c.st);
         CK(hipStreamSynchronize(c.st));
@@ -387,6 +440,11 @@ int main(int argc, char** argv) {
             const double* a = cold_A[turn % NP];
             double* cc = cold_C[turn % NP];
             ++turn;
+            if (sto == 3) {
+                hipLaunchKernelGGL(k_product_pair, dim3(nwg), dim3(256), 16384, s, (const uint32_t*)d_prows, (const char*)a, (char*)cc, 0x06040200u, 0x02020202u, 8u, 256u,
+                                   8192u, 262144u, 8u, pa);
+                return;
+            }
 #define L(NCW, STO) hipLaunchKernelGGL((k_sum16<NCW, STO>), dim3(nwg), dim3(32 * NCW), 0, s, r, a, cc)
             if (ncw == 4) { if (sto == 2) L(4, 2); else if (sto) L(4, 1); else L(4, 0); }
             else if (ncw == 8) { if (sto == 2) L(8, 2); else if (sto) L(8, 1); else L(8, 0); }
@@ -395,7 +453,7 @@ int main(int argc, char** argv) {
         }, 180, 5);
         char buf[200];
         std::snprintf(buf, sizeof buf, "%2d cubes per workgroup (%4zu wgs x %3d lanes), %s, %s; cube pairs forming 64-B runs %ld of %zu [%s]", ncw, nwg,
-                      32 * ncw, sto == 2 ? "reads first, store behind each cube's adds" : sto ? "per cube: reads, adds, store" : "stores last", deal ? "XCD-contiguous runs" : "list order", runs64,
+                      32 * ncw, sto == 3 ? "THE PRODUCT'S orbit_pair_body on this list" : sto == 2 ? "reads first, store behind each cube's adds" : sto ? "per cube: reads, adds, store" : "stores last", deal ? "XCD-contiguous runs" : "list order", runs64,
                       nwg * 4 * P, bad ? "WRONG" : "ok");
         report(buf, us);
         std::printf("      the same, HBM-cold (rotating over %d pairs of arrays): %7.3f us  frac %.3f\n", NP, us_cold, bytes / us_cold * 1e-3 / 8000.0);
@@ -407,5 +465,6 @@ int main(int argc, char** argv) {
             run(8, sto, deal);
             run(16, sto, deal);
         }
+    run(8, 3, 1);
     return 0;
 }

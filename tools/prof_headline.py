@@ -16,7 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=32)
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--which", default="both")
+ap.add_argument("--opt", action="append", default=[], help="name=value library option, may repeat")
 args = ap.parse_args()
+for kv in args.opt:
+    k, v = kv.split("=")
+    S.set_option(k, int(v))
 n = args.n
 fn = S.fn
 plans = {}
