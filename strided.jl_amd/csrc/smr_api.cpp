@@ -924,6 +924,7 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "reduce_row_floor") o.reduce_row_floor = value;
     else if (n == "reduce_row_dense") o.reduce_row_dense = value;
     else if (n == "flat2") o.flat2 = value;
+    else if (n == "flat_wide") o.flat_wide = value;
     else if (n == "flat2_bytes") o.flat2_bytes = value;
     else if (n == "flat2_lead_bytes") o.flat2_lead_bytes = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
@@ -1011,6 +1012,7 @@ int64_t smr_get_option(const char* name) {
     if (n == "reduce_row_floor") return o.reduce_row_floor;
     if (n == "reduce_row_dense") return o.reduce_row_dense;
     if (n == "flat2") return o.flat2;
+    if (n == "flat_wide") return o.flat_wide;
     if (n == "flat2_bytes") return o.flat2_bytes;
     if (n == "flat2_lead_bytes") return o.flat2_lead_bytes;
     if (n == "overlap_any" || n == "overlap_ordered" || n == "overlap_fences") {

@@ -186,7 +186,7 @@ struct FlatPlan {
     bool lshare = false;  // the line side is unit-stride along the SAME lead and continues along q (a transposition of R-element groups)
     bool fuse = false;  // the flat side's run continues along q itself (planar <-> interleaved): the R x TQ tile is one run
     bool ingroup[MAXN] = {false, false, false, false, false, false, false, false};
-    int32_t roff[64];  // line-side element offset of the leading index r
+    int32_t roff[128];  // line-side element offset of the leading index r (round 6: leads of up to 128 elements)
 };
 
 // Two-sided form of the FLAT family: BOTH sides' memory runs are short groups of leading dims (permutedims of (5,300,300,7)
@@ -274,6 +274,7 @@ struct Options {
     i64 reduce_part_wgs = 1024; // partial reductions with fewer workgroups than this are split until about this many run (4096 until
                                 // round 3: 512-1024 is as fast or faster on every shape of tools/reduce_sweep.py, with 4x fewer partials)
     i64 reduce_row_floor = -1;  // ROW form: least log2 lanes per output (-1 = planner's rule)
+    i64 flat_wide = 1;          // one-sided FLAT form for whole rows of 65..128 elements that are not a multiple of the 128-byte line: 1 = matrices of 32 MiB and more, 2 = wherever it applies
     i64 flat2 = 1;              // two-sided FLAT form (both sides' runs are short leading dims): on / off
     i64 flat2_pair = 1;         // two-sided FLAT form: move pairs of elements where a row's parity allows (4- / 8-byte element types)
     i64 flat2_bytes = 384;      // ... target bytes of a run

@@ -21,7 +21,8 @@
 
 namespace smr {
 
-constexpr int FLAT_MAXR = 64;
+constexpr int FLAT_MAXR = 64;    // two-sided form: entries per offset table
+constexpr int FLAT_MAXR1 = 128;  // one-sided form (round 6: whole rows of up to 128 elements whose byte length is not a multiple of the 128-byte line)
 
 struct FlatArgs {
     OpTab ops;
@@ -38,7 +39,7 @@ struct FlatArgs {
     i64 dimp, dimq;                       // extents of p (1 when p < 0) and q
     i64 sfq, slp;                         // flat-side stride of q, line-side stride of p
     i64 sfp;                              // flat-side stride of p (= R)
-    int32_t roff[FLAT_MAXR];              // line-side element offset of the leading index r
+    int32_t roff[FLAT_MAXR1];             // line-side element offset of the leading index r
     int32_t odim[MAXN];                   // outer dims (neither in the group nor p nor q)
     i64 oext[MAXN], osf[MAXN], osl[MAXN]; // their extents and flat- / line-side strides
 };

@@ -1493,7 +1493,16 @@ static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
         if (sf[d] == 1 && c.dims[d] > 1) lead = d;
     if (lead < 0) return false;
     const i64 e0 = c.dims[lead];
-    if (e0 * es >= 128 || (e0 & (e0 - 1)) == 0) return false;  // long or power-of-two leading dims: the tiled family's ground
+    // long or power-of-two leading dims: the tiled family's ground -- except (round 6, option flat_wide) whole rows of 65..128
+    // elements whose byte length is not a multiple of the 128-byte line: there every 256-byte tile row of TILED is three partial
+    // lines, while rows taken whole make the tile one contiguous, line-aligned piece of this side's memory
+    // Measured (tools/ragged_family_ab.py, profiles/r06_flat_wide_ab.txt): this form's phases are loops of dependent loads, so at
+    // 11 MiB it loses ((7200,100) 5.4 against 4.4 us) and it must not take leads of 65 elements away from the two-sided form
+    // ((257,129,65) 13.3 against 9.9 us); on tall matrices of 32 MiB and more (per array) it wins: (100,100000) Float32 23.2 -> 15.1 us,
+    // Float64 34.9 -> 28.5, (100000,100) Float32 21.9 -> 17.4.  flat_wide = 2 forces the form wherever it applies (tests).
+    const i64 fw = options().flat_wide;
+    const bool wide = fw && e0 * es >= 128 && e0 <= 128 && (e0 * es) % 128 != 0 && (fw >= 2 || (c.N == 2 && c.total * es >= ((i64)32 << 20)));
+    if ((e0 * es >= 128 && !wide) || (e0 & (e0 - 1)) == 0) return false;
     // unit axis of the line side: not the lead ...
     int q = -1;
     for (int d = 0; d < c.N; ++d)
@@ -1525,7 +1534,7 @@ static bool plan_flat_side(const Canon& c, FlatPlan& f, int side, int es) {
         p = nxt;
         break;
     }
-    if (R > 64) return false;
+    if (R > (wide ? 128 : 64)) return false;
     int tplog = 0;
     if (p >= 0)
         while ((R << tplog) * es < 256 && ((i64)1 << tplog) < c.dims[p] && (R << (tplog + 1)) <= 128) ++tplog;
@@ -2022,6 +2031,7 @@ int make_plan(const smr_problem* p, Plan& plan) {
                         if (util > best + 0.03) {
                             best = util;
                             btx = tx;
+                            if (util >= 0.9) break;  // the fewest segments that fill the workgroup: longer contiguous pieces per row
                         }
                     }
                     if (btx) {

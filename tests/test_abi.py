@@ -765,3 +765,44 @@ def test_round4_planner_rules_for_ragged_and_batched_shapes():
     d = S.make_plan(lambda x, y: x + y, None, None, (682, 682),
                     (B.sview(slice(0, 682), slice(0, 682)), A.sview(slice(0, 2046, 3), slice(0, 682)), A.permutedims((1, 0)).sview(slice(0, 682), slice(0, 2046, 3)))).describe()
     assert "family=tiled" in d, d
+
+
+def test_round6_planner_rules():
+    """Round 6: the ORBIT work list has a PAIR form for 4^4 cubes of 8-byte elements (two orbits per workgroup: half as many
+    workgroups, every one of them a whole number of orbits), not for Float32 or 8^4 cubes; COL reductions size their lane map to
+    the row when that fills the workgroup better; odd extents below 32 MiB stay in TILED (element-aligned vectors)."""
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+
+    def sum4(n, dt):
+        a = S.StridedView(np.zeros((n,) * 4, dtype=dt, order="F"))
+        c = S.StridedView(np.zeros((n,) * 4, dtype=dt, order="F"))
+        return S.make_plan(lambda w, x, y, z: w + x + y + z, None, None, a.size, (c,) + tuple(a.permutedims(p) for p in perms)).describe()
+
+    d = sum4(32, np.float64)
+    assert "family=orbit" in d and "tile=d0:4,d1:4,d2:4,d3:4" in d and "grid=1024" in d and "pair_grid=512" in d, d
+    assert "pair_grid=512" in sum4(32, np.complex64)
+    assert "pair_grid=" in sum4(24, np.float64) and "pair_grid=" in sum4(36, np.float64)   # 6 and 9 tiles per dim (an odd one out is fine)
+    assert "pair_grid=" not in sum4(32, np.float32)                                        # 4-byte elements: one orbit per workgroup
+    assert "tile=d0:8" in sum4(64, np.float64) and "pair_grid=" not in sum4(64, np.float64)  # 8^4 cubes
+    S.set_option("orbit_pair", 0)
+    try:
+        assert "pair_grid=" not in sum4(32, np.float64)
+    finally:
+        S.set_option("orbit_pair", 1)
+
+    def red(dims, rd, dt=np.float32):
+        a = S.StridedView(np.zeros(dims, dtype=dt, order="F"))
+        out = a.similar(size=tuple(1 if i in rd else n for i, n in enumerate(dims)))
+        return S.make_plan(lambda x: x, "+", "zero", dims, S.promoteshape(dims, out, a)).describe()
+
+    assert "lanes=25x10" in red((100, 90, 80, 7), (1, 2, 3)) and "lanes=50x5" in red((100, 90, 80, 7), (1, 2, 3), np.float64)
+    assert "lanes=" not in red((128, 90, 80), (1, 2))             # 128 Float32 = 32 vectors: the power of two is exact
+    assert "lanes=24x10" in red((96, 90, 80, 7), (1, 2, 3))       # 24 vectors: one segment of 24 lanes (94 %), not two of 12
+    assert "lanes=" not in red((100, 90, 80, 7), (3,))            # a reduction of 7 rows keeps "one lane walks them"
+    # a narrower power-of-two segment that puts a workgroup on every CU beats a split + second pass
+    assert "form=col lanes_per_out=32 split=1" in red((100, 90, 80, 7), (2, 3))
+    S.set_option("reduce_col_exact", 0)
+    try:
+        assert "lanes=" not in red((100, 90, 80, 7), (1, 2, 3))
+    finally:
+        S.set_option("reduce_col_exact", 1)

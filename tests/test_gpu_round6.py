@@ -225,3 +225,41 @@ def test_orbit_pair_form_runs_in_recorded_sequences():
     assert np.array_equal(host(B), np.transpose(a, (3, 2, 1, 0)))
     at = lambda p: np.transpose(a, p)
     assert np.array_equal(host(Cc), ((at(PERMS4[0]) + at(PERMS4[1])) + at(PERMS4[2])) + at(PERMS4[3]))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+@pytest.mark.parametrize("dims,perm", [((7200, 100), (1, 0)), ((100, 7200), (1, 0)), ((104, 3000), (1, 0)), ((100, 90, 80), (1, 0, 2)), ((100, 90, 80), (2, 1, 0)),
+                                       ((65, 129, 33), (2, 1, 0)), ((127, 1000), (1, 0)), ((1000, 127), (1, 0))])
+def test_flat_wide_rows_bit_exact(dims, perm, dt, option):
+    """One-sided FLAT form with whole rows of 65..128 elements (flat_wide = 2 forces it wherever it applies; the planner's own rule
+    takes it for matrices of 32 MiB and more): copies and an n-ary map, bit-identical to NumPy."""
+    rng = np.random.default_rng(sum(dims) + 3 * len(perm))
+    a = rng.integers(-999, 999, size=dims).astype(dt)
+    want = np.transpose(a, perm)
+    hit = 0
+    for fw in (2, 0):
+        option("flat_wide", fw)
+        A = dview(a)
+        B = dview(np.zeros(want.shape, dtype=dt))
+        plan = S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims(perm)))
+        plan.execute(cur())
+        sync()
+        assert np.array_equal(host(B), want), f"{dims} {perm} {dt.__name__} flat_wide={fw}: {plan.describe()}"
+        hit += int(fw == 2 and "family=flat" in plan.describe())
+        c0 = rng.integers(-9, 9, size=want.shape).astype(dt)
+        Cc = dview(c0)
+        plan = S.make_plan(lambda c, x: c + 2 * x, None, None, Cc.size, (Cc, Cc, A.permutedims(perm)))
+        plan.execute(cur())
+        sync()
+        assert np.array_equal(host(Cc), c0 + dt(2) * want), f"n-ary {dims} {perm} {dt.__name__} flat_wide={fw}: {plan.describe()}"
+    if dt != np.complex64 and dims in ((7200, 100), (127, 1000), (1000, 127)):
+        assert hit == 1, "flat_wide = 2 did not select the FLAT family"
+
+
+def test_flat_wide_is_planned_for_big_matrices_only():
+    def fam(dims, dt):
+        A = dview(np.zeros(dims, dtype=dt))
+        B = dview(np.zeros(dims[::-1], dtype=dt))
+        return S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims((1, 0)))).describe()
+    assert "family=flat" in fam((100, 200000), np.float32) and "run=100x1" in fam((100, 200000), np.float32)
+    assert "family=tiled" in fam((7200, 100), np.float64)
