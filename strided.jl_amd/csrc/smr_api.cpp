@@ -929,6 +929,8 @@ int smr_set_option(const char* name, int64_t value) {
     else if (n == "flat2_lead_bytes") o.flat2_lead_bytes = value;
     else if (n == "tiled_vec") o.tiled_vec = value;
     else if (n == "tiled_uavec") o.tiled_uavec = value;
+    else if (n == "tiled_force_edge") o.tiled_force_edge = value;
+    else if (n == "tiled_edge_first") o.tiled_edge_first = value;
     else if (n == "nt_stream_min") o.nt_stream_min = value;
     else if (n == "nt_store") o.nt_store = value;
     else if (n == "seq_self_release") o.seq_self_release = value;
@@ -1026,6 +1028,8 @@ int64_t smr_get_option(const char* name) {
     if (n == "jit_compile_ms") return (int64_t)jit_stats().compile_ms;
     if (n == "tiled_vec") return o.tiled_vec;
     if (n == "tiled_uavec") return o.tiled_uavec;
+    if (n == "tiled_force_edge") return o.tiled_force_edge;
+    if (n == "tiled_edge_first") return o.tiled_edge_first;
     if (n == "nt_stream_min") return o.nt_stream_min;
     if (n == "nt_store") return o.nt_store;
     if (n == "seq_self_release") return o.seq_self_release;

@@ -100,6 +100,9 @@ struct TiledArgs {
     uint32_t Lrd[EPL], Lhd[EPL];   // destination-order LDS index of repeat r / sub-element h
     i64 tstep[MAXM][MAXN];         // 64-bit tile steps (only read when !base32)
     // edge tiles only
+    uint32_t gflip, gflip_pad;        // bit g: grid coordinate g counts DOWN (ragged dims: their last, partly filled tiles start first)
+    int32_t ej_g[MAXT];               // per tiled dim j: its grid slot (-1: none), the index of its LAST tile and the valid elements in
+    uint32_t ej_ntm1[MAXT], ej_last[MAXT];  // that tile (round 6: one batch of scalar loads instead of a dependent chain through tgrid / gdims / glog)
     int32_t tgrid[MAXT], tlog[MAXT];  // grid dim / log2 extent of tiled dim j
     int32_t esh[MAXM][MAXT];          // bit position of tiled dim j in operand k's enumeration
     i64 gdims[MAXN];
@@ -222,6 +225,14 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
         tc[g] = b - q * a.ntiles[g];
         b = q;
     }
+    if constexpr (EDGE && !GENORG) {
+        // ragged grid dims run slowest and backwards: the workgroups of the partly filled last tiles -- the ones with bounds code on
+        // their path -- are the FIRST to start, and their longer lives end with everybody else's instead of after them
+        const uint32_t fl = a.gflip;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if ((fl >> g) & 1u) tc[g] = a.ntiles[g] - 1u - tc[g];
+    }
 #pragma unroll
     for (int g = NG; g < MAXN; ++g) tc[g] = 0;
     if (GENORG && a.ng > NG) {
@@ -238,7 +249,27 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
     uint32_t lim[MAXT];
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) lim[j] = 0x7fffffffu;
+    // Everything the bounds checks need from the kernel arguments is fetched HERE, unconditionally, with the first batch of scalar
+    // loads (round 6).  Fetched where it was used -- inside `if (edge)` -- it was a chain of ~15 dependent scalar-memory round trips
+    // in the workgroups of a ragged last tile, 1-2 us each: they finished that much after everybody else and set the launch's span
+    // (transposes of 7200 x 100 Float64: 4.4 us against 3.0 us for 7200 x 128, with a quarter of the workgroups nearly empty).
+    constexpr int KP = (NINMAX < 3 ? NINMAX : 3) + 1;  // operands whose enumeration shifts are pinned (destination + up to 3 inputs)
+    int gj[MAXT];
+    uint32_t ntm1[MAXT], lastn[MAXT], tlg[MAXT], eshp[KP][MAXT];
     if constexpr (EDGE) {
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+            gj[j] = __builtin_amdgcn_readfirstlane(a.ej_g[j]);
+            ntm1[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ej_ntm1[j]);
+            lastn[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ej_last[j]);
+            tlg[j] = (uint32_t)__builtin_amdgcn_readfirstlane(a.tlog[j]);
+            asm volatile("" : "+s"(gj[j]), "+s"(ntm1[j]), "+s"(lastn[j]), "+s"(tlg[j]));
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                eshp[k][j] = (uint32_t)__builtin_amdgcn_readfirstlane(a.esh[k][j]);
+                asm volatile("" : "+s"(eshp[k][j]));
+            }
+        }
         uint32_t emin = 0xffffffffu;  // 0 iff some grid coordinate sits on a ragged last tile
 #pragma unroll
         for (int g = 0; g < MAXN; ++g)
@@ -246,27 +277,34 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
         edge = emin == 0;
         if (edge) {
 #pragma unroll
-            for (int j = 0; j < MAXT; ++j)
-                if (j < a.nt && a.tgrid[j] >= 0) {
-                    const int g = a.tgrid[j];
-                    i64 left = a.gdims[g];
+            for (int j = 0; j < MAXT; ++j) {
+                uint32_t t = 0xffffffffu;
 #pragma unroll
-                    for (int gg = 0; gg < MAXN; ++gg)
-                        if (gg == g) left -= (i64)tc[gg] << a.glog[gg];
-                    lim[j] = (uint32_t)(left < 0x7fffffff ? left : 0x7fffffff);
-                }
+                for (int gg = 0; gg < MAXN; ++gg)
+                    if (gg == gj[j]) t = tc[gg];
+                if (gj[j] >= 0 && t == ntm1[j]) lim[j] = lastn[j];
+            }
         }
     }
+    const int ntd = a.nt;
     // how many of the V elements e .. e + V - 1 of operand k's enumeration lie inside the array (they differ in the coordinate at
     // bit 0): V or 0, or -- extent of the vector axis not a multiple of V -- something between in the last vector of a row
     auto in_count = [&](int k, uint32_t e) -> uint32_t {
         uint32_t cnt = V;
 #pragma unroll
         for (int j = 0; j < MAXT; ++j)
-            if (j < a.nt) {
-                const uint32_t cj = (e >> a.esh[k][j]) & ((1u << a.tlog[j]) - 1u);
+            if (j < ntd) {
+                uint32_t sh = 0, tl = 0;
+                if constexpr (EDGE) {
+                    tl = tlg[j];
+                    sh = (uint32_t)a.esh[k][j];
+#pragma unroll
+                    for (int kk = 0; kk < KP; ++kk)
+                        if (kk == k) sh = eshp[kk][j];
+                }
+                const uint32_t cj = (e >> sh) & ((1u << tl) - 1u);
                 if (cj >= lim[j]) cnt = 0;
-                else if (PV && V > 1 && a.esh[k][j] == 0) cnt = min(cnt, lim[j] - cj);
+                else if (PV && V > 1 && sh == 0) cnt = min(cnt, lim[j] - cj);
             }
         return cnt;
     };
@@ -284,178 +322,226 @@ SMR_DEV void tiled_map_body(const TiledArgs<WIDE> a, F f) {
         return (char*)a.op[k].base + o;
     };
 
-    // ---- phase A: issue EVERY global load of the tile before anything waits ------------------------
-    VT x[NINMAX > 0 ? NINMAX : 1][NREP];
-    uint32_t cntd[NREP];  // valid elements of repeat r in destination order (edge tiles: 0 .. V)
-#pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        cntd[r] = V;
-        if (edge) cntd[r] = in_count(0, (((uint32_t)r << THRLOG) | tid) << VLOG);
-    }
-#pragma unroll
-    for (int i = 0; i < NINMAX; ++i) {
-#pragma unroll
-        for (int r = 0; r < NREP; ++r)
-#pragma unroll
-            for (int h = 0; h < V; ++h) x[i][r].v[h] = T{};
-        if (i < nin) {
-            const OpDesc<WIDE>& d = a.op[i + 1];
-            const char* bp = tile_base(i + 1);
-            const bool stg = a.staged[i + 1] >= 0;
-#pragma unroll
-            for (int r = 0; r < NREP; ++r) {
-                uint32_t cn = cntd[r];
-                if (edge && stg) cn = in_count(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG);
-                if (PV && V > 1 && cn > 0 && cn < (uint32_t)V) {  // the partial vector at the end of a row: element by element
-                    const char* p = bp + (O)(row[i + 1].g + d.Gr[r]);
-#pragma unroll
-                    for (int h = 0; h < V; ++h)
-                        if ((uint32_t)h < cn) x[i][r].v[h] = load_at<T, MIXED>(p + h * sizeof(T), d.dtype, d.conj);
-                } else if (cn) {
-                    const char* p = bp + (O)(row[i + 1].g + d.Gr[r]);
-                    if constexpr (V == 1) {
-                        x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
-                    } else {
-#if SMR_TILED_NTL == 2  // experiment (A/B build): system-scope loads (sc0 sc1: served below the L2, which keeps its contents)
-                        {
-                            constexpr int NQ = (int)(sizeof(VT) / 8);
-                            uint64_t qw[NQ > 0 ? NQ : 1];
-#pragma unroll
-                            for (int w = 0; w < NQ; ++w)
-                                qw[w] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            __builtin_memcpy(&x[i][r], qw, sizeof(VT));
-                        }
-#elif SMR_TILED_NTL  // experiment (A/B build): non-temporal loads
-                        x[i][r] = load_vec_ct<true, VT>(p);
-#else
-                        {
-                            const GT gv = *reinterpret_cast<const GT*>(p);
-#pragma unroll
-                            for (int h = 0; h < V; ++h) x[i][r].v[h] = gv.v[h];
-                        }
-#endif
-                        if constexpr (tr<T>::cx) {
-                            if (d.conj) {
-#pragma unroll
-                                for (int h = 0; h < V; ++h) x[i][r].v[h] = cj(x[i][r].v[h]);
-                            }
-                        }
-                    }
-                }
-            }
+    // The body below exists twice in the bounds-checking variants (round 6): a workgroup of whole tiles runs the copy WITHOUT any
+    // bounds code (EDG = false) -- the ~90 extra instructions in front of its loads were 0.3 us per launch on whole tiles --, a
+    // workgroup on a ragged last tile the checked one.  `edge` is uniform over the workgroup: both copies keep their barrier.
+    auto body = [&](auto edge_c) {
+        constexpr bool EDG = EDGE && decltype(edge_c)::value;
+        // ---- phase A: issue EVERY global load of the tile before anything waits ------------------------
+        VT x[NINMAX > 0 ? NINMAX : 1][NREP];
+        uint32_t cnl[NINMAX > 0 ? NINMAX : 1][NREP];  // valid elements of input i's repeat r in ITS order (bounds-checking vector variants)
+        uint32_t cntd[NREP];  // valid elements of repeat r in destination order (edge tiles: 0 .. V)
+    #pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            cntd[r] = V;
+            if constexpr (EDG) cntd[r] = in_count(0, (((uint32_t)r << THRLOG) | tid) << VLOG);
         }
-    }
-    char* bp0 = tile_base(0);
-
-    // ---- phase B: staged inputs -> LDS, destination order, XOR-swizzled -----------------------------
-#pragma unroll
-    for (int i = 0; i < NINMAX; ++i) {
-        if (i < nin && a.staged[i + 1] >= 0) {
-            const OpDesc<WIDE>& d = a.op[i + 1];
-            T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
-#pragma unroll
-            for (int r = 0; r < NREP; ++r) {
-                bool ok = true;
-                if (edge) ok = in_count(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG) > 0;
-                if (ok) {
-#pragma unroll
-                    for (int h = 0; h < V; ++h) L[row[i + 1].l ^ d.Lr[r] ^ d.Lh[h]] = x[i][r].v[h];
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- phase C: read back in destination order, apply f, store ---------------------------------------
-#pragma unroll
-    for (int i = 0; i < NINMAX; ++i) {
-        if (i < nin && a.staged[i + 1] >= 0) {
-            const T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
-#pragma unroll
-            for (int r = 0; r < NREP; ++r) {
-                if (cntd[r]) {
-#pragma unroll
-                    for (int h = 0; h < V; ++h) x[i][r].v[h] = L[row[0].l ^ a.Lrd[r] ^ a.Lhd[h]];
-                }
-            }
-        }
-    }
-    VT out[NREP];
-#pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        if (cntd[r]) {
-#pragma unroll
-            for (int h = 0; h < V; ++h) {
-                T arg[MAXIN];
-#pragma unroll
-                for (int i = 0; i < MAXIN; ++i) {
-                    arg[i] = T{};
-                    if (i < NINMAX) arg[i] = x[i < NINMAX ? i : 0][r].v[h];
-                }
-                out[r].v[h] = f(arg);
-            }
-            if constexpr (V == 1) {
-                store_at<T, MIXED>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), a.op[0].dtype, a.op[0].conj, out[r].v[0]);
-            } else {
-                if constexpr (tr<T>::cx) {
-                    if (a.op[0].conj) {
-#pragma unroll
-                        for (int h = 0; h < V; ++h) out[r].v[h] = cj(out[r].v[h]);
-                    }
-                }
-            }
-        }
-    }
-    if constexpr (V > 1) {
-        // one wave-uniform branch around all vector stores (see smr_device.h:store_vec)
-        auto put = [&](auto NT) {
-#pragma unroll
+    #pragma unroll
+        for (int i = 0; i < NINMAX; ++i) {
+    #pragma unroll
             for (int r = 0; r < NREP; ++r)
-                if (cntd[r] == (uint32_t)V) {
-                    GT gv;
-#pragma unroll
-                    for (int h = 0; h < V; ++h) gv.v[h] = out[r].v[h];
-                    store_vec_ct<decltype(NT)::value, GT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), gv);
-                }
-        };
-        // the partial vector at the end of a row (edge tiles, extent of the vector axis not a multiple of V): element by element
-        auto put_partial_vecs = [&](auto WT) {
-            if constexpr (EDGE && PV) {
-#pragma unroll
-                for (int r = 0; r < NREP; ++r)
-                    if (cntd[r] > 0 && cntd[r] < (uint32_t)V) {
-#pragma unroll
-                        for (int h = 0; h < V; ++h)
-                            if ((uint32_t)h < cntd[r]) {
-                                char* p = bp0 + (O)(row[0].g + a.op[0].Gr[r]) + h * sizeof(T);
-                                if constexpr (decltype(WT)::value) {
-                                    TVec<T, 1> one;
-                                    one.v[0] = out[r].v[h];
-                                    store_vec_wt<TVec<T, 1>>(p, one);
-                                } else {
-                                    *reinterpret_cast<T*>(p) = out[r].v[h];
+    #pragma unroll
+                for (int h = 0; h < V; ++h) x[i][r].v[h] = T{};
+            if (i < nin) {
+                const OpDesc<WIDE>& d = a.op[i + 1];
+                const char* bp = tile_base(i + 1);
+                const bool stg = a.staged[i + 1] >= 0;
+    #pragma unroll
+                for (int r = 0; r < NREP; ++r) {
+                    uint32_t cn = cntd[r];
+                    if (EDG && stg) cn = in_count(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG);
+                    if constexpr (EDG && V > 1) {
+                        // Bounds-checking vector variant: the load itself is UNCONDITIONAL -- a lane outside the array reads the operand's
+                        // first vector (always there: the launcher requires an extent of at least V along the vector axis) and drops it.
+                        // Guarded by a branch per load, the compiler put an s_waitcnt vmcnt(0) in front of every one of them: a tile's
+                        // loads went out one memory round trip after the other, in EVERY workgroup of a ragged problem (+0.5 us on whole
+                        // tiles, profiles/r06_ragged_tiles.txt).  Partial vectors are patched up below, after all loads have been issued.
+                        const bool full = cn == (uint32_t)V;
+                        const char* p = full ? bp + (O)(row[i + 1].g + d.Gr[r]) : (const char*)d.base;
+                        const GT gv = *reinterpret_cast<const GT*>(p);
+    #pragma unroll
+                        for (int h = 0; h < V; ++h) x[i][r].v[h] = gv.v[h];  // (nothing may USE the value here: the next load must leave first;
+                        cnl[i][r] = cn;                                       //  what a lane outside the array holds is never stored)
+                    } else if (cn) {
+                        const char* p = bp + (O)(row[i + 1].g + d.Gr[r]);
+                        if constexpr (V == 1) {
+                            x[i][r].v[0] = load_at<T, MIXED>(p, d.dtype, d.conj);
+                        } else {
+    #if SMR_TILED_NTL == 2  // experiment (A/B build): system-scope loads (sc0 sc1: served below the L2, which keeps its contents)
+                            {
+                                constexpr int NQ = (int)(sizeof(VT) / 8);
+                                uint64_t qw[NQ > 0 ? NQ : 1];
+    #pragma unroll
+                                for (int w = 0; w < NQ; ++w)
+                                    qw[w] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __builtin_memcpy(&x[i][r], qw, sizeof(VT));
+                            }
+    #elif SMR_TILED_NTL  // experiment (A/B build): non-temporal loads
+                            x[i][r] = load_vec_ct<true, VT>(p);
+    #else
+                            {
+                                const GT gv = *reinterpret_cast<const GT*>(p);
+    #pragma unroll
+                                for (int h = 0; h < V; ++h) x[i][r].v[h] = gv.v[h];
+                            }
+    #endif
+                            if constexpr (tr<T>::cx) {
+                                if (d.conj) {
+    #pragma unroll
+                                    for (int h = 0; h < V; ++h) x[i][r].v[h] = cj(x[i][r].v[h]);
                                 }
                             }
+                        }
                     }
+                }
             }
-        };
-        if (a.nts == 2) {  // agent-scope write-through ("self-released" launch: smr_device.h)
-            if constexpr (has_wt_store<VT>::value) {
-#pragma unroll
-                for (int r = 0; r < NREP; ++r)
-                    if (cntd[r] == (uint32_t)V) store_vec_wt<VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
-                if constexpr (has_wt_store<TVec<T, 1>>::value) put_partial_vecs(BoolC<true>{});
-                self_release_wait();
-            }
-        } else if (a.nts) {
-            nt_block_guard();
-            put(BoolC<true>{});
-            nt_block_guard();
-            put_partial_vecs(BoolC<false>{});
-        } else {
-            put(BoolC<false>{});
-            put_partial_vecs(BoolC<false>{});
         }
+        if constexpr (EDG && V > 1 && tr<T>::cx) {  // conjugated inputs of the bounds-checking vector variants: behind all loads
+    #pragma unroll
+            for (int i = 0; i < NINMAX; ++i)
+                if (i < nin && a.op[i + 1].conj) {
+    #pragma unroll
+                    for (int r = 0; r < NREP; ++r)
+    #pragma unroll
+                        for (int h = 0; h < V; ++h) x[i][r].v[h] = cj(x[i][r].v[h]);
+                }
+        }
+        if constexpr (EDG && PV && V > 1) {  // the partial vector at the end of a row: element by element, behind the vector loads
+    #pragma unroll
+            for (int i = 0; i < NINMAX; ++i)
+                if (i < nin) {
+                    const OpDesc<WIDE>& d = a.op[i + 1];
+                    const char* bp = tile_base(i + 1);
+    #pragma unroll
+                    for (int r = 0; r < NREP; ++r)
+                        if (cnl[i][r] > 0 && cnl[i][r] < (uint32_t)V) {
+                            const char* p = bp + (O)(row[i + 1].g + d.Gr[r]);
+    #pragma unroll
+                            for (int h = 0; h < V; ++h)
+                                if ((uint32_t)h < cnl[i][r]) x[i][r].v[h] = load_at<T, MIXED>(p + h * sizeof(T), d.dtype, d.conj);
+                        }
+                }
+        }
+        char* bp0 = tile_base(0);
+
+        // ---- phase B: staged inputs -> LDS, destination order, XOR-swizzled -----------------------------
+    #pragma unroll
+        for (int i = 0; i < NINMAX; ++i) {
+            if (i < nin && a.staged[i + 1] >= 0) {
+                const OpDesc<WIDE>& d = a.op[i + 1];
+                T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
+    #pragma unroll
+                for (int r = 0; r < NREP; ++r) {
+                    bool ok = true;
+                    if constexpr (EDG && !(V > 1)) {  // (the vector variants park every lane's vector: a lane outside the array owns its own LDS slots)
+                        ok = in_count(i + 1, (((uint32_t)r << THRLOG) | tid) << VLOG) > 0;
+                    }
+                    if (ok) {
+    #pragma unroll
+                        for (int h = 0; h < V; ++h) L[row[i + 1].l ^ d.Lr[r] ^ d.Lh[h]] = x[i][r].v[h];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase C: read back in destination order, apply f, store ---------------------------------------
+    #pragma unroll
+        for (int i = 0; i < NINMAX; ++i) {
+            if (i < nin && a.staged[i + 1] >= 0) {
+                const T* L = lds + ((size_t)a.staged[i + 1] << a.tilelog);
+    #pragma unroll
+                for (int r = 0; r < NREP; ++r) {
+                    if ((EDG && V > 1) || cntd[r]) {
+    #pragma unroll
+                        for (int h = 0; h < V; ++h) x[i][r].v[h] = L[row[0].l ^ a.Lrd[r] ^ a.Lhd[h]];
+                    }
+                }
+            }
+        }
+        VT out[NREP];
+    #pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            if ((EDG && V > 1) || cntd[r]) {
+    #pragma unroll
+                for (int h = 0; h < V; ++h) {
+                    T arg[MAXIN];
+    #pragma unroll
+                    for (int i = 0; i < MAXIN; ++i) {
+                        arg[i] = T{};
+                        if (i < NINMAX) arg[i] = x[i < NINMAX ? i : 0][r].v[h];
+                    }
+                    out[r].v[h] = f(arg);
+                }
+                if constexpr (V == 1) {
+                    store_at<T, MIXED>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), a.op[0].dtype, a.op[0].conj, out[r].v[0]);
+                } else {
+                    if constexpr (tr<T>::cx) {
+                        if (a.op[0].conj) {
+    #pragma unroll
+                            for (int h = 0; h < V; ++h) out[r].v[h] = cj(out[r].v[h]);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (V > 1) {
+            // one wave-uniform branch around all vector stores (see smr_device.h:store_vec)
+            auto put = [&](auto NT) {
+    #pragma unroll
+                for (int r = 0; r < NREP; ++r)
+                    if (cntd[r] == (uint32_t)V) {
+                        GT gv;
+    #pragma unroll
+                        for (int h = 0; h < V; ++h) gv.v[h] = out[r].v[h];
+                        store_vec_ct<decltype(NT)::value, GT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), gv);
+                    }
+            };
+            // the partial vector at the end of a row (edge tiles, extent of the vector axis not a multiple of V): element by element
+            auto put_partial_vecs = [&](auto WT) {
+                if constexpr (EDG && PV) {
+    #pragma unroll
+                    for (int r = 0; r < NREP; ++r)
+                        if (cntd[r] > 0 && cntd[r] < (uint32_t)V) {
+    #pragma unroll
+                            for (int h = 0; h < V; ++h)
+                                if ((uint32_t)h < cntd[r]) {
+                                    char* p = bp0 + (O)(row[0].g + a.op[0].Gr[r]) + h * sizeof(T);
+                                    if constexpr (decltype(WT)::value) {
+                                        TVec<T, 1> one;
+                                        one.v[0] = out[r].v[h];
+                                        store_vec_wt<TVec<T, 1>>(p, one);
+                                    } else {
+                                        *reinterpret_cast<T*>(p) = out[r].v[h];
+                                    }
+                                }
+                        }
+                }
+            };
+            if (a.nts == 2) {  // agent-scope write-through ("self-released" launch: smr_device.h)
+                if constexpr (has_wt_store<VT>::value) {
+    #pragma unroll
+                    for (int r = 0; r < NREP; ++r)
+                        if (cntd[r] == (uint32_t)V) store_vec_wt<VT>(bp0 + (O)(row[0].g + a.op[0].Gr[r]), out[r]);
+                    if constexpr (has_wt_store<TVec<T, 1>>::value) put_partial_vecs(BoolC<true>{});
+                    self_release_wait();
+                }
+            } else if (a.nts) {
+                nt_block_guard();
+                put(BoolC<true>{});
+                nt_block_guard();
+                put_partial_vecs(BoolC<false>{});
+            } else {
+                put(BoolC<false>{});
+                put_partial_vecs(BoolC<false>{});
+            }
+        }
+    };
+    if constexpr (EDGE) {
+        if (edge) body(BoolC<true>{});
+        else body(BoolC<false>{});
+    } else {
+        body(BoolC<false>{});
     }
 }
 
@@ -975,6 +1061,25 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool ua 
     }
     for (int d = 0; d < c.N; ++d)  // (anything the planner's order left out: canonical order behind it)
         if (gof[d] < 0 && t.ntiles[d] > 1) gof[d] = ng++;
+    a.gflip = 0;
+    auto is_ragged = [&](int d) { return tlogdim[d] > 0 && (c.dims[d] & (((i64)1 << tlogdim[d]) - 1)) != 0; };
+    int nragged = 0;
+    for (int d = 0; d < c.N; ++d)
+        if (gof[d] >= 0 && is_ragged(d)) ++nragged;
+    // (measured with ONE ragged grid dim: transposes of (7200,104) 4.05 -> 3.23 us, (7168,100) 4.08 -> 3.72, (96,9000) 3.42 -> 3.21;
+    // with two -- (100,90,80) permutes -- a tie or a loss: those keep the planner's order.  tiled_edge_first = 2: whenever it applies)
+    if (EDGE && (MODE & 4) == 0 && t.ord.empty() && (options().tiled_edge_first >= 2 || (options().tiled_edge_first == 1 && nragged == 1))) {
+        // ragged dims to the slow end of the grid (stable), counted backwards
+        int order[MAXN], n2 = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int g = 0; g < ng; ++g)
+                for (int d = 0; d < c.N; ++d)
+                    if (gof[d] == g && (is_ragged(d) ? 1 : 0) == pass) order[n2++] = d;
+        for (int i = 0; i < n2; ++i) {
+            gof[order[i]] = i;
+            if (is_ragged(order[i])) a.gflip |= 1u << i;
+        }
+    }
     for (int g = 0; g < MAXN; ++g) {
         a.ntiles[g] = 1;
         a.div_m[g] = 0;
@@ -1009,6 +1114,17 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool ua 
             a.last_ragged[g] = 0;  // tc == 0 always
         }
         a.tgrid[j] = g;
+    }
+    for (int j = 0; j < MAXT; ++j) {
+        a.ej_g[j] = -1;
+        a.ej_ntm1[j] = 0;
+        a.ej_last[j] = 0x7fffffffu;
+        if (j < t.nt && a.tgrid[j] >= 0) {
+            const i64 ext = c.dims[t.tdim[j]], tile = (i64)1 << t.tlog[j], nt = (ext + tile - 1) / tile;
+            a.ej_g[j] = a.tgrid[j];
+            a.ej_ntm1[j] = (uint32_t)(nt - 1);
+            a.ej_last[j] = (uint32_t)(ext - (nt - 1) * tile);  // 1 .. tile (a whole last tile keeps every lane: lim = tile)
+        }
     }
     a.ng = ng;
     // 32-bit tile-origin arithmetic when every operand's tile origins stay below 4 GiB
@@ -1134,6 +1250,7 @@ static int go3(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool ua =
     // ragged extents: the lean kernel plus bounds checks in the workgroups that sit on a last, partly filled tile (round 6; every
     // ragged problem used to take variant 7 -- lane tables from memory, 64-bit origins, order lookups -- and paid ~2 us for it:
     // transposes of 7200 x 100 Float64 5.4 us against 3.0 us for 7200 x 128, profiles/r06_ragged_tiles.txt)
+    if (options().tiled_force_edge) ragged = true;  // experiment: the bounds-checking variant on whole tiles (what does the variant itself cost?)
     bool pv = false;  // does some operand's vector axis end in a partial vector?
     if constexpr (V > 1) {
         for (int k = 0; k < c.M; ++k) {
@@ -1163,7 +1280,7 @@ static bool vector_ok_ua(const Plan& plan, const OpTab& tab, int V) {
         const int j0 = staged ? t.order[k][0] : 0;
         const int d0 = t.tdim[j0];
         if (t.tlog[j0] < vlog) return false;
-        if (c.strides[k][d0] != 1) return false;
+        if (c.strides[k][d0] != 1 || c.dims[d0] < V) return false;
         if (((uintptr_t)tab.base[k]) % sizeof(T)) return false;
     }
     return true;
