@@ -138,14 +138,29 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
                 }
             }
         } else
-        for (int v = (int)tid; v < nvec; v += 256) {
-            const int j = (int)fdiv16((uint32_t)v, a.magicXV), x = (v - j * XV) * VL;
-            if (j < nj && x < nq) {
-                const uint32_t jp = fdiv16((uint32_t)j, a.magicR);
-                const int r = j - (int)jp * a.R;
-                const FVec<T, VL> t = *reinterpret_cast<const FVec<T, VL>*>(src + bl + a.roff[r] + (i64)jp * a.slp + x);
+        {   // four vectors per lane and round, loaded before the first LDS write (round 6; a slot outside the tile re-reads the
+            // tile's first vector and drops it)
+            constexpr int UB = 4;
+            const i64 safe = bl + a.roff[0];
+            for (int v0 = (int)tid; v0 < nvec; v0 += 256 * UB) {
+                FVec<T, VL> t[UB];
+                int at[UB];
 #pragma unroll
-                for (int e = 0; e < VL; ++e) lds[j * PITCH + x + e] = t.v[e];
+                for (int u = 0; u < UB; ++u) {
+                    const int v = v0 + u * 256;
+                    const int j = (int)fdiv16((uint32_t)v, a.magicXV), x = (v - j * XV) * VL;
+                    const bool ok = v < nvec && j < nj && x < nq;
+                    const uint32_t jp = fdiv16((uint32_t)(ok ? j : 0), a.magicR);
+                    const int r = (ok ? j : 0) - (int)jp * a.R;
+                    at[u] = ok ? j * PITCH + x : -1;
+                    t[u] = *reinterpret_cast<const FVec<T, VL>*>(src + (ok ? bl + a.roff[r] + (i64)jp * a.slp + x : safe));
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (at[u] >= 0) {
+#pragma unroll
+                        for (int e = 0; e < VL; ++e) lds[at[u] + e] = t[u].v[e];
+                    }
             }
         }
     } else {
@@ -163,12 +178,25 @@ SMR_DEV void flat_map_body(const FlatArgs a, F f) {
                 }
             }
         } else
-        for (int v = (int)tid; v < nvec; v += 256) {
-            const int x = (int)fdiv16((uint32_t)v, a.magicLv), j = (v - x * LV) * VF;
-            if (j < nj && x < nq) {
-                const FVec<T, VF> t = *reinterpret_cast<const FVec<T, VF>*>(src + bf + (i64)x * a.sfq + j);
+        {   // (four vectors per lane and round, as above)
+            constexpr int UB = 4;
+            for (int v0 = (int)tid; v0 < nvec; v0 += 256 * UB) {
+                FVec<T, VF> t[UB];
+                int at[UB];
 #pragma unroll
-                for (int e = 0; e < VF; ++e) lds[(j + e) * PITCH + x] = t.v[e];
+                for (int u = 0; u < UB; ++u) {
+                    const int v = v0 + u * 256;
+                    const int x = (int)fdiv16((uint32_t)v, a.magicLv), j = (v - x * LV) * VF;
+                    const bool ok = v < nvec && j < nj && x < nq;
+                    at[u] = ok ? j * PITCH + x : -1;
+                    t[u] = *reinterpret_cast<const FVec<T, VF>*>(src + (ok ? bf + (i64)x * a.sfq + j : bf));
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (at[u] >= 0) {
+#pragma unroll
+                        for (int e = 0; e < VF; ++e) lds[at[u] + e * PITCH] = t[u].v[e];
+                    }
             }
         }
     }
@@ -369,17 +397,33 @@ SMR_DEV void flat2_body(const Flat2Args a, F f) {
     }
     // phase 1: (x along the destination run) x (y along the input run), lanes along y; (x, y) advance by 256 positions per step
     {
+        // four positions per lane and round, all four loads issued before the first LDS write (round 6: one load, its wait, one
+        // write per round was a chain of dependent memory round trips -- 8 of them for a 31 x 65 tile); a position outside the tile
+        // re-reads the tile's first element and drops it
         const int dx = (int)fdiv16(256u, a.magicL[1]), dy = 256 - dx * L1;
         int x = (int)fdiv16(tid, a.magicL[1]), y = (int)tid - x * L1;
+        constexpr int UB = 4;
+        const i64 safe = bs + offs[0];
         while (x < L0) {
-            const int xc = xcol[x];
-            if (y < n1 && xc < n0) lds[y * PITCH + xc] = src[bs + y + offs[x]];
-            x += dx;
-            y += dy;
-            if (y >= L1) {
-                y -= L1;
-                ++x;
+            T v[UB];
+            int at[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int xs = x < L0 ? x : 0;
+                const int xc = xcol[xs];
+                const bool ok = x < L0 && y < n1 && xc < n0;
+                at[u] = ok ? y * PITCH + xc : -1;
+                v[u] = src[ok ? bs + y + offs[xs] : safe];
+                x += dx;
+                y += dy;
+                if (y >= L1) {
+                    y -= L1;
+                    ++x;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (at[u] >= 0) lds[at[u]] = v[u];
         }
     }
     __syncthreads();
