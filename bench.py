@@ -552,7 +552,7 @@ def main():
         import re
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_trace_stats.txt")))
         if cands:
-            want_k = ("k_orbit_map", "FAdd4") if dom[0] == "broadcast4" else ("k_tiled_map", "FIdent")
+            want_k = ("k_orbit_", "FAdd4") if dom[0] == "broadcast4" else ("k_tiled_map", "FIdent")  # (k_orbit_pair since round 6, k_orbit_map before)
             for line in open(cands[-1]):
                 f = line.split()
                 if len(f) >= 5 and f[0].isdigit() and all(w in line for w in want_k):

@@ -74,7 +74,7 @@ if args.rocprof and os.path.exists(args.rocprof):
     for line in open(args.rocprof):
         f = line.split()
         if len(f) >= 5 and f[0].isdigit():
-            if "k_orbit_map" in line and "FAdd4" in line:
+            if "k_orbit_" in line and "FAdd4" in line:
                 rows["4-way permuted sum"]["rocprofv3 --kernel-trace --stats average (HIP launch path), %s" % os.path.basename(args.rocprof)] = float(f[1]) / 1e3
             if "k_tiled_map" in line and "FIdent" in line:
                 rows["permutedims!(4,3,2,1)"]["rocprofv3 --kernel-trace --stats average (HIP launch path), %s" % os.path.basename(args.rocprof)] = float(f[1]) / 1e3

@@ -39,6 +39,7 @@ if has sanity; then
   timeout 300 python tools/sum_cases.py reduce_col_exact=0 > $O/sum_cases_exact0.txt 2>/dev/null
   timeout 300 python tools/ragged_cases.py > $O/ragged_tiles.txt 2>/dev/null
   timeout 300 python tools/ragged_family_ab.py > $O/ragged_family_ab.txt 2>/dev/null
+  timeout 300 python tools/row_stride_cases.py > $O/row_stride_cases.txt 2>/dev/null
 fi
 if has rehearsal; then
   for n in 2 8; do
