@@ -359,6 +359,12 @@ int64_t smr_plan_algorithmic_bytes(const smr_plan* plan);
  * appears exactly once, except that a group of order three repeats slot 0 in slot 3 and an incomplete last workgroup of
  * shared (diagonal) orbits repeats its slot 0.                                             */
 int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap);
+/* ORBIT family, PAIR form (4^4 cubes of 8-byte elements, a group of order four; `pair_grid` in smr_plan_describe): the work list
+ * the PAIR kernel walks -- EIGHT tiles per workgroup, out[w * 8 + b * 4 + g] = tile in slot g of the workgroup's slot set b
+ * (the first of an idle workgroup is 0xffffffff).  Every tile of the box appears exactly once (an odd set out repeats set 0);
+ * where the planner found it, set 1 is the orbit of set 0's unit-axis neighbour (tile + 1).  Returns the number of entries,
+ * 0 when the plan has no PAIR form.  No reference counterpart.                                                            */
+int64_t smr_plan_orbit_pairs(const smr_plan* plan, uint32_t* out, size_t cap);
 /* Introspection of the two-sided FLAT form (no reference counterpart): the two memory runs a tile is the product of, for the
  * planner tests (tests/test_abi.py walks every tile with these numbers on the CPU and checks that each element of the box is
  * moved exactly once, from the right place to the right place).  Returns the number of values the description has -- 0 when the

@@ -74,7 +74,7 @@ EXPORTS = [
     "smr_abi_version", "smr_init", "smr_shutdown", "smr_device_count", "smr_last_error",
     "smr_malloc", "smr_free", "smr_memcpy_h2d", "smr_memcpy_d2h", "smr_stream_sync",
     "smr_mapreduce", "smr_plan_create", "smr_plan_execute", "smr_plan_destroy",
-    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_plan_flat_batched", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank", "smr_comm_library",
+    "smr_plan_describe", "smr_plan_algorithmic_bytes", "smr_plan_tile_order", "smr_plan_orbit_pairs", "smr_plan_flat_runs", "smr_plan_flat_side", "smr_plan_flat_batched", "smr_mapreduce_scalar", "smr_plan_jit_compile", "smr_plan_jit_source", "smr_plan_prepare", "smr_comm_unique_id", "smr_comm_init", "smr_comm_rank", "smr_comm_library",
     "smr_comm_destroy", "smr_mapreduce_sharded", "smr_mapreduce_sharded_ex", "smr_shard", "smr_shard_ex", "smr_init_reduction", "smr_set_option",
     "smr_get_option", "smr_overlap_begin", "smr_overlap_end", "smr_overlap_fence", "smr_stream_create", "smr_stream_destroy",
     "smr_seq_create", "smr_seq_add", "smr_seq_run", "smr_seq_wait", "smr_seq_info", "smr_seq_components", "smr_seq_fences", "smr_seq_set", "smr_seq_destroy", "smr_debug_kernarg_layout", "smr_debug_canon_prog",
@@ -139,6 +139,8 @@ def load():
     lib.smr_mapreduce_scalar.argtypes = [C.c_void_p, C.c_void_p]
     lib.smr_plan_tile_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t]
     lib.smr_plan_tile_order.restype = C.c_int64
+    lib.smr_plan_orbit_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t]
+    lib.smr_plan_orbit_pairs.restype = C.c_int64
     lib.smr_plan_flat_runs.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_size_t]
     lib.smr_plan_flat_runs.restype = C.c_int64
     lib.smr_plan_flat_side.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_size_t]
@@ -354,6 +356,15 @@ class Plan:
             return []
         buf = (C.c_uint32 * n)()
         self._lib.smr_plan_tile_order(self._h, buf, n)
+        return list(buf)
+
+    def orbit_pairs(self):
+        """ORBIT, PAIR form: eight tiles per workgroup, [w * 8 + b * 4 + g] (empty list: the plan has no PAIR form)."""
+        n = int(self._lib.smr_plan_orbit_pairs(self._h, None, 0))
+        if n == 0:
+            return []
+        buf = (C.c_uint32 * n)()
+        self._lib.smr_plan_orbit_pairs(self._h, buf, n)
         return list(buf)
 
     def flat_runs(self):

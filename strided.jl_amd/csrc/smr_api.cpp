@@ -727,6 +727,14 @@ int64_t smr_plan_tile_order(const smr_plan* plan, uint32_t* out, size_t cap) {
     return (int64_t)ord.size();
 }
 
+int64_t smr_plan_orbit_pairs(const smr_plan* plan, uint32_t* out, size_t cap) {
+    if (!plan || plan->plan.family != FAM_ORBIT || !plan->plan.orbit.pair_ok) return 0;
+    const std::vector<uint32_t>& pt = plan->plan.orbit.ptile;
+    if (out)
+        for (size_t i = 0; i < pt.size() && i < cap; ++i) out[i] = pt[i];
+    return (int64_t)pt.size();
+}
+
 int64_t smr_plan_flat_runs(const smr_plan* plan, int64_t* out, size_t cap) {
     if (!plan || plan->plan.family != FAM_FLAT || !plan->plan.flat2.on || plan->plan.flatb.on) return 0;
     const Canon& c = plan->plan.c;

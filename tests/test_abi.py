@@ -806,3 +806,45 @@ def test_round6_planner_rules():
         assert "lanes=" not in red((100, 90, 80, 7), (1, 2, 3))
     finally:
         S.set_option("reduce_col_exact", 1)
+
+
+def test_orbit_pair_work_list_covers_every_tile_once():
+    """The PAIR form's work list (smr_plan_orbit_pairs): eight tiles per workgroup; every tile of the box exactly once; each slot set is
+    an orbit under the cyclic shift of the tile coordinates (slot g = the shift applied g times to slot 0); and in nearly all
+    workgroups set 1's slot 0 is the unit-axis neighbour of set 0's (that is what makes 64-byte runs)."""
+    perms = [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]
+    for n in (32, 24, 36):
+        a = S.StridedView(np.zeros((n,) * 4, dtype=np.float64, order="F"))
+        c = S.StridedView(np.zeros((n,) * 4, dtype=np.float64, order="F"))
+        plan = S.make_plan(lambda w, x, y, z: w + x + y + z, None, None, a.size, (c,) + tuple(a.permutedims(p) for p in perms))
+        lst = plan.orbit_pairs()
+        nt = n // 4
+        assert lst and len(lst) % 64 == 0, (n, len(lst))           # whole workgroups, a multiple of 8 of them (one run per XCD)
+        seen = np.zeros(nt ** 4, dtype=np.int64)
+        paired = live = 0
+
+        def coords(t):
+            return [(t // nt ** d) % nt for d in range(4)]
+
+        def tid(cs):
+            return sum(cc * nt ** d for d, cc in enumerate(cs))
+
+        for w in range(len(lst) // 8):
+            sets = [lst[w * 8 + b * 4:w * 8 + b * 4 + 4] for b in range(2)]
+            if sets[0][0] == 0xffffffff:
+                continue
+            live += 1
+            for b, st in enumerate(sets):
+                if b == 1 and st == sets[0]:
+                    continue                                          # an odd set out runs twice
+                for t in set(st):
+                    seen[t] += 1
+                # closed under the shift: with every tile a set holds all its cyclic shifts (one orbit of four tiles, or -- tiles on
+                # a diagonal -- several shorter orbits sharing the set)
+                for t in st:
+                    c0 = coords(t)
+                    assert {tid(c0[k:] + c0[:k]) for k in range(4)} <= set(st), (n, w, b, st)
+            if sets[1][0] == sets[0][0] + 1 and coords(sets[0][0])[0] % 2 == 0:
+                paired += 1
+        assert np.all(seen == 1), (n, int((seen != 1).sum()))
+        assert paired >= 0.85 * live, (n, paired, live)
