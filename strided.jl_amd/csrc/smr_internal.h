@@ -300,7 +300,7 @@ struct Options {
     i64 flatb = 1;              // FLAT family: batched form for contiguous small blocks (batched transposes of small matrices)
     i64 stream_pack_rows = 1;   // STREAM: rows of 129 .. 128*U vectors share a workgroup (U / ceil(n0v / 256) rows per lane) instead of one row segment per workgroup
     i64 tiled_vec = 1;       // 16-byte global accesses in the tiled family when alignment allows
-    i64 tiled_edge_first = 1; // ragged grid dims run slowest and backwards: partly filled last tiles start first
+    i64 tiled_edge_first = 1; // partly filled last tiles start first: one ragged grid dim runs slowest and backwards, several only backwards (2 / 3: one of the two forms always)
     i64 tiled_force_edge = 0; // experiment: run the bounds-checking variant of TILED even when every tile is whole
     i64 tiled_uavec = 1;     // ... and at element alignment (odd extents / row strides), partial vectors of ragged tiles element by element
     i64 orbit = 1;           // FAM_ORBIT for inputs that are permuted views of one buffer (0 = classic tiled kernel)

@@ -1068,7 +1068,12 @@ static int go3e(const Plan& plan, hipStream_t s, F f, const OpTab& tab, bool ua 
         if (gof[d] >= 0 && is_ragged(d)) ++nragged;
     // (measured with ONE ragged grid dim: transposes of (7200,104) 4.05 -> 3.23 us, (7168,100) 4.08 -> 3.72, (96,9000) 3.42 -> 3.21;
     // with two -- (100,90,80) permutes -- a tie or a loss: those keep the planner's order.  tiled_edge_first = 2: whenever it applies)
-    if (EDGE && (MODE & 4) == 0 && t.ord.empty() && (options().tiled_edge_first >= 2 || (options().tiled_edge_first == 1 && nragged == 1))) {
+    // ... with two or more they keep the planner's order and only count backwards ((257,129,65) 8.2 -> 7.8 us, (1400,1500) 6.6 -> 6.5;
+    // moved to the slow end as well: (300,301,35) 12.1 -> 13.1).  tiled_edge_first = 3: backwards only, 2: moved + backwards, always
+    if (EDGE && (MODE & 4) == 0 && t.ord.empty() && (options().tiled_edge_first == 3 || (options().tiled_edge_first == 1 && nragged >= 2))) {
+        for (int d = 0; d < c.N; ++d)
+            if (gof[d] >= 0 && gof[d] < NG && is_ragged(d)) a.gflip |= 1u << gof[d];
+    } else if (EDGE && (MODE & 4) == 0 && t.ord.empty() && (options().tiled_edge_first == 2 || (options().tiled_edge_first == 1 && nragged == 1))) {
         // ragged dims to the slow end of the grid (stable), counted backwards
         int order[MAXN], n2 = 0;
         for (int pass = 0; pass < 2; ++pass)
