@@ -247,6 +247,7 @@ struct Direct {
     // the call that noticed returns SMR_EHIP, and later executions go through HIP (direct().ok is false from then on).
     std::atomic<bool> failed{false};
     std::string fail_why;
+    std::mutex why_mu;                  // guards `why` / `fail_why` (written by whichever thread sees the failure, read by smr_seq_info and the planners of other threads: ADVICE r5)
     // kernarg layouts by code object (storage base address of the loaded image) and kernel-descriptor symbol
     std::map<uint64_t, std::map<std::string, KernargLayout>> code_objects;
     int n_meta = 0, n_v5 = 0;    // kernels resolved with a layout from metadata / from the v5 rule
@@ -310,14 +311,19 @@ double direct_timeout_s() {
 }
 
 void direct_fail(Direct& d, const std::string& why) {
-    const bool first = !d.failed.exchange(true) || d.fail_why.empty();
-    if (first) d.fail_why = why;
-    d.ok = false;
-    d.why = "direct dispatch failed earlier: " + d.fail_why;
+    std::string msg;
+    {
+        std::lock_guard<std::mutex> g(d.why_mu);
+        const bool first = !d.failed.exchange(true) || d.fail_why.empty();
+        if (first) d.fail_why = why;
+        d.ok = false;
+        d.why = "direct dispatch failed earlier: " + d.fail_why;
+        msg = d.fail_why;
+    }
     // a holding kernel on some HIP stream may be polling the replay's completion signals (asynchronous smr_seq_run): let it go
     for (int k = 0; k < SEQ_MAXQ; ++k)
         if (d.q[k] && d.done_ptr[k]) hsa().signal_store_relaxed(d.done[k], 0);
-    set_error(SMR_EHIP, "direct dispatch: " + d.fail_why);
+    set_error(SMR_EHIP, "direct dispatch: " + msg);
 }
 
 // Bounded wait for a completion signal.  false: the queue reported an error or NOTHING MOVED for the time limit -- the device's
@@ -668,7 +674,10 @@ int direct_selftest(Direct& d) {
     while (h.signal_wait(d.done[0], HSA_SIGNAL_CONDITION_EQ, 0, 200000, HSA_WAIT_STATE_ACTIVE) != 0) {
         if (d.failed.load() || now_s() - t0 > std::min(5.0, direct_timeout_s())) {
             d.failed.store(true);
-            d.fail_why = "the self-test packet did not complete";
+            {
+                std::lock_guard<std::mutex> g(d.why_mu);
+                d.fail_why = "the self-test packet did not complete";
+            }
             // the queue may still hold the packet: the buffers stay allocated (leaked on purpose)
             out = nullptr;
             kargs = nullptr;
@@ -1195,7 +1204,14 @@ int eager_fence_all() {
         (void)wait_all(d);  // a sequence replay submitted asynchronously (smr_seq_run) shares the queues
         if (d.failed.load() && !(was_failed && e.fail_reported)) {
             e.fail_reported = true;
-            rc = set_error(SMR_EHIP, "direct dispatch: " + (d.fail_why.empty() ? std::string("the HSA queue reported an error") : d.fail_why));
+            {
+                std::string fw;
+                {
+                    std::lock_guard<std::mutex> g(d.why_mu);
+                    fw = d.fail_why;
+                }
+                rc = set_error(SMR_EHIP, "direct dispatch: " + (fw.empty() ? std::string("the HSA queue reported an error") : fw));
+            }
         }
     }
     return rc;
@@ -1341,7 +1357,10 @@ int seq_build(smr_seq* q) {
     q->nsliced = 0;
     q->device = current_device();  // the plans' tables are uploaded (prepare pass below) on the calling thread's device
     Direct& d = direct_of(q->device);
-    if (!d.ok) q->why_not_aql = d.why;
+    if (!d.ok) {
+        std::lock_guard<std::mutex> g(d.why_mu);
+        q->why_not_aql = d.why;
+    }
     // 1. record every launch of every item (tables uploaded / scratch allocated by a prepare pass first)
     struct Rec {
         std::vector<RecLaunch> launches;
