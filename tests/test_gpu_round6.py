@@ -263,3 +263,26 @@ def test_flat_wide_is_planned_for_big_matrices_only():
         return S.make_plan(lambda x: x, None, None, B.size, (B, A.permutedims((1, 0)))).describe()
     assert "family=flat" in fam((100, 200000), np.float32) and "run=100x1" in fam((100, 200000), np.float32)
     assert "family=tiled" in fam((7200, 100), np.float64)
+
+
+@pytest.mark.parametrize("shape,perms", [
+    ((16, 16, 5, 16, 16), [(0, 1, 2, 3, 4), (1, 3, 2, 4, 0), (3, 4, 2, 0, 1), (4, 0, 2, 1, 3)]),   # a batch dim between the tiled ones
+    ((32, 32, 32, 32), [(0, 1, 2, 3), (3, 0, 1, 2), (2, 3, 0, 1), (1, 2, 3, 0)]),                   # the rotation the other way
+    ((32, 32, 32, 32), [(0, 1, 2, 3), (1, 0, 3, 2), (2, 3, 0, 1), (3, 2, 1, 0)]),                   # Klein four-group, not cyclic
+    ((20, 20, 20, 20), [(0, 1, 2, 3), (1, 2, 3, 0), (2, 3, 0, 1), (3, 0, 1, 2)]),                   # 5 tiles per dim: an odd one out
+    ((32, 32, 32, 32, 3), [(0, 1, 2, 3, 4), (1, 2, 3, 0, 4), (2, 3, 0, 1, 4), (3, 0, 1, 2, 4)])])  # trailing batch dim (8^4 cubes: no PAIR form)
+def test_orbit_pair_form_other_groups_and_batch_dims(shape, perms, option):
+    rng = np.random.default_rng(len(shape) + shape[0])
+    for dt in (np.float64, np.complex64):
+        a = rng.integers(-99, 99, size=shape).astype(dt)
+        want = None
+        for p in perms:
+            t = np.transpose(a, p)
+            want = t if want is None else want + t
+        for pair in (1, 0):
+            option("orbit_pair", pair)
+            A, Cc = dview(a), dview(np.zeros_like(a))
+            plan = S.make_plan(lambda w, x, y, z: w + x + y + z, None, None, A.size, (Cc,) + tuple(A.permutedims(p) for p in perms))
+            plan.execute(cur())
+            sync()
+            assert np.array_equal(host(Cc), want), f"{shape} {dt.__name__} orbit_pair={pair}: {plan.describe()}"
